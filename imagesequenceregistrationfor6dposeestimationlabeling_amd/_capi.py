@@ -1,0 +1,119 @@
+"""ctypes binding of libisr_hip.so (the C ABI declared in include/isr_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails this module raises.
+torch is imported first so that the library binds to the same libamdhip64 instance as torch —
+streams and device pointers are then shared.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import torch  # noqa: F401  (must be loaded before libisr_hip.so: shared HIP runtime)
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libisr_hip.so"
+
+ISR_OK = 0
+DTYPE_BF16 = 0
+DTYPE_F32 = 1
+
+
+class IsrError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp = C.c_void_p
+_i = C.c_int
+_sz = C.c_size_t
+_d = C.c_double
+_f = C.c_float
+_u64 = C.c_uint64
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header.
+SIGNATURES = {
+    "isr_abi_version": (_i, []),
+    "isr_last_error": (C.c_char_p, []),
+    "isr_device_count": (_i, []),
+    "isr_corr_argmax_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "isr_corr_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_corr_logsoftmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "isr_select_top_workspace_bytes": (_sz, [_i]),
+    "isr_select_top": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_gather_corr": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "isr_pnp_ransac_workspace_bytes": (_sz, [_i, _i]),
+    "isr_p3p_hypotheses": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp]),
+    "isr_ransac_score": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp]),
+    "isr_pnp_refine": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "isr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _f, _i, _vp, _vp, _vp, _vp, _vp,
+                            _sz, _vp]),
+    "isr_nn_batched_workspace_bytes": (_sz, [_i, _i, _i]),
+    "isr_nn_batched": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                            _sz, _vp]),
+    "isr_rel_pose_table": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libisr_hip.so (once).  Raises IsrError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise IsrError(
+            f"{LIB_PATH} is missing: build it with "
+            "`python -m imagesequenceregistrationfor6dposeestimationlabeling_amd.build` "
+            "(there is no CPU fallback)")
+    try:
+        L = C.CDLL(str(LIB_PATH))
+    except OSError as e:  # pragma: no cover
+        raise IsrError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise IsrError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if L.isr_abi_version() != 1:
+        raise IsrError(f"ABI version {L.isr_abi_version()} != 1")
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != ISR_OK:
+        msg = lib().isr_last_error()
+        raise IsrError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int | None:
+    """Device (or host) address of a tensor, None for None."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(*tensors) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise IsrError(
+                "libisr_hip operates on device tensors only (got a CPU tensor); "
+                "there is no CPU fallback")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise IsrError(f"tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise IsrError("no device tensor given")
+    return dev

@@ -1,0 +1,66 @@
+// isr_common.hpp — shared host-side plumbing for libisr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/isr_hip.h"
+
+namespace isr {
+
+// Thread-local text behind isr_last_error().
+char* last_error_buf();
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(isr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Launch check: hipGetLastError after a kernel launch, no synchronisation.
+#define ISR_CHECK_LAUNCH(what)                                                  \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      ::isr::set_error("%s: %s", what, hipGetErrorString(e__));                 \
+      return ISR_ERR_HIP;                                                       \
+    }                                                                           \
+  } while (0)
+
+#define ISR_CHECK_HIP(expr)                                                     \
+  do {                                                                          \
+    hipError_t e__ = (expr);                                                    \
+    if (e__ != hipSuccess) {                                                    \
+      ::isr::set_error("%s: %s", #expr, hipGetErrorString(e__));                \
+      return ISR_ERR_HIP;                                                       \
+    }                                                                           \
+  } while (0)
+
+#define ISR_REQUIRE(cond, ...)                                                  \
+  do {                                                                          \
+    if (!(cond)) {                                                              \
+      ::isr::set_error(__VA_ARGS__);                                            \
+      return ISR_ERR_ARG;                                                       \
+    }                                                                           \
+  } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Bump allocator over the caller's workspace; every carve is 256-byte aligned.
+struct Workspace {
+  char* base;
+  size_t size;
+  size_t off = 0;
+  Workspace(void* p, size_t n) : base(static_cast<char*>(p)), size(n) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off, 256);
+    T* p = reinterpret_cast<T*>(base + off);
+    off += count * sizeof(T);
+    return p;
+  }
+  bool ok() const { return off <= size; }
+};
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+}  // namespace isr

@@ -1,0 +1,156 @@
+/*
+ * isr_hip.h — C ABI of libisr_hip.so, the MI355X (gfx950) implementation of the
+ * image-sequence-registration hot path.
+ *
+ * The reference (Kudo510/ImageSequenceRegistrationfor6DPoseEstimationLabeling) has no FFI:
+ * its boundary is a handful of Python functions that call torch / OpenCV / Open3D / sklearn.
+ * Each entry point below replaces one of those library call sites; the citation is the
+ * reference file:line whose arithmetic the entry point takes over.  The Python mirror in
+ * imagesequenceregistrationfor6dposeestimationlabeling_amd/registration.py binds these with
+ * ctypes and keeps the reference's function names and signatures.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - nothing is allocated for the caller: scratch comes from `ws` (size from *_workspace_bytes);
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); no call synchronises;
+ *   - return value: ISR_OK or a negative ISR_ERR_*; isr_last_error() has the text;
+ *   - counts that are produced on the device (M, number of inliers, status) stay on the device
+ *     so a whole per-image pipeline can be enqueued without a host round trip.
+ */
+#ifndef ISR_HIP_H
+#define ISR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISR_ABI_VERSION 1
+
+#define ISR_OK 0
+#define ISR_ERR_ARG (-1)         /* bad shape / null pointer / unsupported value */
+#define ISR_ERR_WORKSPACE (-2)   /* ws_bytes smaller than *_workspace_bytes says */
+#define ISR_ERR_HIP (-3)         /* a HIP runtime call or launch failed */
+#define ISR_ERR_UNSUPPORTED (-4) /* valid request this build does not implement */
+
+#define ISR_DTYPE_BF16 0 /* bf16 inputs, v_mfma_f32_32x32x16_bf16, f32 accumulate */
+#define ISR_DTYPE_F32 1  /* f32 inputs, v_mfma_f32_32x32x2_f32: k-ordered fmaf chain, bit-exact */
+
+typedef void* isr_stream_t; /* hipStream_t */
+
+int isr_abi_version(void);
+const char* isr_last_error(void);
+/* Number of HIP devices visible to the library's runtime (0 on a CPU-only host, no error). */
+int isr_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  feature correlation: getCors(queries, feats, leaves=1)
+ * replaces  torch.log_softmax(queries @ feats.T, -1) + torch.topk(k=1)
+ *           inference.py:142-149 (= finalposes.py:38-45 = choosePose.py:35-42),
+ *           and the logsumexp-only use at pose_refine.py:56 (ask for `lse`).
+ * Q (P, ldq) and K (N, ldk) row-major, element type by `dtype`; the first D columns are used.
+ * D must be a multiple of 16 (bf16) / 2 (f32) and <= 256; ldq, ldk >= D and rows 16-byte aligned.
+ * Outputs, per query row p:
+ *   idx[p]  = argmax_n <Q[p],K[n]>   (lowest n on ties)
+ *   logp[p] = max_n logit - logsumexp_n logit   (= the top-1 value of log_softmax)
+ *   lse[p]  = logsumexp_n logit      (nullable)
+ * The (P x N) matrix is never materialised.
+ */
+size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype);
+int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk, int dtype,
+                    int32_t* idx, float* logp, float* lse, void* ws, size_t ws_bytes,
+                    isr_stream_t stream);
+
+/* K1 materialising variant for small P: out (P, N) f32 = log_softmax(Q K^T) row-wise.
+ * replaces poseEstSurf.py:70 (corr_matrix_log) and getCors with leaves > 1 (caller runs topk). */
+int isr_corr_logsoftmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
+                        int dtype, float* out, int64_t ldo, isr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * a2  top-80 % correspondence filter
+ * replaces  torch.sort(in1[:,0])[0][-perc+1] ; torch.where(in1[:,0] > thr)   inference.py:282-290
+ * n = P; if n > min_n: perc = (int)(frac*n), rank = n - perc + 1 else rank = 1  (0-based rank into
+ * the ascending order); thr = rank-th smallest logp; keep = ascending indices p with logp[p] > thr.
+ * keep has capacity P; *M_dev (device int32) receives the number kept; *thr_dev (nullable) thr.
+ */
+size_t isr_select_top_workspace_bytes(int P);
+int isr_select_top(const float* logp, int P, double frac, int min_n, int32_t* keep, int32_t* M_dev,
+                   float* thr_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
+
+/* a3  correspondence assembly  (inference.py:274-280, 289-290)
+ * p3d[m] = pts[idx[keep[m]]], p2d[m] = pix_xy[keep[m]]  for m < *M_dev.  pts (N,3), pix_xy (P,2)
+ * = (col,row) of every query pixel, both f32.  p3d (P,3) / p2d (P,2) have capacity P rows. */
+int isr_gather_corr(const int32_t* idx, const int32_t* keep, const int32_t* M_dev, int P,
+                    const float* pts, int N, const float* pix_xy, float* p3d, float* p2d,
+                    isr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  PnP + RANSAC:  pnp(h3d, h2d, cam, itr, reperr, P3P)
+ * replaces  cv2.solvePnPRansac(..., iterationsCount=itr, reprojectionError=reperr,
+ *           flags=SOLVEPNP_P3P) + cv2.Rodrigues      inference.py:123-134, call site :293
+ * (OpenCV is not available to this build: the algorithm is owned and documented in DESIGN.md.)
+ *
+ * isr_p3p_hypotheses: hypothesis h draws 4 correspondence indices from Philox4x32-10(seed, h),
+ *   solves P3P (f64) on the first three, keeps the root with the smallest reprojection error on
+ *   the fourth.  Rt (H,12) f64 row-major [R|t]; ok (H) u8; sample (H,4) i32 (nullable).
+ * isr_ransac_score: n_inl[h] = #{m : z>0 and |proj_h(p3d[m]) - p2d[m]|^2 <= reperr^2} in f32,
+ *   evaluated division-free; best_dev = argmax (lowest h on ties, ok hypotheses only),
+ *   best_mask = inlier bitmask of the best hypothesis, ceil(M_cap/32) words.
+ * isr_pnp_refine: `iters` Gauss-Newton steps (f64) on the reprojection error over the masked
+ *   correspondences, starting from Rt_io (12 f64), result written back.
+ * isr_pnp_ransac: the three above + inlier index compaction, one enqueue.
+ *   pose_dev: 12 f64 [R|t];  inl_idx: capacity M_cap;  n_inl_dev: i32;  status_dev: i32
+ *   (1 = pose found, 0 = failed: the Python mirror then returns the reference's (1,1,1)).
+ * Kcam: host pointer, 9 doubles row-major.
+ */
+size_t isr_pnp_ransac_workspace_bytes(int M_cap, int H);
+int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
+                       const double* Kcam, int H, uint64_t seed, double* Rt, uint8_t* ok,
+                       int32_t* sample, isr_stream_t stream);
+int isr_ransac_score(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
+                     const double* Kcam, const double* Rt, const uint8_t* ok, int H, float reperr,
+                     int32_t* n_inl, int32_t* best_dev, uint32_t* best_mask, isr_stream_t stream);
+int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
+                   const uint32_t* mask, const double* Kcam, int iters, double* Rt_io, void* ws,
+                   size_t ws_bytes, isr_stream_t stream);
+int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
+                   const double* Kcam, int H, uint64_t seed, float reperr, int refine_iters,
+                   double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev, int32_t* status_dev,
+                   void* ws, size_t ws_bytes, isr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3 / K4  batched brute-force nearest neighbour with fused reductions
+ * replaces  sklearn KDTree(...).query(k=1)                    inference.py:118-120 (ADD-S)
+ *           open3d compute_point_cloud_distance               verfication.py:97,99; icp.py:113,115
+ *           open3d evaluate_registration / registration_icp   icp.py:97-103 (one ICP iteration)
+ * For batch item b: queries  q' = Tq[b] * qry,  targets t' = Tt[b] * tgt  (3x4 row-major f64
+ * [R|t], NULL = identity; transformed in f64, rounded to f32 for the search).  For each query the
+ * nearest target under f32 squared distance (lowest index on ties); its distance is then
+ * re-evaluated in f64.  radius < 0: every query counts; else only queries with d <= radius.
+ * Outputs (all nullable except n_in or sum_d):
+ *   sum_d[b]  = sum of d over counted queries (f64)      n_in[b] = number counted
+ *   sum_d2[b] = sum of d^2
+ *   nn_idx[b*Nq+q] (-1 if not counted), nn_d[b*Nq+q] (f64 distance of the nearest target)
+ *   cov[b*16 + ..] = { sum q'(3), sum t'(3), sum q' t'^T (9, row-major), unused } over counted
+ *                     pairs — the Kabsch inputs of one point-to-point ICP step.
+ * Reductions use fixed-shape trees (no float atomics): results are run-to-run reproducible.
+ */
+size_t isr_nn_batched_workspace_bytes(int Nq, int Nt, int B);
+int isr_nn_batched(const float* qry, int Nq, const float* tgt, int Nt, const double* Tq,
+                   const double* Tt, int B, double radius, double* sum_d, double* sum_d2,
+                   int32_t* n_in, int32_t* nn_idx, double* nn_d, double* cov, void* ws,
+                   size_t ws_bytes, isr_stream_t stream);
+
+/* a10 / a12  relative-pose tables, rows [i0, i1) of the n x n table, written as (i1-i0, n, 12) f64.
+ * mode 0: compute_rel_poses       choosePose.py:43-51  ->  [R_i^T R_j | t_j - t_i]
+ * mode 1: calculate_relative_pose verfication.py:9-19  ->  [R_j|t_j] * inv([R_i|t_i])
+ * R (n,9), t (n,3) f64 device. */
+int isr_rel_pose_table(const double* R, const double* t, int n, int i0, int i1, int mode,
+                       double* out, isr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISR_HIP_H */

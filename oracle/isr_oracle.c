@@ -1,0 +1,237 @@
+/*
+ * isr_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Plain-C CPU restatement of the arithmetic of the image-sequence-registration hot path, used
+ * only by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as the checker for
+ * the HIP kernels.  Nothing under imagesequenceregistrationfor6dposeestimationlabeling_amd/
+ * may import, link or call it.
+ *
+ * What it restates (reference = /root/reference, read as text):
+ *   orc_corr_argmax_*   getCors: log_softmax(q @ f.T) + topk(1)      inference.py:142-149
+ *   orc_nn_batched      ADDS KDTree.query(k=1)                        inference.py:118-120
+ *                       compute_point_cloud_distance (Chamfer)        verfication.py:97-101, icp.py:113-117
+ *                       evaluate_registration / one registration_icp iteration   icp.py:97-103
+ *   orc_ransac_score    the inlier test inside cv2.solvePnPRansac     inference.py:125
+ *
+ * Pinning: the nearest-neighbour path is pinned against sklearn.neighbors.KDTree (the reference's
+ * own ADD-S call, importable here) and scipy cKDTree; the correlation path against the literal
+ * torch expression of getCors.  OpenCV and Open3D are absent from the image and the reference
+ * ships no tests or golden vectors, so the RANSAC scoring rule and the ICP loop are
+ * PARITY UNPINNED: they restate the documented behaviour of those libraries from memory.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off: every fma below is explicit, so the f32
+ * search order is the one the HIP kernels use and indices / masks compare bit for bit).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- rigid transform in f64: fma chain with the translation as the innermost addend ---- */
+static inline void xform64(const double* T, const float* p, double* o) {
+  const double x = p[0], y = p[1], z = p[2];
+  if (!T) {
+    o[0] = x; o[1] = y; o[2] = z;
+    return;
+  }
+  o[0] = fma(T[2], z, fma(T[1], y, fma(T[0], x, T[3])));
+  o[1] = fma(T[6], z, fma(T[5], y, fma(T[4], x, T[7])));
+  o[2] = fma(T[10], z, fma(T[9], y, fma(T[8], x, T[11])));
+}
+
+/*
+ * Batched brute-force 1-NN.  For batch b: q' = Tq[b] qry, t' = Tt[b] tgt (f64, then rounded to
+ * f32); search in f32 with d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)), strict '<' so the lowest index
+ * wins ties; the winner's distance is re-evaluated in f64 from the unrounded coordinates.
+ * Sums run in query order (the HIP kernel uses a tree: compare sums with a tolerance, per-query
+ * outputs bit for bit).
+ */
+void orc_nn_batched(const float* qry, int Nq, const float* tgt, int Nt, const double* Tq,
+                    const double* Tt, int B, double radius, double* sum_d, double* sum_d2,
+                    int32_t* n_in, int32_t* nn_idx, double* nn_d, double* cov) {
+  float* t32 = (float*)malloc(sizeof(float) * 3 * (size_t)Nt);
+  double* t64 = (double*)malloc(sizeof(double) * 3 * (size_t)Nt);
+  for (int b = 0; b < B; ++b) {
+    const double* tq = Tq ? Tq + 12 * (size_t)b : NULL;
+    const double* tt = Tt ? Tt + 12 * (size_t)b : NULL;
+    for (int j = 0; j < Nt; ++j) {
+      xform64(tt, tgt + 3 * (size_t)j, t64 + 3 * (size_t)j);
+      for (int c = 0; c < 3; ++c) t32[3 * (size_t)j + c] = (float)t64[3 * (size_t)j + c];
+    }
+    int32_t* bis = (int32_t*)malloc(sizeof(int32_t) * (size_t)Nq);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < Nq; ++i) {
+      double q64[3];
+      xform64(tq, qry + 3 * (size_t)i, q64);
+      const float qx = (float)q64[0], qy = (float)q64[1], qz = (float)q64[2];
+      float best = INFINITY;
+      int bi = -1;
+      for (int j = 0; j < Nt; ++j) {
+        const float dx = qx - t32[3 * (size_t)j], dy = qy - t32[3 * (size_t)j + 1],
+                    dz = qz - t32[3 * (size_t)j + 2];
+        const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (d2 < best) { best = d2; bi = j; }
+      }
+      bis[i] = bi;
+    }
+    double sd = 0.0, sd2 = 0.0, acc[16];
+    memset(acc, 0, sizeof acc);
+    int cnt = 0;
+    for (int i = 0; i < Nq; ++i) { /* sequential: sums in query order */
+      double q64[3];
+      xform64(tq, qry + 3 * (size_t)i, q64);
+      const int bi = bis[i];
+      double d = INFINITY, s = INFINITY;
+      int counted = 0;
+      if (bi >= 0) {
+        const double* t = t64 + 3 * (size_t)bi;
+        const double ex = q64[0] - t[0], ey = q64[1] - t[1], ez = q64[2] - t[2];
+        s = fma(ez, ez, fma(ey, ey, ex * ex));
+        d = sqrt(s);
+        counted = (radius < 0.0) || (s <= radius * radius);
+        if (counted) {
+          sd += d; sd2 += s; ++cnt;
+          for (int r = 0; r < 3; ++r) {
+            acc[r] += q64[r];
+            acc[3 + r] += t[r];
+            for (int c = 0; c < 3; ++c) acc[6 + 3 * r + c] += q64[r] * t[c];
+          }
+        }
+      }
+      if (nn_idx) nn_idx[(size_t)b * Nq + i] = counted ? bi : -1;
+      if (nn_d) nn_d[(size_t)b * Nq + i] = d;
+    }
+    free(bis);
+    if (sum_d) sum_d[b] = sd;
+    if (sum_d2) sum_d2[b] = sd2;
+    if (n_in) n_in[b] = cnt;
+    if (cov) memcpy(cov + 16 * (size_t)b, acc, sizeof acc);
+  }
+  free(t32);
+  free(t64);
+}
+
+/*
+ * getCors, f32 inputs: logit[p][n] = k-ordered fmaf chain from 0 (what v_mfma_f32_32x32x2_f32
+ * computes bit for bit); argmax with lowest-index ties; lse in f64 from the f32 logits.
+ * top2 (nullable) receives the runner-up logit, so a test can report the margin of a mismatch.
+ */
+void orc_corr_argmax_f32(const float* Q, const float* K, int P, int N, int D, int ldq, int ldk,
+                         int32_t* idx, float* maxlogit, double* lse, float* top2) {
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < P; ++p) {
+    const float* q = Q + (size_t)p * ldq;
+    float m = -INFINITY, m2 = -INFINITY;
+    int bi = -1;
+    float* row = (float*)malloc(sizeof(float) * (size_t)N);
+    for (int n = 0; n < N; ++n) {
+      const float* k = K + (size_t)n * ldk;
+      float acc = 0.0f;
+      for (int d = 0; d < D; ++d) acc = fmaf(q[d], k[d], acc);
+      row[n] = acc;
+      if (acc > m) { m2 = m; m = acc; bi = n; }
+      else if (acc > m2) m2 = acc;
+    }
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += exp((double)row[n] - (double)m);
+    free(row);
+    idx[p] = bi;
+    if (maxlogit) maxlogit[p] = m;
+    if (lse) lse[p] = (double)m + log(s);
+    if (top2) top2[p] = m2;
+  }
+}
+
+static inline float bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+/*
+ * getCors, bf16 inputs (uint16 bit patterns).  bf16 x bf16 products are exact in f32/f64; the
+ * MFMA's internal summation order is not documented, so the oracle sums in f64 (error ~1e-16)
+ * and the test allows an index mismatch only where the f64 margin top1-top2 is below the f32
+ * accumulation noise.  maxlogit/top2/lse are f64.
+ */
+void orc_corr_argmax_bf16(const uint16_t* Q, const uint16_t* K, int P, int N, int D, int ldq,
+                          int ldk, int32_t* idx, double* maxlogit, double* lse, double* top2) {
+#pragma omp parallel for schedule(static)
+  for (int p = 0; p < P; ++p) {
+    const uint16_t* q = Q + (size_t)p * ldq;
+    double m = -INFINITY, m2 = -INFINITY;
+    int bi = -1;
+    double* row = (double*)malloc(sizeof(double) * (size_t)N);
+    float qf[256];
+    for (int d = 0; d < D; ++d) qf[d] = bf16_to_f32(q[d]);
+    for (int n = 0; n < N; ++n) {
+      const uint16_t* k = K + (size_t)n * ldk;
+      double acc = 0.0;
+      for (int d = 0; d < D; ++d) acc += (double)qf[d] * (double)bf16_to_f32(k[d]);
+      row[n] = acc;
+      if (acc > m) { m2 = m; m = acc; bi = n; }
+      else if (acc > m2) m2 = acc;
+    }
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += exp(row[n] - m);
+    free(row);
+    idx[p] = bi;
+    if (maxlogit) maxlogit[p] = m;
+    if (lse) lse[p] = m + log(s);
+    if (top2) top2[p] = m2;
+  }
+}
+
+/*
+ * RANSAC hypothesis scoring.  Pm = Kcam [R|t] in f64 (fma order below) rounded to f32; per
+ * correspondence the camera-frame homogeneous point is an fmaf chain with the translation
+ * innermost; the inlier test is division-free:
+ *     z > 0  and  (x - u z)^2 + (y - v z)^2 <= (reperr z)^2        (all f32, explicit fmaf)
+ * best = argmax n_inl over ok hypotheses, lowest h on ties, -1 if none is ok.
+ */
+static void proj_matrix_f32(const double* Kc, const double* Rt, float* Pm) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c)
+      Pm[4 * r + c] = (float)fma(Kc[3 * r + 2], Rt[8 + c],
+                                 fma(Kc[3 * r + 1], Rt[4 + c], Kc[3 * r] * Rt[c]));
+}
+
+static inline int is_inlier_f32(const float* Pm, const float* X, const float* uv, float reperr) {
+  const float x = fmaf(Pm[2], X[2], fmaf(Pm[1], X[1], fmaf(Pm[0], X[0], Pm[3])));
+  const float y = fmaf(Pm[6], X[2], fmaf(Pm[5], X[1], fmaf(Pm[4], X[0], Pm[7])));
+  const float z = fmaf(Pm[10], X[2], fmaf(Pm[9], X[1], fmaf(Pm[8], X[0], Pm[11])));
+  const float ex = fmaf(-uv[0], z, x), ey = fmaf(-uv[1], z, y);
+  const float e2 = fmaf(ey, ey, ex * ex);
+  const float lim = reperr * z;
+  return (z > 0.0f) && (e2 <= lim * lim);
+}
+
+void orc_ransac_score(const float* p3d, const float* p2d, int M, const double* Kc,
+                      const double* Rt, const uint8_t* ok, int H, float reperr, int32_t* n_inl,
+                      int32_t* best, uint32_t* best_mask) {
+  int bh = -1, bc = -1;
+  for (int h = 0; h < H; ++h) {
+    int c = 0;
+    if (!ok || ok[h]) {
+      float Pm[12];
+      proj_matrix_f32(Kc, Rt + 12 * (size_t)h, Pm);
+      for (int m = 0; m < M; ++m)
+        c += is_inlier_f32(Pm, p3d + 3 * (size_t)m, p2d + 2 * (size_t)m, reperr);
+      if (c > bc) { bc = c; bh = h; }
+    }
+    n_inl[h] = c;
+  }
+  if (best) *best = bh;
+  if (best_mask) {
+    const int W = (M + 31) / 32;
+    memset(best_mask, 0, sizeof(uint32_t) * (size_t)W);
+    if (bh >= 0) {
+      float Pm[12];
+      proj_matrix_f32(Kc, Rt + 12 * (size_t)bh, Pm);
+      for (int m = 0; m < M; ++m)
+        if (is_inlier_f32(Pm, p3d + 3 * (size_t)m, p2d + 2 * (size_t)m, reperr))
+          best_mask[m >> 5] |= 1u << (m & 31);
+    }
+  }
+}
