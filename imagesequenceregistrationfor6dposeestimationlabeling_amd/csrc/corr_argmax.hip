@@ -1,0 +1,394 @@
+// corr_argmax.hip — K1: fused key/query correlation + online log-sum-exp + arg-max for gfx950.
+//
+// Replaces  getCors(queries, feats, leaves=1):
+//             cMat = torch.log_softmax(queries @ feats.T, -1); vals, idx = torch.topk(cMat, 1)
+//           inference.py:142-149 (= finalposes.py:38-45 = choosePose.py:35-42)
+//           and the logsumexp denominator of pose_refine.py:56 (the `lse` output).
+// The (P x N) matrix is never written: each wave keeps 64 queries' descriptors in registers as
+// MFMA B operands, the block streams the keys through an XOR-swizzled LDS tile as A operands,
+// and each 32(keys) x 32(queries) accumulator tile is consumed in registers.
+//
+// Orientation: S^T = K Q^T, so the C/D layout puts the QUERY on the lane (col = lane & 31) and 16
+// KEYS in the lane's registers (row = (r&3) + 8(r>>2) + 4(lane>>5)): the reduction over keys is
+// lane-local — no cross-lane traffic until one 2-lane merge at the end.
+//
+// Per-lane online state for its query:  m  (max logit, exact, for the arg-max; lowest key on ties)
+//   M2 = ceil(m * log2 e)  (an integer, so exp2(fma(s, log2e, -M2)) has one rounding and every
+//                           rescale  l *= 2^(M2old - M2new)  is exact)
+//   l  = sum_n 2^(s_n log2e - M2)
+// Cost per 32x32 tile at D = 64: 4 MFMA (~140 cycles) vs 16 x (fma + v_exp_f32 + add) + 8 max3
+// (~230 cycles): the kernel is bound by the transcendental unit, see DESIGN.md.
+//
+// dtype bf16: v_mfma_f32_32x32x16_bf16.  dtype f32: v_mfma_f32_32x32x2_f32, which is bit for bit
+// a k-ordered fmaf chain — oracle/isr_oracle.c:orc_corr_argmax_f32 reproduces its logits exactly.
+#include "isr_common.hpp"
+
+namespace {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kQB = 2;                       // 32-query blocks per wave
+constexpr int kQPerBlock = kWaves * kQB * 32;  // 256 queries per workgroup
+constexpr int kTK = 64;                      // keys per LDS stage
+constexpr float kLog2e = 1.4426950408889634f;
+
+struct LaneState {
+  float m;    // running max logit
+  float M2;   // ceil(m * log2e)
+  float l;    // sum 2^(s*log2e - M2)
+  int bi;     // key index of m
+};
+
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// Consume one accumulator tile: rows kb + 4h + (r&3) + 8(r>>2), r = 0..15, of this lane's query.
+__device__ __forceinline__ void consume_tile(const f32x16& acc, int krow0, LaneState& st) {
+  const float x0 = max3(acc[0], acc[1], acc[2]), x1 = max3(acc[3], acc[4], acc[5]),
+              x2 = max3(acc[6], acc[7], acc[8]), x3 = max3(acc[9], acc[10], acc[11]),
+              x4 = max3(acc[12], acc[13], acc[14]);
+  const float t = fmaxf(max3(x0, x1, x2), max3(x3, x4, acc[15]));
+  if (__any(t > st.m)) {  // wave-uniform; rare once the running max has settled
+    if (t > st.m) {
+      int r = 15;
+#pragma unroll
+      for (int i = 14; i >= 0; --i) r = (acc[i] == t) ? i : r;  // lowest register = lowest key
+      st.bi = krow0 + (r & 3) + 8 * (r >> 2);
+      const float M2n = ceilf(t * kLog2e);
+      st.l *= __builtin_amdgcn_exp2f(st.M2 - M2n);  // exact power of two (0 when M2 = -inf)
+      st.M2 = M2n;
+      st.m = t;
+    }
+  }
+  const float nM2 = -st.M2;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st.l += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i], kLog2e, nM2));
+}
+
+__device__ __forceinline__ void mask_tail(f32x16& acc, int krow0, int N) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+    if (krow0 + (i & 3) + 8 * (i >> 2) >= N) acc[i] = -__builtin_inff();
+}
+
+__device__ __forceinline__ bool better(float ma, int ia, float mb, int ib) {
+  return (ma > mb) || (ma == mb && ia < ib);
+}
+
+__device__ __forceinline__ void merge_state(LaneState& a, const LaneState& b) {
+  const float M2 = fmaxf(a.M2, b.M2);
+  const float la = (a.M2 == M2) ? a.l : a.l * __builtin_amdgcn_exp2f(a.M2 - M2);
+  const float lb = (b.M2 == M2) ? b.l : b.l * __builtin_amdgcn_exp2f(b.M2 - M2);
+  if (better(b.m, b.bi, a.m, a.bi)) { a.m = b.m; a.bi = b.bi; }
+  a.M2 = M2;
+  a.l = la + lb;
+}
+
+__device__ __forceinline__ void store_partial(const LaneState& st_, int q, int P, int split,
+                                              float* pm, float* pM2, float* pl, int32_t* pbi) {
+  LaneState st = st_;
+  LaneState o;
+  o.m = __shfl_xor(st.m, 32, 64);
+  o.M2 = __shfl_xor(st.M2, 32, 64);
+  o.l = __shfl_xor(st.l, 32, 64);
+  o.bi = __shfl_xor(st.bi, 32, 64);
+  merge_state(st, o);
+  if ((threadIdx.x & 63) < 32 && q < P) {
+    const size_t off = (size_t)split * P + q;
+    pm[off] = st.m; pM2[off] = st.M2; pl[off] = st.l; pbi[off] = st.bi;
+  }
+}
+
+// ------------------------------------------------------------------------------------ bf16
+template <int DK>  // D = 16 * DK, DK in {1, 2, 4, 8}
+__global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
+    const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
+    int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
+    int32_t* __restrict__ pbi) {
+  constexpr int NCH = 2 * DK;                         // 16-byte chunks per key row
+  constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;     // key rows per 256-byte LDS bank row
+  constexpr int CHUNKS = kTK * NCH;                   // chunks per stage
+  constexpr int NLD = (CHUNKS + kThreads - 1) / kThreads;
+  __shared__ uint4 lds[2][CHUNKS];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int split = blockIdx.y;
+  const int q0 = (blockIdx.x * kWaves + wave) * (kQB * 32);
+
+  bf16x8 bq[kQB][DK];
+#pragma unroll
+  for (int qb = 0; qb < kQB; ++qb) {
+    int row = q0 + qb * 32 + r;
+    row = row < P ? row : P - 1;
+    const uint16_t* src = Q + (size_t)row * ldq + 8 * h;
+#pragma unroll
+    for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+  }
+
+  LaneState st[kQB];
+#pragma unroll
+  for (int qb = 0; qb < kQB; ++qb) {
+    st[qb].m = -__builtin_inff(); st[qb].M2 = -__builtin_inff(); st[qb].l = 0.f; st[qb].bi = 0;
+  }
+
+  const int k0 = split * split_len;
+  const int k1 = min(N, k0 + split_len);
+  const int nstage = (k1 - k0 + kTK - 1) / kTK;
+
+  uint4 stg[NLD];
+  auto gload = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int ci = tid + i * kThreads;
+      const int row = ci / NCH, c = ci % NCH;
+      const int key = k0 + stage * kTK + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ci < CHUNKS && key < k1)
+        v = *reinterpret_cast<const uint4*>(K + (size_t)key * ldk + 8 * c);
+      stg[i] = v;
+    }
+  };
+  auto lwrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int ci = tid + i * kThreads;
+      const int row = ci / NCH, c = ci % NCH;
+      if (ci < CHUNKS) lds[buf][row * NCH + (c ^ ((row / RPB) & (NCH - 1)))] = stg[i];
+    }
+  };
+
+  if (nstage > 0) { gload(0); lwrite(0); }
+  __syncthreads();
+  for (int stage = 0; stage < nstage; ++stage) {
+    const int buf = stage & 1;
+    if (stage + 1 < nstage) gload(stage + 1);
+#pragma unroll
+    for (int sub = 0; sub < kTK / 32; ++sub) {
+      const int kb = k0 + stage * kTK + sub * 32;
+      if (kb < k1) {  // wave-uniform
+        const int row = sub * 32 + r;
+        const int sw = (row / RPB) & (NCH - 1);
+        bf16x8 a[DK];
+#pragma unroll
+        for (int s = 0; s < DK; ++s) {
+          const uint4 v = lds[buf][row * NCH + ((2 * s + h) ^ sw)];
+          a[s] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+        f32x16 acc[kQB];
+#pragma unroll
+        for (int qb = 0; qb < kQB; ++qb) {
+          f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+          for (int s = 0; s < DK; ++s)
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qb][s], c, 0, 0, 0);
+          acc[qb] = c;
+        }
+        const int krow0 = kb + 4 * h;
+        if (kb + 32 > k1) {
+#pragma unroll
+          for (int qb = 0; qb < kQB; ++qb) mask_tail(acc[qb], krow0, k1);
+        }
+#pragma unroll
+        for (int qb = 0; qb < kQB; ++qb) consume_tile(acc[qb], krow0, st[qb]);
+      }
+    }
+    if (stage + 1 < nstage) lwrite(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < kQB; ++qb) store_partial(st[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
+}
+
+// ------------------------------------------------------------------------------------- f32
+template <int DP>  // padded D (multiple of 2): k-steps = DP / 2
+__global__ __launch_bounds__(kThreads) void corr_f32_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, int P, int N, int D, int ldq, int ldk,
+    int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
+    int32_t* __restrict__ pbi) {
+  constexpr int KS = DP / 2;
+  constexpr int LD = DP + 1;  // odd dword stride: conflict-free ds_read_b32 down a column
+  __shared__ float lds[2][kTK * LD];
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int split = blockIdx.y;
+  const int q0 = (blockIdx.x * kWaves + wave) * (kQB * 32);
+
+  float bq[kQB][KS];
+#pragma unroll
+  for (int qb = 0; qb < kQB; ++qb) {
+    int row = q0 + qb * 32 + r;
+    row = row < P ? row : P - 1;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int col = 2 * s + h;
+      bq[qb][s] = col < D ? Q[(size_t)row * ldq + col] : 0.f;
+    }
+  }
+  LaneState st[kQB];
+#pragma unroll
+  for (int qb = 0; qb < kQB; ++qb) {
+    st[qb].m = -__builtin_inff(); st[qb].M2 = -__builtin_inff(); st[qb].l = 0.f; st[qb].bi = 0;
+  }
+
+  const int k0 = split * split_len;
+  const int k1 = min(N, k0 + split_len);
+  const int nstage = (k1 - k0 + kTK - 1) / kTK;
+  constexpr int NEL = (kTK * DP + kThreads - 1) / kThreads;
+  float stg[NEL];
+  auto gload = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+      const int e = tid + i * kThreads;
+      const int row = e / DP, col = e % DP;
+      const int key = k0 + stage * kTK + row;
+      stg[i] = (e < kTK * DP && key < k1 && col < D) ? K[(size_t)key * ldk + col] : 0.f;
+    }
+  };
+  auto lwrite = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NEL; ++i) {
+      const int e = tid + i * kThreads;
+      if (e < kTK * DP) lds[buf][(e / DP) * LD + (e % DP)] = stg[i];
+    }
+  };
+
+  if (nstage > 0) { gload(0); lwrite(0); }
+  __syncthreads();
+  for (int stage = 0; stage < nstage; ++stage) {
+    const int buf = stage & 1;
+    if (stage + 1 < nstage) gload(stage + 1);
+#pragma unroll
+    for (int sub = 0; sub < kTK / 32; ++sub) {
+      const int kb = k0 + stage * kTK + sub * 32;
+      if (kb < k1) {
+        const float* arow = &lds[buf][(sub * 32 + r) * LD + h];
+        f32x16 acc[kQB];
+#pragma unroll
+        for (int qb = 0; qb < kQB; ++qb)
+          acc[qb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          const float a = arow[2 * s];
+#pragma unroll
+          for (int qb = 0; qb < kQB; ++qb)
+            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[qb][s], acc[qb], 0, 0, 0);
+        }
+        const int krow0 = kb + 4 * h;
+        if (kb + 32 > k1) {
+#pragma unroll
+          for (int qb = 0; qb < kQB; ++qb) mask_tail(acc[qb], krow0, k1);
+        }
+#pragma unroll
+        for (int qb = 0; qb < kQB; ++qb) consume_tile(acc[qb], krow0, st[qb]);
+      }
+    }
+    if (stage + 1 < nstage) lwrite(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qb = 0; qb < kQB; ++qb) store_partial(st[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
+}
+
+// Merge the key-range splits (ascending, so equal maxima keep the lowest key) and write outputs.
+// logp = -ln sum_n e^(s_n - m) is formed without the m - lse cancellation, in f64:
+//   sum_n e^(s_n - m) = l * 2^M2 / e^m   ->   logp = -(ln l + M2 ln2 - m)
+__global__ void corr_finalize_kernel(int P, int nsplit, const float* __restrict__ pm,
+                                     const float* __restrict__ pM2, const float* __restrict__ pl,
+                                     const int32_t* __restrict__ pbi, int32_t* __restrict__ idx,
+                                     float* __restrict__ logp, float* __restrict__ lse) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P) return;
+  LaneState a{pm[q], pM2[q], pl[q], pbi[q]};
+  for (int s = 1; s < nsplit; ++s) {
+    const size_t o = (size_t)s * P + q;
+    const LaneState b{pm[o], pM2[o], pl[o], pbi[o]};
+    merge_state(a, b);
+  }
+  const double ln2 = 0.6931471805599453094;
+  const double lp = -(log((double)a.l) + ((double)a.M2 * ln2 - (double)a.m));
+  idx[q] = a.bi;
+  if (logp) logp[q] = (float)lp;
+  if (lse) lse[q] = (float)((double)a.m - lp);
+}
+
+struct CorrPlan {
+  int qblocks, nsplit, split_len;
+};
+
+CorrPlan make_plan(int P, int N) {
+  CorrPlan p;
+  p.qblocks = (P + kQPerBlock - 1) / kQPerBlock;
+  const int max_split = (N + kTK - 1) / kTK;
+  long ns = (1024 + p.qblocks - 1) / p.qblocks;  // aim for >= 4 workgroups per CU
+  if (ns > max_split) ns = max_split;
+  if (ns < 1) ns = 1;
+  const int stages = (max_split + (int)ns - 1) / (int)ns;
+  p.split_len = stages * kTK;
+  p.nsplit = (N + p.split_len - 1) / p.split_len;
+  return p;
+}
+
+}  // namespace
+
+extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype) {
+  (void)D; (void)dtype;
+  if (P <= 0 || N <= 0) return 0;
+  const CorrPlan p = make_plan(P, N);
+  return 4 * isr::align_up((size_t)p.nsplit * P * 4, 256) + 256;
+}
+
+extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
+                               int dtype, int32_t* idx, float* logp, float* lse, void* ws,
+                               size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(Q && K && idx, "isr_corr_argmax: null pointer");
+  ISR_REQUIRE(P > 0 && N > 0 && D > 0, "isr_corr_argmax: P=%d N=%d D=%d must be positive", P, N, D);
+  ISR_REQUIRE(ldq >= D && ldk >= D, "isr_corr_argmax: ldq=%d ldk=%d < D=%d", ldq, ldk, D);
+  if (!ws || ws_bytes < isr_corr_argmax_workspace_bytes(P, N, D, dtype)) {
+    isr::set_error("isr_corr_argmax: workspace %zu < %zu", ws_bytes,
+                   isr_corr_argmax_workspace_bytes(P, N, D, dtype));
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  const CorrPlan p = make_plan(P, N);
+  isr::Workspace w(ws, ws_bytes);
+  float* pm = w.take<float>((size_t)p.nsplit * P);
+  float* pM2 = w.take<float>((size_t)p.nsplit * P);
+  float* pl = w.take<float>((size_t)p.nsplit * P);
+  int32_t* pbi = w.take<int32_t>((size_t)p.nsplit * P);
+  const dim3 grid(p.qblocks, p.nsplit);
+
+  if (dtype == ISR_DTYPE_BF16) {
+    ISR_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128,
+                "isr_corr_argmax(bf16): D=%d must be 16, 32, 64 or 128 (zero-pad the columns)", D);
+    ISR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0),
+                "isr_corr_argmax(bf16): rows must be 16-byte aligned (ldq=%d ldk=%d)", ldq, ldk);
+    const uint16_t* q = static_cast<const uint16_t*>(Q);
+    const uint16_t* k = static_cast<const uint16_t*>(K);
+    switch (D) {
+      case 16: corr_bf16_kernel<1><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+      case 32: corr_bf16_kernel<2><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+      case 64: corr_bf16_kernel<4><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+      default: corr_bf16_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+    }
+  } else if (dtype == ISR_DTYPE_F32) {
+    ISR_REQUIRE(D <= 64, "isr_corr_argmax(f32): D=%d > 64", D);
+    const float* q = static_cast<const float*>(Q);
+    const float* k = static_cast<const float*>(K);
+    if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.split_len, pm, pM2, pl, pbi);
+    else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.split_len, pm, pM2, pl, pbi);
+    else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.split_len, pm, pM2, pl, pbi);
+    else corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.split_len, pm, pM2, pl, pbi);
+  } else {
+    isr::set_error("isr_corr_argmax: dtype %d", dtype);
+    return ISR_ERR_ARG;
+  }
+  ISR_CHECK_LAUNCH("corr kernel");
+  corr_finalize_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, p.nsplit, pm, pM2, pl, pbi, idx, logp, lse);
+  ISR_CHECK_LAUNCH("corr_finalize_kernel");
+  return ISR_OK;
+}

@@ -7,8 +7,6 @@
     return ISR_ERR_UNSUPPORTED;                 \
   } while (0)
 
-extern "C" size_t isr_corr_argmax_workspace_bytes(int, int, int, int) { return 0; }
-extern "C" int isr_corr_argmax(const void*, const void*, int, int, int, int, int, int, int32_t*, float*, float*, void*, size_t, isr_stream_t) { ISR_TODO("isr_corr_argmax"); }
 extern "C" int isr_corr_logsoftmax(const void*, const void*, int, int, int, int, int, int, float*, int64_t, isr_stream_t) { ISR_TODO("isr_corr_logsoftmax"); }
 extern "C" size_t isr_select_top_workspace_bytes(int) { return 0; }
 extern "C" int isr_select_top(const float*, int, double, int, int32_t*, int32_t*, float*, void*, size_t, isr_stream_t) { ISR_TODO("isr_select_top"); }

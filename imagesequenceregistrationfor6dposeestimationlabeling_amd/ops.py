@@ -87,3 +87,48 @@ def rel_pose_table(R: torch.Tensor, t: torch.Tensor, mode: int, i0: int = 0,
         rc = lib().isr_rel_pose_table(ptr(R), ptr(t), n, i0, i1, mode, ptr(out), current_stream(dev))
     check(rc, "isr_rel_pose_table")
     return out
+
+
+def _pad_cols(t: torch.Tensor, D: int) -> torch.Tensor:
+    if t.shape[1] == D:
+        return t.contiguous()
+    out = torch.zeros((t.shape[0], D), dtype=t.dtype, device=t.device)
+    out[:, : t.shape[1]] = t
+    return out
+
+
+def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = False):
+    """isr_corr_argmax.  queries (P,D), keys (N,D); bf16 tensors take the bf16 MFMA path, f32
+    tensors the exact f32 MFMA path (f16/f64 are converted to f32).  Zero columns are appended
+    where the kernel needs a padded D (exact: they add 0 to every logit).
+    Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32] on the device."""
+    dev = require_cuda(queries, keys)
+    if queries.ndim != 2 or keys.ndim != 2 or queries.shape[1] != keys.shape[1]:
+        raise ValueError(f"queries {tuple(queries.shape)} / keys {tuple(keys.shape)} must be (P,D),(N,D)")
+    P, D = queries.shape
+    N = keys.shape[0]
+    if P == 0 or N == 0:
+        raise ValueError("empty queries or keys")
+    if queries.dtype == torch.bfloat16 and keys.dtype == torch.bfloat16:
+        dtype = _capi.DTYPE_BF16
+        Dp = next((d for d in (16, 32, 64, 128) if d >= D), None)
+        if Dp is None:
+            raise ValueError(f"bf16 path supports D <= 128, got {D}")
+    else:
+        dtype = _capi.DTYPE_F32
+        queries, keys = queries.to(torch.float32), keys.to(torch.float32)
+        Dp = D
+        if D > 64:
+            raise ValueError(f"f32 path supports D <= 64, got {D}")
+    q, k = _pad_cols(queries, Dp), _pad_cols(keys, Dp)
+    idx = torch.empty(P, dtype=torch.int32, device=dev)
+    logp = torch.empty(P, dtype=torch.float32, device=dev)
+    lse = torch.empty(P, dtype=torch.float32, device=dev) if want_lse else None
+    L = lib()
+    nbytes = L.isr_corr_argmax_workspace_bytes(P, N, Dp, dtype)
+    ws = workspace(dev, nbytes, "corr")
+    with torch.cuda.device(dev):
+        rc = L.isr_corr_argmax(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, ptr(idx), ptr(logp), ptr(lse),
+                               ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_corr_argmax")
+    return (idx, logp, lse) if want_lse else (idx, logp)

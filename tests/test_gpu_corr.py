@@ -1,0 +1,94 @@
+"""GPU parity: isr_corr_argmax through the C ABI vs the C oracle.
+f32 path: arg-max indices bit-exact (the f32 MFMA is a k-ordered fmaf chain, as the oracle).
+bf16 path: indices equal except where the oracle's f64 top-1/top-2 margin is below the f32
+accumulation noise (reported); logp / lse within 2e-5 (f32 exp/sum vs f64)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _planted(rng, P, N, D, tau=8.0, sigma=0.35):
+    K = rng.normal(0, 1, (N, D))
+    K *= tau / np.linalg.norm(K, axis=1, keepdims=True)
+    gt = rng.integers(N, size=P)
+    Q = K[gt] + sigma * rng.normal(0, 1, (P, D))
+    return Q.astype(np.float32), K.astype(np.float32), gt
+
+
+def _bits(t):
+    return t.view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("P,N,D", [
+    (1, 1, 12), (5, 33, 12), (4500, 20000, 12),      # reference shape (D=12 -> padded 16)
+    (257, 1000, 7), (300, 4097, 33), (1024, 6400, 64),
+])
+def test_corr_f32_bit_exact(cuda0, oracle_lib, P, N, D):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(P + N + D)
+    Q, K, _ = _planted(rng, P, N, D)
+    idx, logp, lse = ops.corr_argmax(torch.from_numpy(Q).to(cuda0), torch.from_numpy(K).to(cuda0),
+                                     want_lse=True)
+    torch.cuda.synchronize()
+    o = oracle_lib.corr_argmax_f32(Q, K)
+    assert np.array_equal(idx.cpu().numpy(), o["idx"])
+    ref_logp = o["maxlogit"].astype(np.float64) - o["lse"]
+    np.testing.assert_allclose(logp.cpu().numpy(), ref_logp, atol=2e-5)
+    np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=2e-6, atol=2e-5)
+
+
+@pytest.mark.parametrize("P,N,D", [
+    (3, 5, 16), (64, 64, 32), (1000, 20000, 64), (777, 3001, 128), (4096, 50000, 64), (100, 999, 48),
+])
+def test_corr_bf16(cuda0, oracle_lib, P, N, D):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(P * 3 + N + D)
+    Q, K, gt = _planted(rng, P, N, D)
+    qb, kb = torch.from_numpy(Q).bfloat16(), torch.from_numpy(K).bfloat16()   # rounded ONCE on host
+    idx, logp, lse = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0), want_lse=True)
+    torch.cuda.synchronize()
+    o = oracle_lib.corr_argmax_bf16(_bits(qb), _bits(kb))
+    got = idx.cpu().numpy()
+    bad = np.nonzero(got != o["idx"])[0]
+    margin = o["maxlogit"] - o["top2"]
+    noise = 1e-5 * np.maximum(1.0, np.abs(o["maxlogit"]))
+    assert (margin[bad] <= noise[bad]).all(), f"{len(bad)} mismatches, min margin {margin[bad].min()}"
+    assert len(bad) <= max(1, P // 1000)
+    np.testing.assert_allclose(logp.cpu().numpy(), o["maxlogit"] - o["lse"], atol=2e-5)
+    np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=2e-6, atol=2e-5)
+
+
+def test_corr_random_unplanted_and_spiked(cuda0, oracle_lib):
+    """No planted peak (flat softmax: l sums 20k comparable terms) and a late spike that forces
+    the rescale branch in the last key tile."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(11)
+    P, N, D = 512, 20000, 64
+    Q = rng.normal(0, 0.4, (P, D)).astype(np.float32)
+    K = rng.normal(0, 0.4, (N, D)).astype(np.float32)
+    K[N - 1] = 3.0 * Q[7]          # query 7 meets its max at the very last key
+    K[0] = 3.0 * Q[9]              # query 9 at the very first
+    qb, kb = torch.from_numpy(Q).bfloat16(), torch.from_numpy(K).bfloat16()
+    idx, logp = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0))
+    torch.cuda.synchronize()
+    o = oracle_lib.corr_argmax_bf16(_bits(qb), _bits(kb))
+    got = idx.cpu().numpy()
+    assert got[7] == N - 1 and got[9] == 0
+    bad = np.nonzero(got != o["idx"])[0]
+    assert ((o["maxlogit"] - o["top2"])[bad] < 1e-5).all()
+    np.testing.assert_allclose(logp.cpu().numpy(), o["maxlogit"] - o["lse"], atol=3e-5)
+
+
+def test_corr_ties_lowest_key(cuda0):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    K = torch.zeros(200, 16)
+    for j in (3, 4, 36, 70, 199):      # same lane half, other half, other tiles, last key
+        K[j, 0] = 1.0
+    Q = torch.zeros(2, 16)
+    Q[0, 0] = 2.0
+    Q[1, 0] = -1.0                      # every other key ties at 0 -> key 0
+    for dt in (torch.float32, torch.bfloat16):
+        idx, _ = ops.corr_argmax(Q.to(dt).to(cuda0), K.to(dt).to(cuda0))
+        assert idx.cpu().tolist() == [3, 0]
