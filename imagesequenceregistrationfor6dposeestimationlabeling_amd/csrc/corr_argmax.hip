@@ -34,6 +34,9 @@ constexpr int kQB = 2;                       // 32-query blocks per wave
 constexpr int kQPerBlock = kWaves * kQB * 32;  // 256 queries per workgroup
 constexpr int kTK = 64;                      // keys per LDS stage
 constexpr float kLog2e = 1.4426950408889634f;
+// M2 of a lane that has seen no valid key yet: finite, so a fully masked tile gives
+// exp2(fma(-inf, log2e, 1e30)) = 0 instead of NaN, and the first real key rescales l by 2^-huge = 0.
+constexpr float kNoM2 = -1.0e30f;
 
 struct LaneState {
   float m;    // running max logit
@@ -57,7 +60,7 @@ __device__ __forceinline__ void consume_tile(const f32x16& acc, int krow0, LaneS
       for (int i = 14; i >= 0; --i) r = (acc[i] == t) ? i : r;  // lowest register = lowest key
       st.bi = krow0 + (r & 3) + 8 * (r >> 2);
       const float M2n = ceilf(t * kLog2e);
-      st.l *= __builtin_amdgcn_exp2f(st.M2 - M2n);  // exact power of two (0 when M2 = -inf)
+      st.l *= __builtin_amdgcn_exp2f(st.M2 - M2n);  // exact power of two (0 when M2 = kNoM2)
       st.M2 = M2n;
       st.m = t;
     }
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
   LaneState st[kQB];
 #pragma unroll
   for (int qb = 0; qb < kQB; ++qb) {
-    st[qb].m = -__builtin_inff(); st[qb].M2 = -__builtin_inff(); st[qb].l = 0.f; st[qb].bi = 0;
+    st[qb].m = -__builtin_inff(); st[qb].M2 = kNoM2; st[qb].l = 0.f; st[qb].bi = 0;
   }
 
   const int k0 = split * split_len;
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(kThreads) void corr_f32_kernel(
   LaneState st[kQB];
 #pragma unroll
   for (int qb = 0; qb < kQB; ++qb) {
-    st[qb].m = -__builtin_inff(); st[qb].M2 = -__builtin_inff(); st[qb].l = 0.f; st[qb].bi = 0;
+    st[qb].m = -__builtin_inff(); st[qb].M2 = kNoM2; st[qb].l = 0.f; st[qb].bi = 0;
   }
 
   const int k0 = split * split_len;

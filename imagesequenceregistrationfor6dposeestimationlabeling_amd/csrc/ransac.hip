@@ -1,0 +1,747 @@
+// ransac.hip — K2: PnP + RANSAC on gfx950.
+//
+// Replaces  pnp(h3d, h2d, cam, itr, reperr, flag=SOLVEPNP_P3P):
+//             cv2.solvePnPRansac(h3d, h2d, cam, None, iterationsCount=itr,
+//                                reprojectionError=reperr, flags=cv2.SOLVEPNP_P3P); cv2.Rodrigues
+//           inference.py:123-134 (= finalposes.py:20-30 = choosePose.py:23-33), call site :293.
+// OpenCV is not in the image and the reference pins no version or test vector, so this file OWNS
+// the algorithm (DESIGN.md "K2"); the CPU statement of it is oracle/pnp_oracle.py.
+//
+//   1. hypotheses   thread h: Philox4x32-10(key = seed, counter = h) -> 4 correspondence indices
+//                   (mulhi(x, M)); P3P on the first three in f64 (degenerate-conic method: one
+//                   root of the pencil cubic by Newton, the singular conic split into its two
+//                   lines, each line intersected with a second conic), <= 4 poses; the pose with
+//                   the smallest reprojection error on the 4th point is kept.
+//   2. scoring      all H hypotheses x all M correspondences, f32, division-free inlier test
+//                       z > 0  and  (x - u z)^2 + (y - v z)^2 <= (reperr z)^2
+//                   lane = correspondence (coalesced loads, 4 per lane in registers), loop over
+//                   hypotheses with the 3x4 projection in SGPRs; ballot + s_bcnt1 counts a wave's
+//                   inliers, LDS integer atomics per block, one global integer atomic per
+//                   (block, hypothesis): deterministic.
+//   3. best         arg-max count, lowest h on ties; its inlier bitmask.
+//   4. refit        Gauss-Newton on the reprojection error over the inliers, f64, fixed-shape
+//                   tree reduction of J^T J / J^T r, 6x6 Cholesky on the device.
+//   5. compaction   inlier mask -> ascending int32 indices.
+// Every step reads M and the status from device memory: the whole chain is enqueued without a
+// host round trip.
+#include "isr_common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- Philox
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// ------------------------------------------------------------------------------ small f64 math
+struct V3 { double x, y, z; };
+__device__ __forceinline__ V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ V3 scale(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
+
+// adjugate of a symmetric 3x3 given as s = {a00,a01,a02,a11,a12,a22}; result same packing
+__device__ __forceinline__ void sym_adj(const double* s, double* o) {
+  o[0] = s[3] * s[5] - s[4] * s[4];
+  o[1] = s[2] * s[4] - s[1] * s[5];
+  o[2] = s[1] * s[4] - s[2] * s[3];
+  o[3] = s[0] * s[5] - s[2] * s[2];
+  o[4] = s[1] * s[2] - s[0] * s[4];
+  o[5] = s[0] * s[3] - s[1] * s[1];
+}
+__device__ __forceinline__ double sym_det(const double* s, const double* adj) {
+  return s[0] * adj[0] + s[1] * adj[1] + s[2] * adj[2];
+}
+// trace(adj(A) B) for symmetric packed A-adjugate and B
+__device__ __forceinline__ double sym_tr(const double* a, const double* b) {
+  return a[0] * b[0] + a[3] * b[3] + a[5] * b[5] + 2.0 * (a[1] * b[1] + a[2] * b[2] + a[4] * b[4]);
+}
+__device__ __forceinline__ double sym_quad(const double* s, const double* u, const double* v) {
+  // u^T S v
+  return u[0] * (s[0] * v[0] + s[1] * v[1] + s[2] * v[2]) +
+         u[1] * (s[1] * v[0] + s[3] * v[1] + s[4] * v[2]) +
+         u[2] * (s[2] * v[0] + s[4] * v[1] + s[5] * v[2]);
+}
+
+// One real root of x^3 + b x^2 + c x + d by Newton from a start on the convex side of an outer
+// root (monotone convergence); fixed op sequence.
+__device__ double cubic_root(double b, double c, double d) {
+  double r;
+  const double disc = b * b - 3.0 * c;
+  if (disc >= 0.0) {
+    const double v = sqrt(disc);
+    const double t1 = (-b - v) / 3.0;  // local max
+    double k = ((t1 + b) * t1 + c) * t1 + d;
+    if (k > 0.0) {
+      r = t1 - sqrt(-k / (3.0 * t1 + b));  // left of the local max: leftmost root
+    } else {
+      const double t2 = (-b + v) / 3.0;  // local min
+      k = ((t2 + b) * t2 + c) * t2 + d;
+      r = t2 + sqrt(-k / (3.0 * t2 + b));
+    }
+  } else {
+    r = -b / 3.0;
+    if (fabs((3.0 * r + 2.0 * b) * r + c) < 1e-4) r += 1.0;
+  }
+  for (int it = 0; it < 50; ++it) {
+    const double f = ((r + b) * r + c) * r + d;
+    const double fp = (3.0 * r + 2.0 * b) * r + c;
+    if (fp == 0.0) break;
+    const double step = f / fp;
+    r -= step;
+    if (fabs(step) <= 1e-15 * fabs(r)) break;
+  }
+  return r;
+}
+
+struct P3PIn {
+  V3 x[3];  // object points
+  V3 y[3];  // unit bearing vectors
+};
+
+// Degenerate-conic P3P.  Writes up to 4 depth triples into lam[][3]; returns the count.
+__device__ int p3p_depths(const P3PIn& in, double lam[4][3]) {
+  const V3 d12 = sub(in.x[0], in.x[1]), d13 = sub(in.x[0], in.x[2]), d23 = sub(in.x[1], in.x[2]);
+  const double a12 = dot(d12, d12), a13 = dot(d13, d13), a23 = dot(d23, d23);
+  const double b12 = dot(in.y[0], in.y[1]), b13 = dot(in.y[0], in.y[2]), b23 = dot(in.y[1], in.y[2]);
+  if (!(a12 > 0.0) || !(a13 > 0.0) || !(a23 > 0.0)) return 0;
+  // Lambda^T D1 Lambda = 0, Lambda^T D2 Lambda = 0 (packed symmetric 00,01,02,11,12,22)
+  const double D1[6] = {a23, -a23 * b12, 0.0, a23 - a12, a12 * b23, -a12};
+  const double D2[6] = {a23, 0.0, -a23 * b13, -a13, a13 * b23, a23 - a13};
+  double A1[6], A2[6];
+  sym_adj(D1, A1);
+  sym_adj(D2, A2);
+  const double c3 = sym_det(D2, A2), c0 = sym_det(D1, A1);
+  const double c2 = sym_tr(A2, D1), c1 = sym_tr(A1, D2);
+  if (!(fabs(c3) > 0.0)) return 0;
+  const double g = cubic_root(c2 / c3, c1 / c3, c0 / c3);
+  double D0[6], B[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) D0[i] = fma(g, D2[i], D1[i]);
+  sym_adj(D0, B);
+  // B = -p p^T for a real line pair: take the largest diagonal magnitude
+  int i = 0;
+  double bd = B[0];
+  if (fabs(B[3]) > fabs(bd)) { bd = B[3]; i = 1; }
+  if (fabs(B[5]) > fabs(bd)) { bd = B[5]; i = 2; }
+  if (!(bd < 0.0)) return 0;
+  const double inv = 1.0 / sqrt(-bd);
+  double p[3];
+  if (i == 0) { p[0] = -B[0] * inv; p[1] = -B[1] * inv; p[2] = -B[2] * inv; }
+  else if (i == 1) { p[0] = -B[1] * inv; p[1] = -B[3] * inv; p[2] = -B[4] * inv; }
+  else { p[0] = -B[2] * inv; p[1] = -B[4] * inv; p[2] = -B[5] * inv; }
+  // N = D0 + [p]x  = 2 m l^T (rank 1): rows are multiples of l, columns multiples of m
+  const double N[3][3] = {{D0[0], D0[1] - p[2], D0[2] + p[1]},
+                          {D0[1] + p[2], D0[3], D0[4] - p[0]},
+                          {D0[2] - p[1], D0[4] + p[0], D0[5]}};
+  int bj = 0, bk = 0;
+  double bm = 0.0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (fabs(N[j][k]) > bm) { bm = fabs(N[j][k]); bj = j; bk = k; }
+  if (!(bm > 0.0)) return 0;
+  double line[2][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    line[0][k] = (bj == 0) ? N[0][k] : (bj == 1) ? N[1][k] : N[2][k];
+    line[1][k] = (bk == 0) ? N[k][0] : (bk == 1) ? N[k][1] : N[k][2];
+  }
+  // second conic for the intersection: the better scaled of D1 / D2 is immaterial; use D1, and
+  // recover the scale from the largest a_ij.
+  int n = 0;
+  for (int li = 0; li < 2; ++li) {
+    const double* l = line[li];
+    int k = 0;
+    if (fabs(l[1]) > fabs(l[k])) k = 1;
+    if (fabs(l[2]) > fabs(l[k])) k = 2;
+    const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+    double u[3] = {0, 0, 0}, v[3] = {0, 0, 0};
+    const double lk = (k == 0) ? l[0] : (k == 1) ? l[1] : l[2];
+    const double l1 = (k1 == 0) ? l[0] : (k1 == 1) ? l[1] : l[2];
+    const double l2 = (k2 == 0) ? l[0] : (k2 == 1) ? l[1] : l[2];
+    // basis of the plane l^T Lambda = 0
+    double uk = -l1 / lk, vk = -l2 / lk;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      u[c] = (c == k1) ? 1.0 : (c == k) ? uk : 0.0;
+      v[c] = (c == k2) ? 1.0 : (c == k) ? vk : 0.0;
+    }
+    const double qa = sym_quad(D1, u, u), qb = sym_quad(D1, u, v), qc = sym_quad(D1, v, v);
+    // qa mu^2 + 2 qb mu nu + qc nu^2 = 0
+    const double disc = qb * qb - qa * qc;
+    if (!(disc >= 0.0)) continue;
+    const double sq = sqrt(disc);
+    for (int sgn = 0; sgn < 2; ++sgn) {
+      double mu, nu;
+      const double num = sgn ? (-qb - sq) : (-qb + sq);
+      if (fabs(qa) >= fabs(qc)) { if (qa == 0.0) continue; mu = num / qa; nu = 1.0; }
+      else { mu = 1.0; nu = num / qc; }
+      double dvec[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dvec[c] = fma(mu, u[c], nu * v[c]);
+      // orientation: all depths positive
+      if (dvec[0] < 0.0 && dvec[1] < 0.0 && dvec[2] < 0.0) {
+        dvec[0] = -dvec[0]; dvec[1] = -dvec[1]; dvec[2] = -dvec[2];
+      }
+      if (!(dvec[0] > 0.0 && dvec[1] > 0.0 && dvec[2] > 0.0)) continue;
+      // scale from the largest side
+      double q, a;
+      if (a12 >= a13 && a12 >= a23) { q = dvec[0] * dvec[0] + dvec[1] * dvec[1] - 2.0 * b12 * dvec[0] * dvec[1]; a = a12; }
+      else if (a13 >= a23) { q = dvec[0] * dvec[0] + dvec[2] * dvec[2] - 2.0 * b13 * dvec[0] * dvec[2]; a = a13; }
+      else { q = dvec[1] * dvec[1] + dvec[2] * dvec[2] - 2.0 * b23 * dvec[1] * dvec[2]; a = a23; }
+      if (!(q > 0.0)) continue;
+      const double s = sqrt(a / q);
+      double L[3] = {dvec[0] * s, dvec[1] * s, dvec[2] * s};
+      // polish: Newton on the three distance equations
+      for (int it = 0; it < 3; ++it) {
+        const double r0 = L[0] * L[0] + L[1] * L[1] - 2.0 * b12 * L[0] * L[1] - a12;
+        const double r1 = L[0] * L[0] + L[2] * L[2] - 2.0 * b13 * L[0] * L[2] - a13;
+        const double r2 = L[1] * L[1] + L[2] * L[2] - 2.0 * b23 * L[1] * L[2] - a23;
+        const double J00 = 2.0 * (L[0] - b12 * L[1]), J01 = 2.0 * (L[1] - b12 * L[0]);
+        const double J10 = 2.0 * (L[0] - b13 * L[2]), J12 = 2.0 * (L[2] - b13 * L[0]);
+        const double J21 = 2.0 * (L[1] - b23 * L[2]), J22 = 2.0 * (L[2] - b23 * L[1]);
+        // J = [[J00,J01,0],[J10,0,J12],[0,J21,J22]]
+        const double det = -J00 * J12 * J21 - J01 * J10 * J22;
+        if (!(fabs(det) > 0.0)) break;
+        const double id = 1.0 / det;
+        // delta = J^-1 r via the adjugate
+        const double e0 = (-J12 * J21 * r0 - J01 * J22 * r1 + J01 * J12 * r2) * id;
+        const double e1 = (-J10 * J22 * r0 + J00 * J22 * r1 - J00 * J12 * r2) * id;
+        const double e2 = (J10 * J21 * r0 - J00 * J21 * r1 - J01 * J10 * r2) * id;
+        L[0] -= e0; L[1] -= e1; L[2] -= e2;
+      }
+      if (!(L[0] > 0.0 && L[1] > 0.0 && L[2] > 0.0)) continue;
+      if (n < 4) { lam[n][0] = L[0]; lam[n][1] = L[1]; lam[n][2] = L[2]; ++n; }
+    }
+  }
+  return n;
+}
+
+// Pose from depths: R (x_i - x_j) = Y_i - Y_j with Y_i = lam_i y_i.
+__device__ bool pose_from_depths(const P3PIn& in, const double* L, double* Rt) {
+  const V3 Y0 = scale(in.y[0], L[0]), Y1 = scale(in.y[1], L[1]), Y2 = scale(in.y[2], L[2]);
+  const V3 xa = sub(in.x[0], in.x[1]), xb = sub(in.x[0], in.x[2]), xc = cross(xa, xb);
+  const V3 ya = sub(Y0, Y1), yb = sub(Y0, Y2), yc = cross(ya, yb);
+  // X = [xa xb xc] (columns); X^-1 rows = cross products / det
+  const double det = dot(xa, cross(xb, xc));
+  if (!(fabs(det) > 0.0)) return false;
+  const double id = 1.0 / det;
+  const V3 r0 = scale(cross(xb, xc), id), r1 = scale(cross(xc, xa), id), r2 = scale(cross(xa, xb), id);
+  // R = Ya r0^T + Yb r1^T + Yc r2^T
+  const double R[9] = {
+      ya.x * r0.x + yb.x * r1.x + yc.x * r2.x, ya.x * r0.y + yb.x * r1.y + yc.x * r2.y, ya.x * r0.z + yb.x * r1.z + yc.x * r2.z,
+      ya.y * r0.x + yb.y * r1.x + yc.y * r2.x, ya.y * r0.y + yb.y * r1.y + yc.y * r2.y, ya.y * r0.z + yb.y * r1.z + yc.y * r2.z,
+      ya.z * r0.x + yb.z * r1.x + yc.z * r2.x, ya.z * r0.y + yb.z * r1.y + yc.z * r2.y, ya.z * r0.z + yb.z * r1.z + yc.z * r2.z};
+  const V3 x0 = in.x[0];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    Rt[4 * r] = R[3 * r]; Rt[4 * r + 1] = R[3 * r + 1]; Rt[4 * r + 2] = R[3 * r + 2];
+  }
+  Rt[3] = Y0.x - (R[0] * x0.x + R[1] * x0.y + R[2] * x0.z);
+  Rt[7] = Y0.y - (R[3] * x0.x + R[4] * x0.y + R[5] * x0.z);
+  Rt[11] = Y0.z - (R[6] * x0.x + R[7] * x0.y + R[8] * x0.z);
+  bool fin = true;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) fin = fin && (fabs(Rt[i]) < 1e300);
+  return fin;
+}
+
+struct Cam { double k[9]; double ki[9]; };
+
+__global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
+                           const int32_t* __restrict__ M_dev, Cam cam, int H, uint32_t seed_lo,
+                           uint32_t seed_hi, double* __restrict__ Rt_out, uint8_t* __restrict__ ok_out,
+                           int32_t* __restrict__ sample_out) {
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= H) return;
+  const int M = *M_dev;
+  double* Rt = Rt_out + 12 * (size_t)h;
+  uint8_t ok = 0;
+  int s[4] = {0, 0, 0, 0};
+  if (M >= 4) {
+    uint32_t rnd[4];
+    philox4x32_10((uint32_t)h, 0u, 0u, 0u, seed_lo, seed_hi, rnd);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = (int)(((uint64_t)rnd[j] * (uint64_t)M) >> 32);
+    P3PIn in;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      in.x[j] = {(double)p3d[3 * (size_t)s[j]], (double)p3d[3 * (size_t)s[j] + 1], (double)p3d[3 * (size_t)s[j] + 2]};
+      const double u = p2d[2 * (size_t)s[j]], v = p2d[2 * (size_t)s[j] + 1];
+      V3 y = {cam.ki[0] * u + cam.ki[1] * v + cam.ki[2], cam.ki[3] * u + cam.ki[4] * v + cam.ki[5],
+              cam.ki[6] * u + cam.ki[7] * v + cam.ki[8]};
+      in.y[j] = scale(y, 1.0 / sqrt(dot(y, y)));
+    }
+    double lam[4][3];
+    const int n = p3p_depths(in, lam);
+    const V3 X4 = {(double)p3d[3 * (size_t)s[3]], (double)p3d[3 * (size_t)s[3] + 1], (double)p3d[3 * (size_t)s[3] + 2]};
+    const double u4 = p2d[2 * (size_t)s[3]], v4 = p2d[2 * (size_t)s[3] + 1];
+    double best = 1e300;
+    for (int i = 0; i < n; ++i) {
+      double cand[12];
+      if (!pose_from_depths(in, lam[i], cand)) continue;
+      const double xc = cand[0] * X4.x + cand[1] * X4.y + cand[2] * X4.z + cand[3];
+      const double yc = cand[4] * X4.x + cand[5] * X4.y + cand[6] * X4.z + cand[7];
+      const double zc = cand[8] * X4.x + cand[9] * X4.y + cand[10] * X4.z + cand[11];
+      if (!(zc > 0.0)) continue;
+      const double px = cam.k[0] * xc + cam.k[1] * yc + cam.k[2] * zc;
+      const double py = cam.k[3] * xc + cam.k[4] * yc + cam.k[5] * zc;
+      const double pz = cam.k[6] * xc + cam.k[7] * yc + cam.k[8] * zc;
+      const double eu = px / pz - u4, ev = py / pz - v4;
+      const double e = eu * eu + ev * ev;
+      if (e < best) {
+        best = e;
+        ok = 1;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Rt[k] = cand[k];
+      }
+    }
+  }
+  if (!ok) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Rt[k] = (k % 5 == 0) ? 1.0 : 0.0;
+  }
+  ok_out[h] = ok;
+  if (sample_out) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sample_out[4 * (size_t)h + j] = s[j];
+  }
+}
+
+// ------------------------------------------------------------------------------- scoring
+// Pm (H,12) f32 = float(K [R|t]) with the f64 fma order of oracle/isr_oracle.c:proj_matrix_f32.
+__global__ void proj_matrix_kernel(const double* __restrict__ Rt, Cam cam, int H, float* __restrict__ Pm) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= H * 12) return;
+  const int h = e / 12, r = (e % 12) / 4, c = e % 4;
+  const double* T = Rt + 12 * (size_t)h;
+  Pm[e] = (float)fma(cam.k[3 * r + 2], T[8 + c], fma(cam.k[3 * r + 1], T[4 + c], cam.k[3 * r] * T[c]));
+}
+
+__device__ __forceinline__ bool inlier_f32(const float* __restrict__ Pm, float X, float Y, float Z,
+                                           float u, float v, float reperr) {
+  const float x = __builtin_fmaf(Pm[2], Z, __builtin_fmaf(Pm[1], Y, __builtin_fmaf(Pm[0], X, Pm[3])));
+  const float y = __builtin_fmaf(Pm[6], Z, __builtin_fmaf(Pm[5], Y, __builtin_fmaf(Pm[4], X, Pm[7])));
+  const float z = __builtin_fmaf(Pm[10], Z, __builtin_fmaf(Pm[9], Y, __builtin_fmaf(Pm[8], X, Pm[11])));
+  const float ex = __builtin_fmaf(-u, z, x), ey = __builtin_fmaf(-v, z, y);
+  const float e2 = __builtin_fmaf(ey, ey, ex * ex);
+  const float lim = reperr * z;
+  return (z > 0.0f) && (e2 <= lim * lim);
+}
+
+constexpr int kScoreThreads = 256;
+constexpr int kCPL = 4;  // correspondences per lane
+constexpr int kMaxH = 8192;
+
+__global__ __launch_bounds__(kScoreThreads) void score_kernel(
+    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev,
+    const float* __restrict__ Pm, const uint8_t* __restrict__ ok, int H, float reperr,
+    int32_t* __restrict__ n_inl) {
+  extern __shared__ int32_t cnt[];  // H
+  const int M = *M_dev;
+  const int base = blockIdx.x * (kScoreThreads * kCPL);
+  if (base >= M) return;  // block-uniform
+  for (int h = threadIdx.x; h < H; h += kScoreThreads) cnt[h] = 0;
+  __syncthreads();
+  float X[kCPL], Y[kCPL], Z[kCPL], U[kCPL], V[kCPL];
+  bool valid[kCPL];
+#pragma unroll
+  for (int c = 0; c < kCPL; ++c) {
+    const int m = base + c * kScoreThreads + threadIdx.x;
+    valid[c] = m < M;
+    const int mm = valid[c] ? m : 0;
+    X[c] = p3d[3 * (size_t)mm]; Y[c] = p3d[3 * (size_t)mm + 1]; Z[c] = p3d[3 * (size_t)mm + 2];
+    U[c] = p2d[2 * (size_t)mm]; V[c] = p2d[2 * (size_t)mm + 1];
+  }
+  const int lane = threadIdx.x & 63;
+  for (int h = 0; h < H; ++h) {
+    if (!ok[h]) continue;  // uniform
+    const float* P = Pm + 12 * (size_t)h;  // uniform address: scalar loads
+    int c_wave = 0;
+#pragma unroll
+    for (int c = 0; c < kCPL; ++c) {
+      const bool in = valid[c] && inlier_f32(P, X[c], Y[c], Z[c], U[c], V[c], reperr);
+      c_wave += __popcll(__ballot(in));
+    }
+    if (lane == 0 && c_wave) atomicAdd(&cnt[h], c_wave);
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < H; h += kScoreThreads)
+    if (cnt[h]) atomicAdd(&n_inl[h], cnt[h]);
+}
+
+// One block: best = arg-max n_inl over ok hypotheses (lowest h on ties); status = count >= 4.
+__global__ void best_kernel(const int32_t* __restrict__ n_inl, const uint8_t* __restrict__ ok, int H,
+                            int32_t* __restrict__ best_dev, int32_t* __restrict__ status_dev,
+                            const double* __restrict__ Rt, double* __restrict__ pose_dev) {
+  __shared__ int32_t sc[256], sh[256];
+  int bc = -1, bh = -1;
+  for (int h = threadIdx.x; h < H; h += 256) {
+    if (ok[h] && n_inl[h] > bc) { bc = n_inl[h]; bh = h; }  // ascending h per thread: lowest kept
+  }
+  sc[threadIdx.x] = bc; sh[threadIdx.x] = bh;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      const int oc = sc[threadIdx.x + off], oh = sh[threadIdx.x + off];
+      if (oc > sc[threadIdx.x] || (oc == sc[threadIdx.x] && oh >= 0 && (sh[threadIdx.x] < 0 || oh < sh[threadIdx.x]))) {
+        sc[threadIdx.x] = oc; sh[threadIdx.x] = oh;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *best_dev = sh[0];
+    if (status_dev) *status_dev = (sh[0] >= 0 && sc[0] >= 4) ? 1 : 0;
+  }
+  if (pose_dev && threadIdx.x < 12) {
+    const int b = sh[0];
+    pose_dev[threadIdx.x] = (b >= 0) ? Rt[12 * (size_t)b + threadIdx.x] : ((threadIdx.x % 5 == 0) ? 1.0 : 0.0);
+  }
+}
+
+__global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
+                                 const int32_t* __restrict__ M_dev, int M_cap,
+                                 const float* __restrict__ Pm, const int32_t* __restrict__ best_dev,
+                                 float reperr, uint32_t* __restrict__ mask) {
+  const int m = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim multiple of 64
+  const int M = *M_dev;
+  const int b = *best_dev;
+  bool in = false;
+  if (m < M && b >= 0)
+    in = inlier_f32(Pm + 12 * (size_t)b, p3d[3 * (size_t)m], p3d[3 * (size_t)m + 1], p3d[3 * (size_t)m + 2],
+                    p2d[2 * (size_t)m], p2d[2 * (size_t)m + 1], reperr);
+  const unsigned long long bal = __ballot(in);
+  const int lane = threadIdx.x & 63;
+  const int w = m >> 5;
+  if ((lane == 0 || lane == 32) && w < (M_cap + 31) / 32)
+    mask[w] = (lane == 0) ? (uint32_t)bal : (uint32_t)(bal >> 32);
+}
+
+// ---------------------------------------------------------------------------------- refit
+constexpr int kRefThreads = 256;
+constexpr int kRefBlocks = 128;
+constexpr int kNAcc = 28;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2)
+
+__global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
+    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev,
+    const uint32_t* __restrict__ mask, Cam cam, const double* __restrict__ Rt,
+    const int32_t* __restrict__ status_dev, double* __restrict__ partial) {
+  __shared__ double red[kRefThreads / 64][kNAcc];
+  double acc[kNAcc];
+#pragma unroll
+  for (int i = 0; i < kNAcc; ++i) acc[i] = 0.0;
+  const int M = *M_dev;
+  const bool live = (status_dev == nullptr) || (*status_dev != 0);
+  if (live) {
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = Rt[i];
+    for (int m = blockIdx.x * kRefThreads + threadIdx.x; m < M; m += kRefBlocks * kRefThreads) {
+      if (mask && !((mask[m >> 5] >> (m & 31)) & 1u)) continue;
+      const double X = p3d[3 * (size_t)m], Y = p3d[3 * (size_t)m + 1], Z = p3d[3 * (size_t)m + 2];
+      const double xc = T[0] * X + T[1] * Y + T[2] * Z + T[3];
+      const double yc = T[4] * X + T[5] * Y + T[6] * Z + T[7];
+      const double zc = T[8] * X + T[9] * Y + T[10] * Z + T[11];
+      const double px = cam.k[0] * xc + cam.k[1] * yc + cam.k[2] * zc;
+      const double py = cam.k[3] * xc + cam.k[4] * yc + cam.k[5] * zc;
+      const double pz = cam.k[6] * xc + cam.k[7] * yc + cam.k[8] * zc;
+      const double ipz = 1.0 / pz;
+      const double u = px * ipz, v = py * ipz;
+      const double ru = u - (double)p2d[2 * (size_t)m], rv = v - (double)p2d[2 * (size_t)m + 1];
+      // d(u,v)/dXc = (K_row - (u,v) K_row2) / pz
+      const double a0 = (cam.k[0] - u * cam.k[6]) * ipz, a1 = (cam.k[1] - u * cam.k[7]) * ipz, a2 = (cam.k[2] - u * cam.k[8]) * ipz;
+      const double b0 = (cam.k[3] - v * cam.k[6]) * ipz, b1 = (cam.k[4] - v * cam.k[7]) * ipz, b2 = (cam.k[5] - v * cam.k[8]) * ipz;
+      // Xc' = Xc + w x Xc + dt  ->  dXc/dw = -[Xc]x, dXc/dt = I
+      const double Ju[6] = {a2 * yc - a1 * zc, a0 * zc - a2 * xc, a1 * xc - a0 * yc, a0, a1, a2};
+      const double Jv[6] = {b2 * yc - b1 * zc, b0 * zc - b2 * xc, b1 * xc - b0 * yc, b0, b1, b2};
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) acc[k++] += Ju[i] * Ju[j] + Jv[i] * Jv[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[21 + i] += Ju[i] * ru + Jv[i] * rv;
+      acc[27] += ru * ru + rv * rv;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < kNAcc; ++i) {
+    double s = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNAcc)
+    partial[(size_t)blockIdx.x * kNAcc + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+// One thread: sum the block partials in order, solve the 6x6 normal equations by Cholesky,
+// retract:  R <- Q(w) R,  t <- Q(w) t + dt  with Q(w) the rotation of the unit quaternion
+// (1, w/2)/|.| (sqrt only: no sin/cos, so the step is plain IEEE arithmetic).
+__global__ void gn_solve_kernel(const double* __restrict__ partial, double* __restrict__ Rt,
+                                const int32_t* __restrict__ status_dev, double* __restrict__ cost_out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (status_dev && *status_dev == 0) return;
+  double s[kNAcc];
+  for (int i = 0; i < kNAcc; ++i) {
+    double a = 0.0;
+    for (int b = 0; b < kRefBlocks; ++b) a += partial[(size_t)b * kNAcc + i];
+    s[i] = a;
+  }
+  if (cost_out) *cost_out = s[27];
+  double A[6][6], g[6];
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) { A[i][j] = s[k]; A[j][i] = s[k]; ++k; }
+  for (int i = 0; i < 6; ++i) g[i] = -s[21 + i];
+  // Cholesky A = L L^T (tiny relative damping keeps a rank-deficient system finite)
+  double tr = 0.0;
+  for (int i = 0; i < 6; ++i) tr += A[i][i];
+  for (int i = 0; i < 6; ++i) A[i][i] += 1e-14 * tr;
+  double L[6][6];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j][j];
+    for (int p = 0; p < j; ++p) d -= L[j][p] * L[j][p];
+    if (!(d > 0.0)) return;  // not positive definite: keep the pose
+    L[j][j] = sqrt(d);
+    for (int i = j + 1; i < 6; ++i) {
+      double v = A[i][j];
+      for (int p = 0; p < j; ++p) v -= L[i][p] * L[j][p];
+      L[i][j] = v / L[j][j];
+    }
+  }
+  double y[6], x[6];
+  for (int i = 0; i < 6; ++i) {
+    double v = g[i];
+    for (int p = 0; p < i; ++p) v -= L[i][p] * y[p];
+    y[i] = v / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double v = y[i];
+    for (int p = i + 1; p < 6; ++p) v -= L[p][i] * x[p];
+    x[i] = v / L[i][i];
+  }
+  // quaternion (1, w/2) normalised
+  const double hx = 0.5 * x[0], hy = 0.5 * x[1], hz = 0.5 * x[2];
+  const double nrm = 1.0 / sqrt(1.0 + hx * hx + hy * hy + hz * hz);
+  const double qw = nrm, qx = hx * nrm, qy = hy * nrm, qz = hz * nrm;
+  const double Q[9] = {1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw),
+                       2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw),
+                       2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)};
+  double T[12], O[12];
+  for (int i = 0; i < 12; ++i) T[i] = Rt[i];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 4; ++c) O[4 * r + c] = Q[3 * r] * T[c] + Q[3 * r + 1] * T[4 + c] + Q[3 * r + 2] * T[8 + c];
+    O[4 * r + 3] += x[3 + r];
+  }
+  for (int i = 0; i < 12; ++i) Rt[i] = O[i];
+}
+
+// ------------------------------------------------------------------------------ compaction
+// One block: bitmask (W words) -> ascending indices; n_out = popcount total.
+__global__ void mask_compact_kernel(const uint32_t* __restrict__ mask, const int32_t* __restrict__ M_dev,
+                                    const int32_t* __restrict__ status_dev, int32_t* __restrict__ out,
+                                    int32_t* __restrict__ n_out) {
+  __shared__ int32_t tsum[1024];
+  const int t = threadIdx.x;
+  const int M = *M_dev;
+  const int W = (status_dev && *status_dev == 0) ? 0 : (M + 31) / 32;
+  const int per = (W + 1023) / 1024;
+  int32_t s = 0;
+  for (int j = 0; j < per; ++j) {
+    const int w = t * per + j;
+    if (w < W) s += __popc(mask[w]);
+  }
+  tsum[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int32_t v = (t >= off) ? tsum[t - off] : 0;
+    __syncthreads();
+    tsum[t] += v;
+    __syncthreads();
+  }
+  int32_t o = (t > 0) ? tsum[t - 1] : 0;
+  for (int j = 0; j < per; ++j) {
+    const int w = t * per + j;
+    if (w < W) {
+      uint32_t bits = mask[w];
+      while (bits) {
+        const int b = __ffs(bits) - 1;
+        out[o++] = w * 32 + b;
+        bits &= bits - 1;
+      }
+    }
+  }
+  if (t == 1023) *n_out = tsum[1023];
+}
+
+bool make_cam(const double* K, Cam* cam) {
+  for (int i = 0; i < 9; ++i) cam->k[i] = K[i];
+  const double a = K[0], b = K[1], c = K[2], d = K[3], e = K[4], f = K[5], g = K[6], h = K[7], k = K[8];
+  const double A = e * k - f * h, B = -(d * k - f * g), C = d * h - e * g;
+  const double det = a * A + b * B + c * C;
+  if (!(det != 0.0)) return false;
+  const double id = 1.0 / det;
+  cam->ki[0] = A * id; cam->ki[1] = -(b * k - c * h) * id; cam->ki[2] = (b * f - c * e) * id;
+  cam->ki[3] = B * id; cam->ki[4] = (a * k - c * g) * id; cam->ki[5] = -(a * f - c * d) * id;
+  cam->ki[6] = C * id; cam->ki[7] = -(a * h - b * g) * id; cam->ki[8] = (a * e - b * d) * id;
+  return true;
+}
+
+struct RansacWs {
+  double* Rt;        // H x 12
+  float* Pm;         // H x 12
+  uint8_t* ok;       // H
+  int32_t* n_inl;    // H
+  int32_t* best;     // 1
+  uint32_t* mask;    // ceil(M_cap/32)
+  double* partial;   // kRefBlocks x kNAcc
+  float* Pm1;        // 12 (refine path)
+};
+
+size_t carve(isr::Workspace& w, int M_cap, int H, RansacWs* o) {
+  o->Rt = w.take<double>((size_t)H * 12);
+  o->Pm = w.take<float>((size_t)H * 12);
+  o->ok = w.take<uint8_t>(H);
+  o->n_inl = w.take<int32_t>(H);
+  o->best = w.take<int32_t>(4);
+  o->mask = w.take<uint32_t>((M_cap + 31) / 32 + 2);
+  o->partial = w.take<double>((size_t)kRefBlocks * kNAcc);
+  o->Pm1 = w.take<float>(12);
+  return w.off;
+}
+
+}  // namespace
+
+extern "C" size_t isr_pnp_ransac_workspace_bytes(int M_cap, int H) {
+  if (M_cap <= 0 || H <= 0) return 0;
+  isr::Workspace w(nullptr, 0);
+  RansacWs o;
+  return carve(w, M_cap, H, &o) + 512;
+}
+
+extern "C" int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
+                                  const double* Kcam, int H, uint64_t seed, double* Rt, uint8_t* ok,
+                                  int32_t* sample, isr_stream_t stream) {
+  ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt && ok, "isr_p3p_hypotheses: null pointer");
+  ISR_REQUIRE(M_cap > 0 && H > 0, "isr_p3p_hypotheses: M_cap=%d H=%d", M_cap, H);
+  Cam cam;
+  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_p3p_hypotheses: singular camera matrix");
+  p3p_kernel<<<(H + 63) / 64, 64, 0, isr::as_stream(stream)>>>(p3d, p2d, M_dev, cam, H, (uint32_t)seed,
+                                                               (uint32_t)(seed >> 32), Rt, ok, sample);
+  ISR_CHECK_LAUNCH("p3p_kernel");
+  return ISR_OK;
+}
+
+static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, const Cam& cam,
+                      const double* Rt, const uint8_t* ok, int H, float reperr, float* Pm, int32_t* n_inl,
+                      int32_t* best_dev, uint32_t* best_mask, int32_t* status_dev, double* pose_dev,
+                      hipStream_t stream) {
+  proj_matrix_kernel<<<(H * 12 + 255) / 256, 256, 0, stream>>>(Rt, cam, H, Pm);
+  ISR_CHECK_HIP(hipMemsetAsync(n_inl, 0, sizeof(int32_t) * (size_t)H, stream));
+  const int nblk = (M_cap + kScoreThreads * kCPL - 1) / (kScoreThreads * kCPL);
+  score_kernel<<<nblk, kScoreThreads, sizeof(int32_t) * (size_t)H, stream>>>(p3d, p2d, M_dev, Pm, ok, H, reperr, n_inl);
+  best_kernel<<<1, 256, 0, stream>>>(n_inl, ok, H, best_dev, status_dev, Rt, pose_dev);
+  if (best_mask)
+    best_mask_kernel<<<(M_cap + 255) / 256, 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, Pm, best_dev, reperr, best_mask);
+  ISR_CHECK_LAUNCH("ransac score kernels");
+  return ISR_OK;
+}
+
+extern "C" int isr_ransac_score(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
+                                const double* Kcam, const double* Rt, const uint8_t* ok, int H,
+                                float reperr, int32_t* n_inl, int32_t* best_dev, uint32_t* best_mask,
+                                void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt && ok && n_inl && best_dev, "isr_ransac_score: null pointer");
+  ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH, "isr_ransac_score: M_cap=%d H=%d (H <= %d)", M_cap, H, kMaxH);
+  Cam cam;
+  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_ransac_score: singular camera matrix");
+  if (!ws || ws_bytes < isr_pnp_ransac_workspace_bytes(M_cap, H)) {
+    isr::set_error("isr_ransac_score: workspace %zu < %zu", ws_bytes, isr_pnp_ransac_workspace_bytes(M_cap, H));
+    return ISR_ERR_WORKSPACE;
+  }
+  isr::Workspace w(ws, ws_bytes);
+  float* Pm = w.take<float>((size_t)H * 12);
+  return score_impl(p3d, p2d, M_dev, M_cap, cam, Rt, ok, H, reperr, Pm, n_inl, best_dev, best_mask,
+                    nullptr, nullptr, isr::as_stream(stream_));
+}
+
+static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev, const uint32_t* mask,
+                       const Cam& cam, int iters, double* Rt_io, const int32_t* status_dev, double* partial,
+                       hipStream_t stream) {
+  for (int it = 0; it < iters; ++it) {
+    gn_accumulate_kernel<<<kRefBlocks, kRefThreads, 0, stream>>>(p3d, p2d, M_dev, mask, cam, Rt_io, status_dev, partial);
+    gn_solve_kernel<<<1, 64, 0, stream>>>(partial, Rt_io, status_dev, nullptr);
+  }
+  ISR_CHECK_LAUNCH("pnp refine kernels");
+  return ISR_OK;
+}
+
+extern "C" int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
+                              const uint32_t* mask, const double* Kcam, int iters, double* Rt_io, void* ws,
+                              size_t ws_bytes, isr_stream_t stream) {
+  ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt_io, "isr_pnp_refine: null pointer");
+  ISR_REQUIRE(M_cap > 0 && iters >= 0, "isr_pnp_refine: M_cap=%d iters=%d", M_cap, iters);
+  Cam cam;
+  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_pnp_refine: singular camera matrix");
+  const size_t need = sizeof(double) * kRefBlocks * kNAcc + 256;
+  if (!ws || ws_bytes < need) {
+    isr::set_error("isr_pnp_refine: workspace %zu < %zu", ws_bytes, need);
+    return ISR_ERR_WORKSPACE;
+  }
+  isr::Workspace w(ws, ws_bytes);
+  double* partial = w.take<double>((size_t)kRefBlocks * kNAcc);
+  return refine_impl(p3d, p2d, M_dev, mask, cam, iters, Rt_io, nullptr, partial, isr::as_stream(stream));
+}
+
+extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
+                              const double* Kcam, int H, uint64_t seed, float reperr, int refine_iters,
+                              double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev, int32_t* status_dev,
+                              void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(p3d && p2d && M_dev && Kcam && pose_dev && inl_idx && n_inl_dev && status_dev,
+              "isr_pnp_ransac: null pointer");
+  ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH, "isr_pnp_ransac: M_cap=%d H=%d (H <= %d)", M_cap, H, kMaxH);
+  Cam cam;
+  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_pnp_ransac: singular camera matrix");
+  if (!ws || ws_bytes < isr_pnp_ransac_workspace_bytes(M_cap, H)) {
+    isr::set_error("isr_pnp_ransac: workspace %zu < %zu", ws_bytes, isr_pnp_ransac_workspace_bytes(M_cap, H));
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  isr::Workspace w(ws, ws_bytes);
+  RansacWs b;
+  carve(w, M_cap, H, &b);
+  p3p_kernel<<<(H + 63) / 64, 64, 0, stream>>>(p3d, p2d, M_dev, cam, H, (uint32_t)seed, (uint32_t)(seed >> 32),
+                                               b.Rt, b.ok, nullptr);
+  ISR_CHECK_LAUNCH("p3p_kernel");
+  int rc = score_impl(p3d, p2d, M_dev, M_cap, cam, b.Rt, b.ok, H, reperr, b.Pm, b.n_inl, b.best, b.mask,
+                      status_dev, pose_dev, stream);
+  if (rc != ISR_OK) return rc;
+  rc = refine_impl(p3d, p2d, M_dev, b.mask, cam, refine_iters, pose_dev, status_dev, b.partial, stream);
+  if (rc != ISR_OK) return rc;
+  mask_compact_kernel<<<1, 1024, 0, stream>>>(b.mask, M_dev, status_dev, inl_idx, n_inl_dev);
+  ISR_CHECK_LAUNCH("mask_compact_kernel");
+  return ISR_OK;
+}

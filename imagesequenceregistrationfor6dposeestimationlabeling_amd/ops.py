@@ -132,3 +132,133 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
                                ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_corr_argmax")
     return (idx, logp, lse) if want_lse else (idx, logp)
+
+
+def select_top(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500):
+    """isr_select_top: keep (P,) i32 (first M entries valid, ascending), M_dev (1,) i32, thr (1,) f32."""
+    dev = require_cuda(logp)
+    logp = _f32c(logp).reshape(-1)
+    P = logp.numel()
+    keep = torch.empty(P, dtype=torch.int32, device=dev)
+    M_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    thr = torch.empty(1, dtype=torch.float32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_select_top_workspace_bytes(P), "select")
+    with torch.cuda.device(dev):
+        rc = L.isr_select_top(ptr(logp), P, float(frac), int(min_n), ptr(keep), ptr(M_dev), ptr(thr),
+                              ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_select_top")
+    return keep, M_dev, thr
+
+
+def gather_corr(idx, keep, M_dev, pts, pix_xy):
+    """isr_gather_corr: p3d (P,3) f32, p2d (P,2) f32 (first M rows valid)."""
+    dev = require_cuda(idx, keep, M_dev, pts, pix_xy)
+    pts, pix_xy = _f32c(pts), _f32c(pix_xy)
+    P = idx.numel()
+    p3d = torch.empty((P, 3), dtype=torch.float32, device=dev)
+    p2d = torch.empty((P, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_gather_corr(ptr(idx), ptr(keep), ptr(M_dev), P, ptr(pts), pts.shape[0],
+                                   ptr(pix_xy), ptr(p3d), ptr(p2d), current_stream(dev))
+    check(rc, "isr_gather_corr")
+    return p3d, p2d
+
+
+def _kcam(K) -> "ctypes.Array":
+    import ctypes
+    import numpy as np
+    k = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9))
+    return (ctypes.c_double * 9)(*k.tolist())
+
+
+def _m_dev(M, dev, cap):
+    if isinstance(M, torch.Tensor):
+        return M
+    return torch.tensor([cap if M is None else int(M)], dtype=torch.int32, device=dev)
+
+
+def p3p_hypotheses(p3d, p2d, Kcam, H: int, seed: int, M_dev=None, want_samples: bool = False):
+    import ctypes
+    dev = require_cuda(p3d, p2d)
+    p3d, p2d = _f32c(p3d), _f32c(p2d)
+    cap = p3d.shape[0]
+    M_dev = _m_dev(M_dev, dev, cap)
+    Rt = torch.empty((H, 3, 4), dtype=torch.float64, device=dev)
+    ok = torch.empty(H, dtype=torch.uint8, device=dev)
+    smp = torch.empty((H, 4), dtype=torch.int32, device=dev) if want_samples else None
+    k = _kcam(Kcam)
+    with torch.cuda.device(dev):
+        rc = lib().isr_p3p_hypotheses(ptr(p3d), ptr(p2d), ptr(M_dev), cap, ctypes.cast(k, ctypes.c_void_p),
+                                      H, seed & 0xFFFFFFFFFFFFFFFF, ptr(Rt), ptr(ok), ptr(smp),
+                                      current_stream(dev))
+    check(rc, "isr_p3p_hypotheses")
+    return (Rt, ok, smp) if want_samples else (Rt, ok)
+
+
+def ransac_score(p3d, p2d, Kcam, Rt, ok, reperr: float, M_dev=None):
+    import ctypes
+    dev = require_cuda(p3d, p2d, Rt, ok)
+    p3d, p2d, Rt = _f32c(p3d), _f32c(p2d), _f64c(Rt)
+    cap, H = p3d.shape[0], Rt.numel() // 12
+    M_dev = _m_dev(M_dev, dev, cap)
+    n_inl = torch.empty(H, dtype=torch.int32, device=dev)
+    best = torch.empty(1, dtype=torch.int32, device=dev)
+    mask = torch.zeros((cap + 31) // 32, dtype=torch.int32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_pnp_ransac_workspace_bytes(cap, H), "ransac")
+    k = _kcam(Kcam)
+    with torch.cuda.device(dev):
+        rc = L.isr_ransac_score(ptr(p3d), ptr(p2d), ptr(M_dev), cap, ctypes.cast(k, ctypes.c_void_p),
+                                ptr(Rt), ptr(ok.contiguous()), H, float(reperr), ptr(n_inl), ptr(best),
+                                ptr(mask), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_ransac_score")
+    return n_inl, best, mask
+
+
+def pnp_refine(p3d, p2d, Kcam, Rt0, mask=None, iters: int = 10, M_dev=None):
+    import ctypes
+    dev = require_cuda(p3d, p2d, Rt0)
+    p3d, p2d = _f32c(p3d), _f32c(p2d)
+    cap = p3d.shape[0]
+    M_dev = _m_dev(M_dev, dev, cap)
+    Rt = _f64c(Rt0).clone().reshape(3, 4)
+    L = lib()
+    ws = workspace(dev, 1 << 20, "refine")
+    k = _kcam(Kcam)
+    with torch.cuda.device(dev):
+        rc = L.isr_pnp_refine(ptr(p3d), ptr(p2d), ptr(M_dev), cap, ptr(mask), ctypes.cast(k, ctypes.c_void_p),
+                              int(iters), ptr(Rt), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_pnp_refine")
+    return Rt
+
+
+@dataclass
+class PnPResult:
+    pose: torch.Tensor      # (3,4) f64 device
+    inl_idx: torch.Tensor   # (cap,) i32 device, first n_inl valid
+    n_inl: torch.Tensor     # (1,) i32 device
+    status: torch.Tensor    # (1,) i32 device
+
+
+def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
+               refine_iters: int = 10, M_dev=None) -> PnPResult:
+    """isr_pnp_ransac, fully asynchronous: every output stays on the device."""
+    import ctypes
+    dev = require_cuda(p3d, p2d)
+    p3d, p2d = _f32c(p3d), _f32c(p2d)
+    cap = p3d.shape[0]
+    M_dev = _m_dev(M_dev, dev, cap)
+    pose = torch.empty((3, 4), dtype=torch.float64, device=dev)
+    inl = torch.empty(cap, dtype=torch.int32, device=dev)
+    n_inl = torch.zeros(1, dtype=torch.int32, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_pnp_ransac_workspace_bytes(cap, H), "ransac")
+    k = _kcam(Kcam)
+    with torch.cuda.device(dev):
+        rc = L.isr_pnp_ransac(ptr(p3d), ptr(p2d), ptr(M_dev), cap, ctypes.cast(k, ctypes.c_void_p), int(H),
+                              seed & 0xFFFFFFFFFFFFFFFF, float(reperr), int(refine_iters), ptr(pose),
+                              ptr(inl), ptr(n_inl), ptr(status), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_pnp_ransac")
+    return PnPResult(pose, inl, n_inl, status)

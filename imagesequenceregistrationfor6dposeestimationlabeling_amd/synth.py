@@ -1,0 +1,132 @@
+"""Synthetic stand-ins for the BOP inputs: no dataset, checkpoint or `dep/`
+package ships with the reference, so tests and bench.py drive the hot path from these generators.
+NumPy only, seeded; nothing here is on the measured path."""
+from __future__ import annotations
+
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+
+def _unit_sphere(rng, n):
+    v = rng.normal(size=(n, 3))
+    return v / np.linalg.norm(v, axis=1, keepdims=True)
+
+
+def bumpy_ellipsoid(rng, n, radii=(60.0, 40.0, 25.0)):
+    """Asymmetric bumpy ellipsoid, r * (1 + 0.15 sin(3 theta) cos(2 phi)) — config 1 (Ruapc-like)."""
+    d = _unit_sphere(rng, n)
+    theta = np.arccos(np.clip(d[:, 2], -1, 1))
+    phi = np.arctan2(d[:, 1], d[:, 0])
+    s = 1.0 + 0.15 * np.sin(3 * theta) * np.cos(2 * phi)
+    return (d * np.asarray(radii) * s[:, None]).astype(np.float32)
+
+
+def tless_like(rng, n):
+    """Box 60x40x30 with a cylinder boss (r=12, h=15) on top: discrete-symmetric solid — config 2."""
+    hx, hy, hz = 30.0, 20.0, 15.0
+    areas = np.array([4 * hy * hz, 4 * hy * hz, 4 * hx * hz, 4 * hx * hz, 4 * hx * hy, 4 * hx * hy,
+                      2 * np.pi * 12 * 15, np.pi * 144])
+    face = rng.choice(len(areas), size=n, p=areas / areas.sum())
+    u, v = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    p = np.zeros((n, 3))
+    for f, (ax, sg) in enumerate([(0, 1), (0, -1), (1, 1), (1, -1), (2, 1), (2, -1)]):
+        m = face == f
+        h = [hx, hy, hz]
+        o = [a for a in range(3) if a != ax]
+        p[m, ax] = sg * h[ax]
+        p[m, o[0]] = u[m] * h[o[0]]
+        p[m, o[1]] = v[m] * h[o[1]]
+    m = face == 6
+    ang = np.pi * u[m]
+    p[m] = np.stack([12 * np.cos(ang), 12 * np.sin(ang), hz + 7.5 * (v[m] + 1)], 1)
+    m = face == 7
+    rr = 12 * np.sqrt(0.5 * (u[m] + 1))
+    ang = np.pi * v[m]
+    p[m] = np.stack([rr * np.cos(ang), rr * np.sin(ang), np.full(m.sum(), hz + 15.0)], 1)
+    return p.astype(np.float32)
+
+
+def revolution(rng, n):
+    """Cylinder r=30, h=60 with a cone cap: continuous-symmetry object — config 4."""
+    part = rng.uniform(size=n) < 0.7
+    ang = rng.uniform(0, 2 * np.pi, n)
+    z = np.where(part, rng.uniform(-30, 30, n), 0.0)
+    r = np.full(n, 30.0)
+    tcone = rng.uniform(0, 1, n)
+    z = np.where(part, z, 30 + 25 * tcone)
+    r = np.where(part, r, 30 * (1 - tcone))
+    return np.stack([r * np.cos(ang), r * np.sin(ang), z], 1).astype(np.float32)
+
+
+def diameter(pts, sample=2000, rng=None):
+    rng = rng or np.random.default_rng(0)
+    s = pts[rng.choice(len(pts), min(sample, len(pts)), replace=False)].astype(np.float64)
+    d = np.linalg.norm(s[:, None] - s[None], axis=-1)
+    return float(d.max())
+
+
+def camera(width=640, height=480, f=None):
+    f = f or 1.2 * width
+    return np.array([[f, 0, (width - 1) / 2.0], [0, f, (height - 1) / 2.0], [0, 0, 1.0]])
+
+
+def random_poses(rng, n, tz=700.0, t_sigma=20.0):
+    R = Rotation.random(n, random_state=int(rng.integers(1 << 31))).as_matrix()
+    t = np.array([0.0, 0.0, tz]) + rng.normal(0, t_sigma, (n, 3))
+    return R, t
+
+
+def perturb_pose(rng, R, t, rot_deg, trans):
+    ax = _unit_sphere(rng, 1)[0]
+    dR = Rotation.from_rotvec(ax * np.deg2rad(rot_deg) * rng.uniform(0.3, 1.0)).as_matrix()
+    return dR @ R, t + rng.uniform(-trans, trans, 3)
+
+
+def project(K, R, t, X):
+    Xc = X.astype(np.float64) @ R.T + t
+    p = Xc @ K.T
+    return p[:, :2] / p[:, 2:3]
+
+
+def unit_keys(rng, N, D, tau=8.0):
+    """Key descriptors with |k| = tau (so a planted query's own key wins the dot product)."""
+    K = rng.normal(size=(N, D))
+    return (tau * K / np.linalg.norm(K, axis=1, keepdims=True)).astype(np.float32)
+
+
+def image_case(rng, keys, pts, Kcam, R, t, P, sigma=0.35, noise_px=0.5, outlier_frac=0.3):
+    """One second-sequence image: P query descriptors + their pixel coordinates.
+    gt_geo[p] is the key whose 3-D point really projects to pixel p; a fraction `outlier_frac` of
+    the descriptors is planted on a different, uniformly drawn key (wrong 2D-3D match)."""
+    N = len(keys)
+    gt_geo = rng.integers(N, size=P)
+    gt_match = gt_geo.copy()
+    out = rng.uniform(size=P) < outlier_frac
+    gt_match[out] = rng.integers(N, size=int(out.sum()))
+    Q = keys[gt_match] + sigma * rng.normal(size=(P, keys.shape[1])).astype(np.float32)
+    pix = project(Kcam, R, t, pts[gt_geo]) + noise_px * rng.normal(size=(P, 2))
+    return Q.astype(np.float32), pix.astype(np.float32), gt_match, gt_geo
+
+
+def pnp_case(rng, pts, Kcam, R, t, M, noise_px=0.5, outlier_frac=0.3):
+    """Correspondences for the RANSAC stage alone: p3d (M,3) f32, p2d (M,2) f32, inlier flags."""
+    idx = rng.integers(len(pts), size=M)
+    p2d = project(Kcam, R, t, pts[idx]) + noise_px * rng.normal(size=(M, 2))
+    out = rng.uniform(size=M) < outlier_frac
+    idx3 = idx.copy()
+    idx3[out] = rng.integers(len(pts), size=int(out.sum()))
+    return pts[idx3].astype(np.float32), p2d.astype(np.float32), ~out
+
+
+def split_halves(rng, cloud, n_each, overlap=5.0):
+    """Upper / lower halves of an object with an overlap band (two NeRF reconstructions)."""
+    up = cloud[cloud[:, 2] > -overlap]
+    lo = cloud[cloud[:, 2] < overlap]
+    up = up[rng.choice(len(up), n_each, replace=len(up) < n_each)]
+    lo = lo[rng.choice(len(lo), n_each, replace=len(lo) < n_each)]
+    return up.astype(np.float32), lo.astype(np.float32)
+
+
+def rot_angle(Ra, Rb):
+    c = (np.trace(Ra.T @ Rb) - 1) / 2
+    return float(np.arccos(np.clip(c, -1, 1)))

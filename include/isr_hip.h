@@ -97,7 +97,8 @@ int isr_gather_corr(const int32_t* idx, const int32_t* keep, const int32_t* M_de
  *   the fourth.  Rt (H,12) f64 row-major [R|t]; ok (H) u8; sample (H,4) i32 (nullable).
  * isr_ransac_score: n_inl[h] = #{m : z>0 and |proj_h(p3d[m]) - p2d[m]|^2 <= reperr^2} in f32,
  *   evaluated division-free; best_dev = argmax (lowest h on ties, ok hypotheses only),
- *   best_mask = inlier bitmask of the best hypothesis, ceil(M_cap/32) words.
+ *   best_mask = inlier bitmask of the best hypothesis, ceil(M_cap/32) words (nullable);
+ *   ws as for isr_pnp_ransac.
  * isr_pnp_refine: `iters` Gauss-Newton steps (f64) on the reprojection error over the masked
  *   correspondences, starting from Rt_io (12 f64), result written back.
  * isr_pnp_ransac: the three above + inlier index compaction, one enqueue.
@@ -111,7 +112,8 @@ int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int32_t* M_dev,
                        int32_t* sample, isr_stream_t stream);
 int isr_ransac_score(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
                      const double* Kcam, const double* Rt, const uint8_t* ok, int H, float reperr,
-                     int32_t* n_inl, int32_t* best_dev, uint32_t* best_mask, isr_stream_t stream);
+                     int32_t* n_inl, int32_t* best_dev, uint32_t* best_mask, void* ws,
+                     size_t ws_bytes, isr_stream_t stream);
 int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
                    const uint32_t* mask, const double* Kcam, int iters, double* Rt_io, void* ws,
                    size_t ws_bytes, isr_stream_t stream);
