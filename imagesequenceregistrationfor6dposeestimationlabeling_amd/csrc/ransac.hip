@@ -279,6 +279,8 @@ __global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restric
     philox4x32_10((uint32_t)h, 0u, 0u, 0u, seed_lo, seed_hi, rnd);
 #pragma unroll
     for (int j = 0; j < 4; ++j) s[j] = (int)(((uint64_t)rnd[j] * (uint64_t)M) >> 32);
+    // a sample that repeats a correspondence is rejected (degenerate, and its 4th-point test ties)
+    const bool distinct = s[0] != s[1] && s[0] != s[2] && s[0] != s[3] && s[1] != s[2] && s[1] != s[3] && s[2] != s[3];
     P3PIn in;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -289,7 +291,7 @@ __global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restric
       in.y[j] = scale(y, 1.0 / sqrt(dot(y, y)));
     }
     double lam[4][3];
-    const int n = p3p_depths(in, lam);
+    const int n = distinct ? p3p_depths(in, lam) : 0;
     const V3 X4 = {(double)p3d[3 * (size_t)s[3]], (double)p3d[3 * (size_t)s[3] + 1], (double)p3d[3 * (size_t)s[3] + 2]};
     const double u4 = p2d[2 * (size_t)s[3]], v4 = p2d[2 * (size_t)s[3] + 1];
     double best = 1e300;

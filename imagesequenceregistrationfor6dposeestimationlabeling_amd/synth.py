@@ -128,5 +128,6 @@ def split_halves(rng, cloud, n_each, overlap=5.0):
 
 
 def rot_angle(Ra, Rb):
-    c = (np.trace(Ra.T @ Rb) - 1) / 2
-    return float(np.arccos(np.clip(c, -1, 1)))
+    """Rotation angle between two rotations, stable near 0: |Ra - Rb|_F = 2 sqrt(2) sin(angle / 2)."""
+    f = np.linalg.norm(np.asarray(Ra, np.float64) - np.asarray(Rb, np.float64))
+    return float(2.0 * np.arcsin(min(1.0, f / (2.0 * np.sqrt(2.0)))))

@@ -131,7 +131,10 @@ def project(K, R, t, X):
 
 
 def hypothesis(p3d, p2d, K, idx4):
-    """Best P3P root of one 4-sample (or None): [R|t] (3,4) f64."""
+    """Best P3P root of one 4-sample (or None): [R|t] (3,4) f64.  Samples that repeat a
+    correspondence are rejected."""
+    if len(set(int(i) for i in idx4)) < 4:
+        return None
     X = p3d[idx4[:3]].astype(np.float64)
     uv = p2d[idx4[:3]].astype(np.float64)
     best, be = None, np.inf
