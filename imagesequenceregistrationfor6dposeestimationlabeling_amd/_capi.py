@@ -53,6 +53,7 @@ SIGNATURES = {
     "isr_nn_batched_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_nn_batched": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _sz, _vp]),
+    "isr_add_metric": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
     "isr_rel_pose_table": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 

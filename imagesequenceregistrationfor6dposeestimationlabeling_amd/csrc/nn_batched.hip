@@ -229,6 +229,31 @@ __global__ void nn_reduce_kernel(const double* __restrict__ part_sums, int nblk,
   if (k == 3 && cov) cov[(size_t)b * 16 + 15] = 0.0;
 }
 
+
+// a8 ADD (inference.py:116-117): mean_v || Ta v - Tb v ||, one block per pose pair, f64.
+__global__ __launch_bounds__(kThreads) void add_metric_kernel(const float* __restrict__ verts, int V,
+                                                              const double* __restrict__ Ta,
+                                                              const double* __restrict__ Tb,
+                                                              double* __restrict__ out) {
+  __shared__ double red[kThreads / 64];
+  const int b = blockIdx.x;
+  const double* ta = Ta ? Ta + 12 * (size_t)b : nullptr;
+  const double* tb = Tb ? Tb + 12 * (size_t)b : nullptr;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < V; i += kThreads) {
+    const float x = verts[3 * (size_t)i], y = verts[3 * (size_t)i + 1], z = verts[3 * (size_t)i + 2];
+    double a0, a1, a2, b0, b1, b2;
+    xform64(ta, x, y, z, a0, a1, a2);
+    xform64(tb, x, y, z, b0, b1, b2);
+    const double ex = a0 - b0, ey = a1 - b1, ez = a2 - b2;
+    s += sqrt(fma(ez, ez, fma(ey, ey, ex * ex)));
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] = (((red[0] + red[1]) + red[2]) + red[3]) / (double)V;
+}
+
 struct NNPlan {
   int rq;          // queries per lane
   int qblocks;     // search grid.x
@@ -324,5 +349,14 @@ extern "C" int isr_nn_batched(const float* qry, int Nq, const float* tgt, int Nt
                                                          n_in, cov);
     ISR_CHECK_LAUNCH("nn_reduce_kernel");
   }
+  return ISR_OK;
+}
+
+extern "C" int isr_add_metric(const float* verts, int V, const double* Ta, const double* Tb, int B,
+                              double* mean_out, isr_stream_t stream) {
+  ISR_REQUIRE(verts && mean_out, "isr_add_metric: null pointer");
+  ISR_REQUIRE(V > 0 && B > 0, "isr_add_metric: V=%d B=%d", V, B);
+  add_metric_kernel<<<B, kThreads, 0, isr::as_stream(stream)>>>(verts, V, Ta, Tb, mean_out);
+  ISR_CHECK_LAUNCH("add_metric_kernel");
   return ISR_OK;
 }

@@ -262,3 +262,15 @@ def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
                               ptr(inl), ptr(n_inl), ptr(status), ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_pnp_ransac")
     return PnPResult(pose, inl, n_inl, status)
+
+
+def add_metric(verts: torch.Tensor, Ta: torch.Tensor | None, Tb: torch.Tensor | None) -> torch.Tensor:
+    """isr_add_metric: (B,) f64 mean vertex distance between poses Ta[b] and Tb[b]."""
+    dev = require_cuda(verts, Ta, Tb)
+    verts, Ta, Tb = _f32c(verts), _f64c(Ta), _f64c(Tb)
+    B = max([1] + [T.numel() // 12 for T in (Ta, Tb) if T is not None])
+    out = torch.empty(B, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_add_metric(ptr(verts), verts.shape[0], ptr(Ta), ptr(Tb), B, ptr(out), current_stream(dev))
+    check(rc, "isr_add_metric")
+    return out

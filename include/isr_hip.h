@@ -145,6 +145,11 @@ int isr_nn_batched(const float* qry, int Nq, const float* tgt, int Nt, const dou
                    int32_t* n_in, int32_t* nn_idx, double* nn_d, double* cov, void* ws,
                    size_t ws_bytes, isr_stream_t stream);
 
+/* a8  ADD(verts, gtR, gtT, R, T)   inference.py:116-117
+ * mean_out[b] = mean_v || Ta[b] v - Tb[b] v ||  (f64; Ta/Tb (B,12) f64 [R|t], NULL = identity). */
+int isr_add_metric(const float* verts, int V, const double* Ta, const double* Tb, int B,
+                   double* mean_out, isr_stream_t stream);
+
 /* a10 / a12  relative-pose tables, rows [i0, i1) of the n x n table, written as (i1-i0, n, 12) f64.
  * mode 0: compute_rel_poses       choosePose.py:43-51  ->  [R_i^T R_j | t_j - t_i]
  * mode 1: calculate_relative_pose verfication.py:9-19  ->  [R_j|t_j] * inv([R_i|t_i])
