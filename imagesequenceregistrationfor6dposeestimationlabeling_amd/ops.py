@@ -11,6 +11,47 @@ from ._capi import check, current_stream, lib, ptr, require_cuda
 
 _workspaces: dict[tuple, torch.Tensor] = {}
 
+# Optional per-entry-point HIP-event timing (bench.py's live roofline measurement): when enabled,
+# every wrapper brackets its C-ABI call with events on the stream it launches on and records
+# (start, end, algorithmic work).  Off by default: no events, no overhead.
+_timers: dict[str, list] | None = None
+
+
+def enable_timing(on: bool = True) -> None:
+    global _timers
+    _timers = {} if on else None
+
+
+def drain_timing() -> dict[str, tuple[int, float, float]]:
+    """-> {name: (calls, total_ms, total_work)}; synchronises.  Clears the records."""
+    out = {}
+    if _timers is None:
+        return out
+    torch.cuda.synchronize()
+    for name, recs in _timers.items():
+        ms = sum(a.elapsed_time(b) for a, b, _ in recs)
+        out[name] = (len(recs), ms, float(sum(w for _, _, w in recs)))
+    _timers.clear()
+    return out
+
+
+class _timed:
+    def __init__(self, name: str, work: float):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if _timers is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _timers is not None:
+            self.e1.record()
+            _timers.setdefault(self.name, []).append((self.e0, self.e1, self.work))
+        return False
+
 
 def workspace(device: torch.device, nbytes: int, tag: str = "default") -> torch.Tensor:
     """A cached, grow-only scratch buffer per (device, stream, tag)."""
@@ -67,7 +108,7 @@ def nn_batched(qry: torch.Tensor, tgt: torch.Tensor, Tq: torch.Tensor | None = N
     cov = torch.empty((B, 16), dtype=torch.float64, device=dev) if want_cov else None
     nbytes = L.isr_nn_batched_workspace_bytes(Nq, Nt, B)
     ws = workspace(dev, nbytes, "nn")
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("nn_batched", float(B) * Nq * Nt):
         rc = L.isr_nn_batched(ptr(qry), Nq, ptr(tgt), Nt, ptr(Tq), ptr(Tt), B, float(radius),
                               ptr(sum_d), ptr(sum_d2), ptr(n_in), ptr(nn_idx), ptr(nn_d), ptr(cov),
                               ptr(ws), ws.numel(), current_stream(dev))
@@ -127,7 +168,7 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     L = lib()
     nbytes = L.isr_corr_argmax_workspace_bytes(P, N, Dp, dtype)
     ws = workspace(dev, nbytes, "corr")
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("corr_argmax", 2.0 * P * N * Dp):
         rc = L.isr_corr_argmax(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, ptr(idx), ptr(logp), ptr(lse),
                                ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_corr_argmax")
@@ -144,7 +185,7 @@ def select_top(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500):
     thr = torch.empty(1, dtype=torch.float32, device=dev)
     L = lib()
     ws = workspace(dev, L.isr_select_top_workspace_bytes(P), "select")
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("select_top", 4.0 * P):
         rc = L.isr_select_top(ptr(logp), P, float(frac), int(min_n), ptr(keep), ptr(M_dev), ptr(thr),
                               ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_select_top")
@@ -256,7 +297,7 @@ def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
     L = lib()
     ws = workspace(dev, L.isr_pnp_ransac_workspace_bytes(cap, H), "ransac")
     k = _kcam(Kcam)
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timed("pnp_ransac", 30.0 * H * cap):
         rc = L.isr_pnp_ransac(ptr(p3d), ptr(p2d), ptr(M_dev), cap, ctypes.cast(k, ctypes.c_void_p), int(H),
                               seed & 0xFFFFFFFFFFFFFFFF, float(reperr), int(refine_iters), ptr(pose),
                               ptr(inl), ptr(n_inl), ptr(status), ptr(ws), ws.numel(), current_stream(dev))

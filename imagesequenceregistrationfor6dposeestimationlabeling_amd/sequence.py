@@ -1,0 +1,77 @@
+"""The per-sequence driver: what finalposes.py:105-238 / choosePose.py:154-309 (per-image
+registration), verfication.py:61-108 (consecutive-pair Chamfer pick) and icp.py:37-126 (ICP +
+final Chamfer) do, as one asynchronous pipeline per image on the HIP stream and one reduction per
+sequence.  Everything between the encoder output and the pose stays on the device: the reference's
+idx.cpu() / nidx.cpu() round trips (inference.py:273-290) are gone because the kept count M and
+the RANSAC status live in device memory.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import ops, registration, shard
+
+
+@dataclass
+class SequenceModel:
+    """First-sequence model as exported by genFeat.py:223-228 (vert1_scaled / feat1_scaled)."""
+    keys: torch.Tensor   # (N, D) descriptors on the device, bf16 (MFMA bf16 path) or f32 (exact path)
+    pts: torch.Tensor    # (N, 3) f32 surface points, mm
+
+
+@dataclass
+class ImageResult:
+    pose: torch.Tensor     # (3,4) f64 device [R|t]
+    status: torch.Tensor   # (1,) i32 device
+    n_inl: torch.Tensor    # (1,) i32 device
+    inl_idx: torch.Tensor  # (P,) i32 device (first n_inl valid; indices into the kept set)
+    keep: torch.Tensor     # (P,) i32 device (first M valid): nidx of inference.py:289
+    M: torch.Tensor        # (1,) i32 device
+    idx: torch.Tensor      # (P,) i32 device: idx1 of inference.py:273
+    logp: torch.Tensor     # (P,) f32 device: in1[:,0]
+
+
+def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Tensor, cam,
+                   itr: int = 500, reperr: float = 2.0, seed: int = 0, refine_iters: int = 10,
+                   timing: list | None = None) -> ImageResult:
+    """inference.py:273-293 for one image, fully enqueued (no host synchronisation):
+    getCors -> top-80 % filter -> correspondence assembly -> pnp(itr, reperr, P3P)."""
+    if timing is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    idx, logp = ops.corr_argmax(queries, model.keys)
+    if timing is not None:
+        e1.record()
+        timing.append((e0, e1))
+    keep, M, _ = ops.select_top(logp)
+    p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix_xy)
+    r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M)
+    return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp)
+
+
+def stack_poses(results: list[ImageResult]) -> tuple[torch.Tensor, torch.Tensor]:
+    """(n,12) f64 poses and (n,) status, still on the device."""
+    return (torch.stack([r.pose.reshape(12) for r in results]),
+            torch.cat([r.status for r in results]))
+
+
+def pick_by_chamfer(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.ndarray, t_gt_all: np.ndarray,
+                    n_total: int) -> tuple[int, float]:
+    """verfication.py:61-108 sharded: this rank evaluates the consecutive pairs it owns, then one
+    packed all-reduce(MIN) picks the global first minimum.  poses_all (n,12) predicted poses of ALL
+    images (after the all-gather), R_gt_all/t_gt_all the GT poses from scene_gt.json."""
+    rank, size = shard.world()
+    lo, hi = shard.owned_pairs(n_total, rank, size)
+    best = (None, 0)
+    if hi > lo:
+        Rp = poses_all.reshape(-1, 3, 4)[lo:hi + 1, :, :3].cpu().numpy()
+        Rrel = np.stack([registration.calculate_relative_pose(R_gt_all[i], t_gt_all[i], R_gt_all[i + 1],
+                                                              t_gt_all[i + 1])[0] for i in range(lo, hi)])
+        ch = registration.chamfer_pairs(pc1, Rp, Rrel)
+        i, v = registration.choose_best(ch)
+        best = (float(np.float32(v)), lo + i)
+    val, idx = shard.allreduce_min_pair(best[0], best[1])
+    return idx, val

@@ -1,0 +1,74 @@
+"""N > 1 path on CPU: world_size-2 gloo processes exercise the block partition, the pose
+all-gather and the packed (min, idx) all-reduce exactly as the GPU ranks use them."""
+import os
+import socket
+import struct
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import shard
+
+
+def test_block_range_partitions():
+    for n in (1, 7, 64, 512, 513):
+        for size in (1, 2, 3, 8):
+            blocks = [shard.block_range(n, r, size) for r in range(size)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(size - 1))
+            pairs = [shard.owned_pairs(n, r, size) for r in range(size)]
+            covered = [i for lo, hi in pairs for i in range(lo, hi)]
+            assert covered == list(range(n - 1))
+
+
+def test_pack_min_orders_like_value_then_index():
+    rng = np.random.default_rng(0)
+    vals = np.abs(rng.normal(size=200)).astype(np.float32)
+    vals[10] = vals[3]                       # a tie: the lower index must win
+    packed = [shard.pack_min(float(v), i) for i, v in enumerate(vals)]
+    v, i = shard.unpack_min(min(packed))
+    assert i == int(np.argmin(vals)) and v == vals.min()
+    assert shard.unpack_min(shard.EMPTY)[0] == float("inf")
+    with pytest.raises(ValueError):
+        shard.pack_min(-1.0, 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, size, port, n, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size))
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        lo, hi = shard.block_range(n, rank, size)
+        full = torch.arange(n * 12, dtype=torch.float64).reshape(n, 12)
+        got = shard.allgather_rows(full[lo:hi].clone(), n)
+        assert torch.equal(got, full)
+        # every rank proposes the minimum of its own pairs of a fixed vector
+        ch = np.abs(np.sin(np.arange(n - 1) * 1.7)).astype(np.float32)
+        ch[5] = ch[n - 3] = ch.min()          # global tie across ranks: first index wins
+        plo, phi = shard.owned_pairs(n, rank, size)
+        loc = (None, 0) if phi <= plo else (float(ch[plo:phi].min()), plo + int(np.argmin(ch[plo:phi])))
+        v, i = shard.allreduce_min_pair(loc[0], loc[1])
+        ret[rank] = (v, i)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [9, 64])
+def test_world2_gather_and_min_reduce(n):
+    size, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(size, port, n, ret), nprocs=size, join=True)
+        ch = np.abs(np.sin(np.arange(n - 1) * 1.7)).astype(np.float32)
+        ch[5] = ch[n - 3] = ch.min()
+        for r in range(size):
+            v, i = ret[r]
+            assert i == int(np.argmin(ch)) and v == float(ch.min())
