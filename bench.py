@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--itr", type=int, default=500)
     ap.add_argument("--cad", type=int, default=5000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg")
     return ap.parse_args()
 
 
@@ -92,7 +93,8 @@ def make_image(dev, keys_f32, pts, Kcam, R, t, P, seed):
 def cpu_baseline(args, keys_bf16, pts, Q0, pix0, Kcam, upper, lower, cad, R_gt, t_gt):
     """The CPU oracle on a bounded sample of one image's work, scaled to images/s."""
     from oracle import cbind, pnp_oracle, registration_oracle as ro
-    cores = os.cpu_count() or 1
+    # the box exposes every host core but a 1-GPU job's share is 16 (see the task's Environment notes)
+    cores = min(len(os.sched_getaffinity(0)), args.cpu_threads)
     torch.set_num_threads(cores)
     P, N = Q0.shape[0], keys_bf16.shape[0]
     Ps = min(P, 16384)
@@ -106,7 +108,7 @@ def cpu_baseline(args, keys_bf16, pts, Q0, pix0, Kcam, upper, lower, cad, R_gt, 
     nidx = ro.filter_top(full_vals)
     t_filt = time.perf_counter() - t0
     # RANSAC: Hs hypotheses on Ms correspondences, scaled to itr x 0.8 P
-    Ms, Hs = 20000, 16
+    Ms, Hs = min(20000, Ps), 16
     p3d = pts.cpu().numpy()[idx.numpy()[:Ms] % N]
     p2d = pix0[:Ms].cpu().numpy()
     t0 = time.perf_counter()
@@ -241,8 +243,11 @@ def main():
             "stage_ms_per_step": {k: v[1] / args.steps for k, v in timing.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, keys, pts, images[0][0], images[0][1], Kcam, upper, lower,
-                                                cad, R_gt, t_gt)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args, keys, pts, images[0][0], images[0][1], Kcam, upper,
+                                                    lower, cad, R_gt, t_gt)
+            except Exception as e:  # the GPU line must survive a checker-side failure
+                line["cpu_baseline"] = {"value": None, "error": repr(e), "kind": "port"}
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.barrier()

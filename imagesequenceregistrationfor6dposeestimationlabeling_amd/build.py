@@ -28,6 +28,9 @@ HIPCC_FLAGS = [
     "-fPIC",
     "-ffp-contract=off",
     "-fno-fast-math",
+    # MFMA results land in VGPRs (gfx950's register file is unified): the softmax epilogue reads
+    # every accumulator three times, and AGPR accumulators cost a v_accvgpr_read per read.
+    "-mllvm", "-amdgpu-mfma-vgpr-form",
     "-Wall",
     "-Wno-unused-function",
 ]

@@ -23,6 +23,8 @@
 // a k-ordered fmaf chain — oracle/isr_oracle.c:orc_corr_argmax_f32 reproduces its logits exactly.
 #include "isr_common.hpp"
 
+#include <type_traits>
+
 namespace {
 
 using bf16x8 = __attribute__((ext_vector_type(8))) short;
@@ -30,9 +32,13 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kQB = 2;                       // 32-query blocks per wave
-constexpr int kQPerBlock = kWaves * kQB * 32;  // 256 queries per workgroup
-constexpr int kTK = 64;                      // keys per LDS stage
+constexpr int kQB = 2;                       // 32-query blocks per wave (f32 kernel)
+constexpr int kQPerBlock = kWaves * kQB * 32;  // 256 queries per workgroup (f32 kernel)
+#ifndef ISR_BF16_QB
+#define ISR_BF16_QB 2
+#endif
+constexpr int kQBbf16 = ISR_BF16_QB;         // 32-query blocks per wave, bf16 kernel (D <= 64)
+constexpr int kTK = 128;                     // keys per LDS stage
 constexpr float kLog2e = 1.4426950408889634f;
 // M2 of a lane that has seen no valid key yet: finite, so a fully masked tile gives
 // exp2(fma(-inf, log2e, 1e30)) = 0 instead of NaN, and the first real key rescales l by 2^-huge = 0.
@@ -47,13 +53,23 @@ struct LaneState {
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-// Consume one accumulator tile: rows kb + 4h + (r&3) + 8(r>>2), r = 0..15, of this lane's query.
-__device__ __forceinline__ void consume_tile(const f32x16& acc, int krow0, LaneState& st) {
+// Part A of consuming a tile (rows kb + 4h + (r&3) + 8(r>>2), r = 0..15, of this lane's query):
+// the running maximum / arg-max and the integer log2 reference M2.
+__device__ __forceinline__ void update_max(const f32x16& acc, int krow0, LaneState& st) {
+#ifdef ISR_ABL_NOMAX  // timing-only ablation (tools/ablate_corr.hip): keep acc live, skip part A
+  asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
+  (void)krow0; (void)st;
+  return;
+#endif
   const float x0 = max3(acc[0], acc[1], acc[2]), x1 = max3(acc[3], acc[4], acc[5]),
               x2 = max3(acc[6], acc[7], acc[8]), x3 = max3(acc[9], acc[10], acc[11]),
               x4 = max3(acc[12], acc[13], acc[14]);
   const float t = fmaxf(max3(x0, x1, x2), max3(x3, x4, acc[15]));
-  if (__any(t > st.m)) {  // wave-uniform; rare once the running max has settled
+#ifdef ISR_ABL_NOUPD  // timing-only ablation: maximum without the arg-max/rescale branch
+  st.m = fmaxf(st.m, t);
+  return;
+#endif
+  if (__any(t > st.m)) {  // wave-uniform; taken for ~64(1 + ln(tiles/64)) of a key range's tiles
     if (t > st.m) {
       int r = 15;
 #pragma unroll
@@ -65,9 +81,51 @@ __device__ __forceinline__ void consume_tile(const f32x16& acc, int krow0, LaneS
       st.m = t;
     }
   }
+}
+
+// Part B: l += sum_i 2^(acc_i log2e - M2).
+__device__ __forceinline__ void accumulate_exp(const f32x16& acc, LaneState& st) {
   const float nM2 = -st.M2;
 #pragma unroll
   for (int i = 0; i < 16; ++i) st.l += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i], kLog2e, nM2));
+}
+
+__device__ __forceinline__ void consume_tile(const f32x16& acc, int krow0, LaneState& st) {
+  update_max(acc, krow0, st);
+  accumulate_exp(acc, st);
+}
+
+// Part B of tile `cur` interleaved with the DK MFMAs of the next tile, so one wave keeps both the
+// matrix pipe and the VALU/transcendental pipe fed (co-resident waves run this same program in
+// lockstep, so overlap cannot be left to chance between waves — measured: 14 % co-execution).
+template <int DK>
+__device__ __forceinline__ f32x16 exp_and_next_mfma(const f32x16& cur, LaneState& st,
+                                                    const bf16x8 (&a)[DK], const bf16x8 (&b)[DK]) {
+  constexpr int E = 16 / DK > 0 ? 16 / DK : 1;  // exp elements per MFMA
+  const float nM2 = -st.M2;
+  float l = st.l;
+  f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < DK; ++s) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], c, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int i = s * E + e;
+#ifdef ISR_ABL_NOEXP  // timing-only ablation: keep the accumulator live, no fma/exp/add
+      if (i < 16) asm volatile("" :: "v"(cur[i]));
+#else
+      if (i < 16) l += __builtin_amdgcn_exp2f(__builtin_fmaf(cur[i], kLog2e, nM2));
+#endif
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, 3 * E, 0);  // then this step's fma/exp/add
+  }
+  if (DK * E < 16) {
+#pragma unroll
+    for (int i = DK * E; i < 16; ++i) l += __builtin_amdgcn_exp2f(__builtin_fmaf(cur[i], kLog2e, nM2));
+  }
+  st.l = l;
+  return c;
 }
 
 __device__ __forceinline__ void mask_tail(f32x16& acc, int krow0, int N) {
@@ -105,7 +163,12 @@ __device__ __forceinline__ void store_partial(const LaneState& st_, int q, int P
 }
 
 // ------------------------------------------------------------------------------------ bf16
-template <int DK>  // D = 16 * DK, DK in {1, 2, 4, 8}
+// Keys are staged through LDS once per workgroup (coalesced 16-byte global loads, XOR-swizzled
+// image, ds_read_b128 in MFMA operand layout) and shared by the workgroup's four waves.
+// (Tried and rejected, measured on MI355X: every wave streaming its own A fragments straight from
+// global memory — no LDS, no barrier — is bound by the CU's vector L1: 245 ns per tile against
+// 202 ns here, with the epilogue entirely hidden behind the loads.)
+template <int DK, int QB>  // D = 16 * DK, DK in {1, 2, 4, 8}; QB 32-query blocks per wave
 __global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
@@ -119,11 +182,11 @@ __global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
   const int split = blockIdx.y;
-  const int q0 = (blockIdx.x * kWaves + wave) * (kQB * 32);
+  const int q0 = (blockIdx.x * kWaves + wave) * (QB * 32);
 
-  bf16x8 bq[kQB][DK];
+  bf16x8 bq[QB][DK];
 #pragma unroll
-  for (int qb = 0; qb < kQB; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     int row = q0 + qb * 32 + r;
     row = row < P ? row : P - 1;
     const uint16_t* src = Q + (size_t)row * ldq + 8 * h;
@@ -131,9 +194,9 @@ __global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
     for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
   }
 
-  LaneState st[kQB];
+  LaneState st[QB];
 #pragma unroll
-  for (int qb = 0; qb < kQB; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     st[qb].m = -__builtin_inff(); st[qb].M2 = kNoM2; st[qb].l = 0.f; st[qb].bi = 0;
   }
 
@@ -162,48 +225,72 @@ __global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
       if (ci < CHUNKS) lds[buf][row * NCH + (c ^ ((row / RPB) & (NCH - 1)))] = stg[i];
     }
   };
+  // A fragments of key sub-tile `sub` of LDS buffer `buf`
+  bf16x8 a[DK];
+  auto load_a = [&](int buf, int sub) {
+    const int row = sub * 32 + r;
+    const int sw = (row / RPB) & (NCH - 1);
+#pragma unroll
+    for (int s = 0; s < DK; ++s) {
+      const uint4 v = lds[buf][row * NCH + ((2 * s + h) ^ sw)];
+      a[s] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  };
 
-  if (nstage > 0) { gload(0); lwrite(0); }
+  // Software pipeline over the stage's work items w = (sub, qb): while item w's logits go through
+  // the softmax epilogue, the MFMAs of item w + 1 run.  The stage barrier sits before the LAST
+  // item's epilogue (all LDS reads of the stage are done by then), so the first MFMAs of the next
+  // stage overlap that epilogue too.  Two named accumulators alternate by the (static) item
+  // parity: no register copies between items.
+  constexpr int NSUB = kTK / 32, NW = NSUB * QB;
+  static_assert(NW % 2 == 0, "items per stage must be even for the accumulator ping-pong");
+  gload(0);
+  lwrite(0);
   __syncthreads();
-  for (int stage = 0; stage < nstage; ++stage) {
+  load_a(0, 0);
+  f32x16 acc[2];
+  acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int s = 0; s < DK; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[0][s], acc[0], 0, 0, 0);
+
+  // FULL stages (every key of the stage exists) run without any per-item condition, so the two
+  // accumulators never meet in a phi and the compiler keeps them in place (a v_mov between the
+  // MFMA chain and the epilogue would stall the in-order wave until the chain retires).
+  // The last, partial stage takes the guarded body.
+  auto stage_body = [&](int stage, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
     const int buf = stage & 1;
-    if (stage + 1 < nstage) gload(stage + 1);
+    const bool has_next = stage + 1 < nstage;
+    if (has_next) gload(stage + 1);
 #pragma unroll
-    for (int sub = 0; sub < kTK / 32; ++sub) {
+    for (int w = 0; w < NW; ++w) {
+      const int sub = w / QB, qb = w % QB;
+      const int qbn = (w + 1) % QB;
+      if (w + 1 == NW) {
+        if (has_next) lwrite(buf ^ 1);
+        __syncthreads();
+        if (has_next) load_a(buf ^ 1, 0);
+      } else if (qbn == 0) {
+        load_a(buf, sub + 1);
+      }
       const int kb = k0 + stage * kTK + sub * 32;
-      if (kb < k1) {  // wave-uniform
-        const int row = sub * 32 + r;
-        const int sw = (row / RPB) & (NCH - 1);
-        bf16x8 a[DK];
-#pragma unroll
-        for (int s = 0; s < DK; ++s) {
-          const uint4 v = lds[buf][row * NCH + ((2 * s + h) ^ sw)];
-          a[s] = *reinterpret_cast<const bf16x8*>(&v);
-        }
-        f32x16 acc[kQB];
-#pragma unroll
-        for (int qb = 0; qb < kQB; ++qb) {
-          f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-          for (int s = 0; s < DK; ++s)
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qb][s], c, 0, 0, 0);
-          acc[qb] = c;
-        }
-        const int krow0 = kb + 4 * h;
-        if (kb + 32 > k1) {
-#pragma unroll
-          for (int qb = 0; qb < kQB; ++qb) mask_tail(acc[qb], krow0, k1);
-        }
-#pragma unroll
-        for (int qb = 0; qb < kQB; ++qb) consume_tile(acc[qb], krow0, st[qb]);
+      const int krow0 = kb + 4 * h;
+      if (FULL) {
+        update_max(acc[w & 1], krow0, st[qb]);
+        acc[(w + 1) & 1] = exp_and_next_mfma<DK>(acc[w & 1], st[qb], a, bq[qbn]);
+      } else if (kb < k1) {  // block-uniform
+        if (kb + 32 > k1) mask_tail(acc[w & 1], krow0, k1);
+        update_max(acc[w & 1], krow0, st[qb]);
+        acc[(w + 1) & 1] = exp_and_next_mfma<DK>(acc[w & 1], st[qb], a, bq[qbn]);
       }
     }
-    if (stage + 1 < nstage) lwrite(buf ^ 1);
-    __syncthreads();
-  }
+  };
+  const int nfull = (k1 - k0) / kTK;  // stages whose kTK keys all exist
+  for (int stage = 0; stage < nfull; ++stage) stage_body(stage, std::true_type{});
+  if (nfull < nstage) stage_body(nfull, std::false_type{});
 
 #pragma unroll
-  for (int qb = 0; qb < kQB; ++qb) store_partial(st[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
+  for (int qb = 0; qb < QB; ++qb) store_partial(st[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
 }
 
 // ------------------------------------------------------------------------------------- f32
@@ -319,30 +406,78 @@ __global__ void corr_finalize_kernel(int P, int nsplit, const float* __restrict_
   if (lse) lse[q] = (float)((double)a.m - lp);
 }
 
+// upper bound on nsplit (also sizes the workspace, which must not depend on the device)
+constexpr int kMaxSplit = 64;
+
 struct CorrPlan {
   int qblocks, nsplit, split_len;
 };
 
-CorrPlan make_plan(int P, int N) {
+// Work units = (query block, key range).  Splitting the key range costs VALU work: every split
+// restarts its running maximum, and the arg-max update path (taken whenever ANY of a wave's 64
+// lanes improves, i.e. for ~64(1 + ln(tiles/64)) of a split's tiles) is the expensive part of the
+// epilogue — measured: 23 splits raised VALU instructions per tile from ~75 to 113.  So the range
+// is split only when the query blocks alone cannot fill the machine (small P, e.g. the
+// reference's 75x75 crops), and then just enough to give every resident slot one unit.
+// Launch tails of large-P calls are hidden by the caller pipelining images over streams.
+CorrPlan make_plan(int P, int N, int slots, int q_per_block) {
   CorrPlan p;
-  p.qblocks = (P + kQPerBlock - 1) / kQPerBlock;
+  p.qblocks = (P + q_per_block - 1) / q_per_block;
   const int max_split = (N + kTK - 1) / kTK;
-  long ns = (1024 + p.qblocks - 1) / p.qblocks;  // aim for >= 4 workgroups per CU
+  int ns = 1;
+  if (p.qblocks < slots) ns = (slots + p.qblocks - 1) / p.qblocks;
   if (ns > max_split) ns = max_split;
-  if (ns < 1) ns = 1;
-  const int stages = (max_split + (int)ns - 1) / (int)ns;
+  if (ns > kMaxSplit) ns = kMaxSplit;
+  const int stages = (max_split + ns - 1) / ns;
   p.split_len = stages * kTK;
   p.nsplit = (N + p.split_len - 1) / p.split_len;
   return p;
 }
 
+template <typename Kern>
+int resident_slots(Kern kern) {
+  int dev = 0, cus = 256, per_cu = 4;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kThreads, 0) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 4;
+    }
+  } else {
+    (void)hipGetLastError();
+  }
+  return cus * per_cu;
+}
+
+int slots_for(int dtype, int D) {
+  // cached per (dtype, padded D): the occupancy query costs tens of microseconds
+  static int cache[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  int v = 0;
+  if (dtype == ISR_DTYPE_BF16) v = (D <= 16) ? 0 : (D <= 32) ? 1 : (D <= 64) ? 2 : 3;
+  else v = (D <= 8) ? 0 : (D <= 16) ? 1 : (D <= 32) ? 2 : 3;
+  int& c = cache[dtype == ISR_DTYPE_BF16 ? 0 : 1][v];
+  if (c == 0) {
+    if (dtype == ISR_DTYPE_BF16) {
+      c = v == 0 ? resident_slots(corr_bf16_kernel<1, kQBbf16>) : v == 1 ? resident_slots(corr_bf16_kernel<2, kQBbf16>)
+        : v == 2 ? resident_slots(corr_bf16_kernel<4, kQBbf16>) : resident_slots(corr_bf16_kernel<8, 2>);
+    } else {
+      c = v == 0 ? resident_slots(corr_f32_kernel<8>) : v == 1 ? resident_slots(corr_f32_kernel<16>)
+        : v == 2 ? resident_slots(corr_f32_kernel<32>) : resident_slots(corr_f32_kernel<64>);
+    }
+  }
+  return c;
+}
+
+// upper bound on nsplit for the workspace query (which must not depend on the device)
 }  // namespace
 
 extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype) {
   (void)D; (void)dtype;
   if (P <= 0 || N <= 0) return 0;
-  const CorrPlan p = make_plan(P, N);
-  return 4 * isr::align_up((size_t)p.nsplit * P * 4, 256) + 256;
+  const int max_split = (N + kTK - 1) / kTK;
+  const int ns = max_split < kMaxSplit ? max_split : kMaxSplit;
+  return 4 * isr::align_up((size_t)ns * P * 4, 256) + 256;
 }
 
 extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
@@ -357,7 +492,8 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     return ISR_ERR_WORKSPACE;
   }
   hipStream_t stream = isr::as_stream(stream_);
-  const CorrPlan p = make_plan(P, N);
+  const int qb_wave = (dtype == ISR_DTYPE_BF16 && D <= 64) ? kQBbf16 : 2;
+  const CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * qb_wave * 32);
   isr::Workspace w(ws, ws_bytes);
   float* pm = w.take<float>((size_t)p.nsplit * P);
   float* pM2 = w.take<float>((size_t)p.nsplit * P);
@@ -373,10 +509,10 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     const uint16_t* q = static_cast<const uint16_t*>(Q);
     const uint16_t* k = static_cast<const uint16_t*>(K);
     switch (D) {
-      case 16: corr_bf16_kernel<1><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
-      case 32: corr_bf16_kernel<2><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
-      case 64: corr_bf16_kernel<4><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
-      default: corr_bf16_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+      case 16: corr_bf16_kernel<1, kQBbf16><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+      case 32: corr_bf16_kernel<2, kQBbf16><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+      case 64: corr_bf16_kernel<4, kQBbf16><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+      default: corr_bf16_kernel<8, 2><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
     }
   } else if (dtype == ISR_DTYPE_F32) {
     ISR_REQUIRE(D <= 64, "isr_corr_argmax(f32): D=%d > 64", D);

@@ -348,18 +348,21 @@ __device__ __forceinline__ bool inlier_f32(const float* __restrict__ Pm, float X
 }
 
 constexpr int kScoreThreads = 256;
-constexpr int kCPL = 4;  // correspondences per lane
+constexpr int kCPL = 4;    // correspondences per lane
+constexpr int kHC = 32;    // hypotheses per block: grid.y = ceil(H / kHC) keeps >= 8 waves per SIMD
 constexpr int kMaxH = 8192;
 
 __global__ __launch_bounds__(kScoreThreads) void score_kernel(
     const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev,
     const float* __restrict__ Pm, const uint8_t* __restrict__ ok, int H, float reperr,
     int32_t* __restrict__ n_inl) {
-  extern __shared__ int32_t cnt[];  // H
+  __shared__ int32_t cnt[kHC];
   const int M = *M_dev;
   const int base = blockIdx.x * (kScoreThreads * kCPL);
   if (base >= M) return;  // block-uniform
-  for (int h = threadIdx.x; h < H; h += kScoreThreads) cnt[h] = 0;
+  const int h0 = blockIdx.y * kHC;
+  const int h1 = min(H, h0 + kHC);
+  if (threadIdx.x < kHC) cnt[threadIdx.x] = 0;
   __syncthreads();
   float X[kCPL], Y[kCPL], Z[kCPL], U[kCPL], V[kCPL];
   bool valid[kCPL];
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
     U[c] = p2d[2 * (size_t)mm]; V[c] = p2d[2 * (size_t)mm + 1];
   }
   const int lane = threadIdx.x & 63;
-  for (int h = 0; h < H; ++h) {
+  for (int h = h0; h < h1; ++h) {
     if (!ok[h]) continue;  // uniform
     const float* P = Pm + 12 * (size_t)h;  // uniform address: scalar loads
     int c_wave = 0;
@@ -381,11 +384,10 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
       const bool in = valid[c] && inlier_f32(P, X[c], Y[c], Z[c], U[c], V[c], reperr);
       c_wave += __popcll(__ballot(in));
     }
-    if (lane == 0 && c_wave) atomicAdd(&cnt[h], c_wave);
+    if (lane == 0 && c_wave) atomicAdd(&cnt[h - h0], c_wave);
   }
   __syncthreads();
-  for (int h = threadIdx.x; h < H; h += kScoreThreads)
-    if (cnt[h]) atomicAdd(&n_inl[h], cnt[h]);
+  if (threadIdx.x < h1 - h0 && cnt[threadIdx.x]) atomicAdd(&n_inl[h0 + threadIdx.x], cnt[threadIdx.x]);
 }
 
 // One block: best = arg-max n_inl over ok hypotheses (lowest h on ties); status = count >= 4.
@@ -438,14 +440,16 @@ __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __r
 
 // ---------------------------------------------------------------------------------- refit
 constexpr int kRefThreads = 256;
-constexpr int kRefBlocks = 128;
+constexpr int kRefBlocks = 64;
 constexpr int kNAcc = 28;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2)
 
 __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
     const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev,
     const uint32_t* __restrict__ mask, Cam cam, const double* __restrict__ Rt,
-    const int32_t* __restrict__ status_dev, double* __restrict__ partial) {
+    const int32_t* __restrict__ status_dev, const int32_t* __restrict__ state,
+    double* __restrict__ partial) {
   __shared__ double red[kRefThreads / 64][kNAcc];
+  if (state[0]) return;  // converged (block-uniform)
   double acc[kNAcc];
 #pragma unroll
   for (int i = 0; i < kNAcc; ++i) acc[i] = 0.0;
@@ -497,20 +501,22 @@ __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-// One thread: sum the block partials in order, solve the 6x6 normal equations by Cholesky,
-// retract:  R <- Q(w) R,  t <- Q(w) t + dt  with Q(w) the rotation of the unit quaternion
-// (1, w/2)/|.| (sqrt only: no sin/cos, so the step is plain IEEE arithmetic).
+// One block: 28 lanes sum the block partials in order (fixed order: reproducible), lane 0 solves
+// the 6x6 normal equations by Cholesky and retracts:  R <- Q(w) R,  t <- Q(w) t + dt  with Q(w) the
+// rotation of the unit quaternion (1, w/2)/|.| (sqrt only: no sin/cos, so the step is plain IEEE
+// arithmetic).  state[0] = 1 once the step is below 1e-12: later launches return at once.
 __global__ void gn_solve_kernel(const double* __restrict__ partial, double* __restrict__ Rt,
-                                const int32_t* __restrict__ status_dev, double* __restrict__ cost_out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+                                const int32_t* __restrict__ status_dev, int32_t* __restrict__ state) {
+  __shared__ double s[kNAcc];
   if (status_dev && *status_dev == 0) return;
-  double s[kNAcc];
-  for (int i = 0; i < kNAcc; ++i) {
+  if (state[0]) return;
+  if (threadIdx.x < kNAcc) {
     double a = 0.0;
-    for (int b = 0; b < kRefBlocks; ++b) a += partial[(size_t)b * kNAcc + i];
-    s[i] = a;
+    for (int b = 0; b < kRefBlocks; ++b) a += partial[(size_t)b * kNAcc + threadIdx.x];
+    s[threadIdx.x] = a;
   }
-  if (cost_out) *cost_out = s[27];
+  __syncthreads();
+  if (threadIdx.x != 0) return;
   double A[6][6], g[6];
   int k = 0;
   for (int i = 0; i < 6; ++i)
@@ -526,7 +532,7 @@ __global__ void gn_solve_kernel(const double* __restrict__ partial, double* __re
   for (int j = 0; j < 6; ++j) {
     double d = A[j][j];
     for (int p = 0; p < j; ++p) d -= L[j][p] * L[j][p];
-    if (!(d > 0.0)) return;  // not positive definite: keep the pose
+    if (!(d > 0.0)) { state[0] = 1; return; }  // not positive definite: keep the pose
     L[j][j] = sqrt(d);
     for (int i = j + 1; i < 6; ++i) {
       double v = A[i][j];
@@ -559,22 +565,58 @@ __global__ void gn_solve_kernel(const double* __restrict__ partial, double* __re
     O[4 * r + 3] += x[3 + r];
   }
   for (int i = 0; i < 12; ++i) Rt[i] = O[i];
+  // converged: rotation step below 1e-12 rad and translation step below 1e-10 of |t|
+  const double dw = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+  const double dt = x[3] * x[3] + x[4] * x[4] + x[5] * x[5];
+  const double tt = O[3] * O[3] + O[7] * O[7] + O[11] * O[11];
+  if (dw < 1e-24 && dt < 1e-20 * (tt + 1.0)) state[0] = 1;
 }
 
 // ------------------------------------------------------------------------------ compaction
-// One block: bitmask (W words) -> ascending indices; n_out = popcount total.
-__global__ void mask_compact_kernel(const uint32_t* __restrict__ mask, const int32_t* __restrict__ M_dev,
-                                    const int32_t* __restrict__ status_dev, int32_t* __restrict__ out,
-                                    int32_t* __restrict__ n_out) {
+// Bitmask -> ascending indices: per-block popcounts, a one-block scan of the block totals, then
+// every word scatters its set bits at its exclusive prefix.  kCompBlock words per block.
+constexpr int kCompBlock = 256;
+
+__device__ __forceinline__ int block_scan_excl(int v, int* total) {
+  __shared__ int wsum[kCompBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kCompBlock / 64; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kCompBlock) void mask_count_kernel(const uint32_t* __restrict__ mask,
+                                                                const int32_t* __restrict__ M_dev,
+                                                                const int32_t* __restrict__ status_dev,
+                                                                int32_t* __restrict__ block_counts) {
+  const int W = (status_dev && *status_dev == 0) ? 0 : (*M_dev + 31) / 32;
+  const int w = blockIdx.x * kCompBlock + threadIdx.x;
+  int total;
+  (void)block_scan_excl(w < W ? __popc(mask[w]) : 0, &total);
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+__global__ void mask_scan_kernel(int32_t* __restrict__ block_counts, int nblocks, int32_t* __restrict__ n_out) {
   __shared__ int32_t tsum[1024];
   const int t = threadIdx.x;
-  const int M = *M_dev;
-  const int W = (status_dev && *status_dev == 0) ? 0 : (M + 31) / 32;
-  const int per = (W + 1023) / 1024;
+  const int per = (nblocks + 1023) / 1024;
   int32_t s = 0;
   for (int j = 0; j < per; ++j) {
-    const int w = t * per + j;
-    if (w < W) s += __popc(mask[w]);
+    const int b = t * per + j;
+    if (b < nblocks) s += block_counts[b];
   }
   tsum[t] = s;
   __syncthreads();
@@ -584,19 +626,32 @@ __global__ void mask_compact_kernel(const uint32_t* __restrict__ mask, const int
     tsum[t] += v;
     __syncthreads();
   }
-  int32_t o = (t > 0) ? tsum[t - 1] : 0;
+  int32_t run = (t > 0) ? tsum[t - 1] : 0;
   for (int j = 0; j < per; ++j) {
-    const int w = t * per + j;
-    if (w < W) {
-      uint32_t bits = mask[w];
-      while (bits) {
-        const int b = __ffs(bits) - 1;
-        out[o++] = w * 32 + b;
-        bits &= bits - 1;
-      }
+    const int b = t * per + j;
+    if (b < nblocks) {
+      const int32_t c = block_counts[b];
+      block_counts[b] = run;
+      run += c;
     }
   }
   if (t == 1023) *n_out = tsum[1023];
+}
+
+__global__ __launch_bounds__(kCompBlock) void mask_scatter_kernel(const uint32_t* __restrict__ mask,
+                                                                  const int32_t* __restrict__ M_dev,
+                                                                  const int32_t* __restrict__ status_dev,
+                                                                  const int32_t* __restrict__ block_off,
+                                                                  int32_t* __restrict__ out) {
+  const int W = (status_dev && *status_dev == 0) ? 0 : (*M_dev + 31) / 32;
+  const int w = blockIdx.x * kCompBlock + threadIdx.x;
+  uint32_t bits = w < W ? mask[w] : 0u;
+  int total;
+  int o = block_off[blockIdx.x] + block_scan_excl(__popc(bits), &total);
+  while (bits) {
+    out[o++] = w * 32 + (__ffs(bits) - 1);
+    bits &= bits - 1;
+  }
 }
 
 bool make_cam(const double* K, Cam* cam) {
@@ -620,7 +675,8 @@ struct RansacWs {
   int32_t* best;     // 1
   uint32_t* mask;    // ceil(M_cap/32)
   double* partial;   // kRefBlocks x kNAcc
-  float* Pm1;        // 12 (refine path)
+  int32_t* state;    // GN convergence flag
+  int32_t* cblocks;  // compaction block counts
 };
 
 size_t carve(isr::Workspace& w, int M_cap, int H, RansacWs* o) {
@@ -631,7 +687,8 @@ size_t carve(isr::Workspace& w, int M_cap, int H, RansacWs* o) {
   o->best = w.take<int32_t>(4);
   o->mask = w.take<uint32_t>((M_cap + 31) / 32 + 2);
   o->partial = w.take<double>((size_t)kRefBlocks * kNAcc);
-  o->Pm1 = w.take<float>(12);
+  o->state = w.take<int32_t>(4);
+  o->cblocks = w.take<int32_t>(((M_cap + 31) / 32 + kCompBlock - 1) / kCompBlock + 1);
   return w.off;
 }
 
@@ -664,7 +721,7 @@ static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, 
   proj_matrix_kernel<<<(H * 12 + 255) / 256, 256, 0, stream>>>(Rt, cam, H, Pm);
   ISR_CHECK_HIP(hipMemsetAsync(n_inl, 0, sizeof(int32_t) * (size_t)H, stream));
   const int nblk = (M_cap + kScoreThreads * kCPL - 1) / (kScoreThreads * kCPL);
-  score_kernel<<<nblk, kScoreThreads, sizeof(int32_t) * (size_t)H, stream>>>(p3d, p2d, M_dev, Pm, ok, H, reperr, n_inl);
+  score_kernel<<<dim3(nblk, (H + kHC - 1) / kHC), kScoreThreads, 0, stream>>>(p3d, p2d, M_dev, Pm, ok, H, reperr, n_inl);
   best_kernel<<<1, 256, 0, stream>>>(n_inl, ok, H, best_dev, status_dev, Rt, pose_dev);
   if (best_mask)
     best_mask_kernel<<<(M_cap + 255) / 256, 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, Pm, best_dev, reperr, best_mask);
@@ -692,10 +749,11 @@ extern "C" int isr_ransac_score(const float* p3d, const float* p2d, const int32_
 
 static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev, const uint32_t* mask,
                        const Cam& cam, int iters, double* Rt_io, const int32_t* status_dev, double* partial,
-                       hipStream_t stream) {
+                       int32_t* state, hipStream_t stream) {
+  ISR_CHECK_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int32_t), stream));
   for (int it = 0; it < iters; ++it) {
-    gn_accumulate_kernel<<<kRefBlocks, kRefThreads, 0, stream>>>(p3d, p2d, M_dev, mask, cam, Rt_io, status_dev, partial);
-    gn_solve_kernel<<<1, 64, 0, stream>>>(partial, Rt_io, status_dev, nullptr);
+    gn_accumulate_kernel<<<kRefBlocks, kRefThreads, 0, stream>>>(p3d, p2d, M_dev, mask, cam, Rt_io, status_dev, state, partial);
+    gn_solve_kernel<<<1, 64, 0, stream>>>(partial, Rt_io, status_dev, state);
   }
   ISR_CHECK_LAUNCH("pnp refine kernels");
   return ISR_OK;
@@ -708,14 +766,15 @@ extern "C" int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t*
   ISR_REQUIRE(M_cap > 0 && iters >= 0, "isr_pnp_refine: M_cap=%d iters=%d", M_cap, iters);
   Cam cam;
   ISR_REQUIRE(make_cam(Kcam, &cam), "isr_pnp_refine: singular camera matrix");
-  const size_t need = sizeof(double) * kRefBlocks * kNAcc + 256;
+  const size_t need = sizeof(double) * kRefBlocks * kNAcc + 1024;
   if (!ws || ws_bytes < need) {
     isr::set_error("isr_pnp_refine: workspace %zu < %zu", ws_bytes, need);
     return ISR_ERR_WORKSPACE;
   }
   isr::Workspace w(ws, ws_bytes);
   double* partial = w.take<double>((size_t)kRefBlocks * kNAcc);
-  return refine_impl(p3d, p2d, M_dev, mask, cam, iters, Rt_io, nullptr, partial, isr::as_stream(stream));
+  int32_t* state = w.take<int32_t>(4);
+  return refine_impl(p3d, p2d, M_dev, mask, cam, iters, Rt_io, nullptr, partial, state, isr::as_stream(stream));
 }
 
 extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
@@ -741,9 +800,12 @@ extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t*
   int rc = score_impl(p3d, p2d, M_dev, M_cap, cam, b.Rt, b.ok, H, reperr, b.Pm, b.n_inl, b.best, b.mask,
                       status_dev, pose_dev, stream);
   if (rc != ISR_OK) return rc;
-  rc = refine_impl(p3d, p2d, M_dev, b.mask, cam, refine_iters, pose_dev, status_dev, b.partial, stream);
+  rc = refine_impl(p3d, p2d, M_dev, b.mask, cam, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
   if (rc != ISR_OK) return rc;
-  mask_compact_kernel<<<1, 1024, 0, stream>>>(b.mask, M_dev, status_dev, inl_idx, n_inl_dev);
-  ISR_CHECK_LAUNCH("mask_compact_kernel");
+  const int cb = ((M_cap + 31) / 32 + kCompBlock - 1) / kCompBlock;
+  mask_count_kernel<<<cb, kCompBlock, 0, stream>>>(b.mask, M_dev, status_dev, b.cblocks);
+  mask_scan_kernel<<<1, 1024, 0, stream>>>(b.cblocks, cb, n_inl_dev);
+  mask_scatter_kernel<<<cb, kCompBlock, 0, stream>>>(b.mask, M_dev, status_dev, b.cblocks, inl_idx);
+  ISR_CHECK_LAUNCH("mask compaction kernels");
   return ISR_OK;
 }

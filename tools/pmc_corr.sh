@@ -1,0 +1,32 @@
+#!/bin/bash
+# PMC passes over tools/time_corr.py (K1 alone).  Separate passes: SQ has 8 slots, TCC 4.
+# Usage on the GPU box: bash tools/pmc_corr.sh <outdir> [P N D]
+set -u
+out=${1:-gpurun_out/pmc_corr}; shift || true
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p "$out"
+pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$out/$name" -- python3 tools/time_corr.py ${ARGS:-} > "$out/$name.log" 2>&1; }
+ARGS="$*"
+pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
+pass sq2 SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU
+pass sq3 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_LEVEL_WAVES SQ_INSTS_VMEM
+pass grbm GRBM_GUI_ACTIVE GRBM_COUNT
+pass tcc1 FETCH_SIZE
+pass tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
+python3 - "$out" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "corr_" not in k: continue
+        k = "corr_finalize" if "finalize" in k else k.split("(")[0][-40:]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(out + "/summary.txt", "w") as g:
+    for k, d in agg.items():
+        g.write(f"== {k}\n")
+        for c, v in sorted(d.items()):
+            g.write(f"  {c:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
+print(open(out + "/summary.txt").read())
+PY
