@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--keys", type=int, default=20000)
     ap.add_argument("--itr", type=int, default=500)
     ap.add_argument("--cad", type=int, default=5000)
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the images are pipelined over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg")
     return ap.parse_args()
@@ -170,8 +171,8 @@ def main():
     torch.cuda.synchronize()
 
     def step(s: int):
-        res = [sequence.register_image(model, q, pix, Kcam, itr=args.itr, reperr=2.0, seed=(s << 20) + lo + j)
-               for j, (q, pix) in enumerate(images)]
+        res = sequence.register_images(model, images, Kcam, itr=args.itr, reperr=2.0, seed0=(s << 20) + lo,
+                                       n_streams=args.streams)
         poses, status = sequence.stack_poses(res)
         poses_all = shard.allgather_rows(poses, n_total)
         best, ch = sequence.pick_by_chamfer(pts, poses_all, R_gt, t_gt, n_total)

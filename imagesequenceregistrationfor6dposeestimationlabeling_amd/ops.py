@@ -315,3 +315,21 @@ def add_metric(verts: torch.Tensor, Ta: torch.Tensor | None, Tb: torch.Tensor | 
         rc = lib().isr_add_metric(ptr(verts), verts.shape[0], ptr(Ta), ptr(Tb), B, ptr(out), current_stream(dev))
     check(rc, "isr_add_metric")
     return out
+
+
+def corr_logsoftmax(queries: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
+    """isr_corr_logsoftmax: the full (P,N) f32 log-softmax matrix (small P only: it is written out)."""
+    dev = require_cuda(queries, keys)
+    if queries.dtype == torch.bfloat16 and keys.dtype == torch.bfloat16:
+        dtype = _capi.DTYPE_BF16
+    else:
+        dtype = _capi.DTYPE_F32
+        queries, keys = queries.to(torch.float32), keys.to(torch.float32)
+    q, k = queries.contiguous(), keys.contiguous()
+    P, D = q.shape
+    N = k.shape[0]
+    out = torch.empty((P, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_corr_logsoftmax(ptr(q), ptr(k), P, N, D, D, D, dtype, ptr(out), N, current_stream(dev))
+    check(rc, "isr_corr_logsoftmax")
+    return out

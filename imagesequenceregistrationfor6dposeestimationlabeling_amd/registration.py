@@ -56,8 +56,11 @@ def getCors(queries, feats, leaves=1):
     if leaves == 1:
         idx, logp = ops.corr_argmax(q, f)
         return idx.to(torch.int64).cpu(), logp[:, None]
-    raise IsrError("getCors(leaves > 1) needs the materialising kernel (isr_corr_logsoftmax), "
-                   "not built in this round; the reference only ever calls leaves=1")
+    # leaves > 1 (never used by the reference's call sites): materialise the log-softmax matrix with
+    # the HIP kernel, then torch.topk picks the k largest per row as the reference does
+    cMat = ops.corr_logsoftmax(q, f)
+    vals, idx = torch.topk(cMat, k=leaves, dim=-1)
+    return idx.cpu(), vals
 
 
 # --------------------------------------------------------------------- a2 / a3 filter + assembly

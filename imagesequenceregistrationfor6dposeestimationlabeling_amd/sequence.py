@@ -52,6 +52,41 @@ def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
     return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp)
 
 
+_streams: dict[tuple, list] = {}
+
+
+def _stream_pool(dev: torch.device, n: int) -> list:
+    key = (dev.index, n)
+    if key not in _streams:
+        _streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+    return _streams[key]
+
+
+def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: float = 2.0,
+                    seed0: int = 0, refine_iters: int = 10, n_streams: int = 3) -> list[ImageResult]:
+    """Register a block of images, image j on HIP stream j % n_streams.  Each image's chain is a
+    dozen dependent launches of which only K1 fills the chip; issuing consecutive images on
+    different streams lets image j+1's K1 fill the launch tail of image j's and run beside its small
+    RANSAC kernels.  `images` is a sequence of (queries, pix_xy); `cam` one 3x3 or one per image.
+    The caller's current stream waits for every side stream before this returns (no host sync)."""
+    dev = model.keys.device
+    cur = torch.cuda.current_stream(dev)
+    if n_streams <= 1:
+        return [register_image(model, q, pix, cam if np.ndim(cam) == 2 else cam[j], itr, reperr, seed0 + j,
+                               refine_iters) for j, (q, pix) in enumerate(images)]
+    pool = _stream_pool(dev, n_streams)
+    for s in pool:
+        s.wait_stream(cur)
+    out = []
+    for j, (q, pix) in enumerate(images):
+        with torch.cuda.stream(pool[j % n_streams]):
+            out.append(register_image(model, q, pix, cam if np.ndim(cam) == 2 else cam[j], itr, reperr,
+                                      seed0 + j, refine_iters))
+    for s in pool:
+        cur.wait_stream(s)
+    return out
+
+
 def stack_poses(results: list[ImageResult]) -> tuple[torch.Tensor, torch.Tensor]:
     """(n,12) f64 poses and (n,) status, still on the device."""
     return (torch.stack([r.pose.reshape(12) for r in results]),

@@ -92,3 +92,20 @@ def test_corr_ties_lowest_key(cuda0):
     for dt in (torch.float32, torch.bfloat16):
         idx, _ = ops.corr_argmax(Q.to(dt).to(cuda0), K.to(dt).to(cuda0))
         assert idx.cpu().tolist() == [3, 0]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_corr_logsoftmax_and_topk_leaves(cuda0, dt):
+    """Materialising variant (poseEstSurf.py:70) and getCors(leaves=3) vs the literal torch expression."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, registration
+    rng = np.random.default_rng(21)
+    Q, K, _ = _planted(rng, 70, 1234, 12)
+    q, k = torch.from_numpy(Q).to(dt), torch.from_numpy(K).to(dt)
+    got = ops.corr_logsoftmax(q.to(cuda0), k.to(cuda0)).cpu()
+    ref = torch.log_softmax(q.double() @ k.double().T, dim=-1)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=5e-5)
+    idx, vals = registration.getCors(q.to(cuda0), k.to(cuda0), leaves=3)
+    rv, ri = torch.topk(ref, k=3, dim=-1)
+    assert idx.shape == (70, 3) and not idx.is_cuda and vals.is_cuda
+    assert (idx == ri).float().mean() > 0.99
+    np.testing.assert_allclose(vals.cpu().numpy(), rv.numpy(), atol=5e-5)
