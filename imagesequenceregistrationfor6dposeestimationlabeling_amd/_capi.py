@@ -17,6 +17,7 @@ LIB_PATH = _PKG / "libisr_hip.so"
 ISR_OK = 0
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
+DTYPE_BF16_LOG2 = 2
 
 
 class IsrError(RuntimeError):

@@ -162,14 +162,146 @@ __device__ __forceinline__ void store_partial(const LaneState& st_, int q, int P
   }
 }
 
+
+// ---------------------------------------------------------------------- bf16, log2-domain variant
+// dtype ISR_DTYPE_BF16_LOG2: the caller multiplied the queries by log2(e) BEFORE rounding them to
+// bf16, so the MFMA produces logits in log2 units and exp2 needs no multiply.  The subtraction of
+// the integer reference M2 rides in the MFMA's C operand: each query block keeps a 16-register
+// tile holding -M2 (rewritten only when M2 moves), the first MFMA of every chain takes it as C and
+// writes a different destination, so the accumulator already holds s' - M2 and the epilogue is
+// exp2 + add per element: 16 VALU instructions per tile fewer than the natural-log path, no extra
+// MFMA.  (Carrying -M2 as an extra k-step instead was measured: the fifth MFMA cost what the 16
+// fmas saved.)  MFMA numerics with the large C term: profiles/r01_mfma_numerics.txt (max abs error
+// 1.9e-5 over |s' - M2| <= 190, no bias).
+struct L2State {
+  float mr;   // max(s') - M2 of this lane's rows (-inf before the first key)
+  float M2;   // integer reference, SHARED by the two lanes (h = 0, 1) of a query
+  float l;    // sum 2^(s' - M2)
+  int bi;
+};
+
+__device__ __forceinline__ f32x16 splat16(float v) {
+  return f32x16{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
+}
+
+// Part A, log2 domain.  acc holds s' - M2; a new maximum above the reference bumps M2 by an integer d
+// (both lanes of the query, exchanged with one cross-half shuffle), rescales l by 2^-d exactly,
+// shifts this tile's accumulators and rewrites the query block's -M2 tile.
+__device__ __forceinline__ void update_max_l2(f32x16& acc, int krow0, L2State& st, f32x16& cinit) {
+  const float x0 = max3(acc[0], acc[1], acc[2]), x1 = max3(acc[3], acc[4], acc[5]),
+              x2 = max3(acc[6], acc[7], acc[8]), x3 = max3(acc[9], acc[10], acc[11]),
+              x4 = max3(acc[12], acc[13], acc[14]);
+  const float t = fmaxf(max3(x0, x1, x2), max3(x3, x4, acc[15]));
+  if (__any(t > st.mr)) {
+    const float ninf = -__builtin_inff();
+    const bool first = !(st.mr > ninf);
+    const bool up = t > st.mr;
+    float d = up ? (first ? ceilf(t) : fmaxf(0.f, ceilf(t))) : (first ? ninf : 0.f);
+    d = fmaxf(d, __shfl_xor(d, 32, 64));
+    d = (d > ninf) ? d : 0.f;
+    if (up) {
+      int r = 15;
+#pragma unroll
+      for (int i = 14; i >= 0; --i) r = (acc[i] == t) ? i : r;
+      st.bi = krow0 + (r & 3) + 8 * (r >> 2);
+      st.mr = t;
+    }
+    if (__any(d != 0.f)) {
+      if (d != 0.f) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] -= d;
+        st.mr -= d;
+        st.l = (st.l > 0.f) ? st.l * __builtin_amdgcn_exp2f(-d) : 0.f;
+        st.M2 += d;
+        cinit = splat16(-st.M2);
+      }
+    }
+  }
+}
+
+// Part B, log2 domain, interleaved with the DK MFMAs of the next tile (first one takes C = -M2).
+// Compile-time recursion over the steps: sched_group_barrier needs literal group sizes.
+template <int DK, int S>
+__device__ __forceinline__ void l2_step(const f32x16& cur, float& l, f32x16& c, const bf16x8 (&a)[DK],
+                                        const bf16x8 (&b)[DK], const f32x16& cinit) {
+  constexpr int E = 16 / DK > 0 ? 16 / DK : 1;
+  if constexpr (S == 0) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], cinit, 0, 0, 0);
+  else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S], b[S], c, 0, 0, 0);
+#pragma unroll
+  for (int e = 0; e < E; ++e) l += __builtin_amdgcn_exp2f(cur[S * E + e]);
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+  __builtin_amdgcn_sched_group_barrier(0x002, 2 * E, 0);
+  if constexpr (S + 1 < DK) l2_step<DK, S + 1>(cur, l, c, a, b, cinit);
+}
+
+template <int DK>
+__device__ __forceinline__ f32x16 exp_and_next_mfma_l2(const f32x16& cur, L2State& st, const bf16x8 (&a)[DK],
+                                                       const bf16x8 (&b)[DK], const f32x16& cinit) {
+  static_assert(DK <= 16, "one exp group per MFMA");
+  float l = st.l;
+  f32x16 c;
+  l2_step<DK, 0>(cur, l, c, a, b, cinit);
+  st.l = l;
+  return c;
+}
+
+__device__ __forceinline__ void consume_tile_l2(f32x16& acc, int krow0, L2State& st, f32x16& cinit) {
+  update_max_l2(acc, krow0, st, cinit);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) st.l += __builtin_amdgcn_exp2f(acc[i]);
+}
+
+// Halves share M2, so the winner is decided on mr directly (exact); partial = (mr_w, M2, l, idx).
+__device__ __forceinline__ void store_partial_l2(const L2State& st, int q, int P, int split, float* pm,
+                                                 float* pM2, float* pl, int32_t* pbi) {
+  const float omr = __shfl_xor(st.mr, 32, 64);
+  const float ol = __shfl_xor(st.l, 32, 64);
+  const int obi = __shfl_xor(st.bi, 32, 64);
+  const bool other = better(omr, obi, st.mr, st.bi);
+  if ((threadIdx.x & 63) < 32 && q < P) {
+    const size_t off = (size_t)split * P + q;
+    pm[off] = other ? omr : st.mr;
+    pM2[off] = st.M2;
+    pl[off] = st.l + ol;
+    pbi[off] = other ? obi : st.bi;
+  }
+}
+
+// Merge splits in f64: winner by M2 + mr (exact), l rescaled to the largest M2;
+//   logp = -(ln l + ((M2f - M2w) - mrw) ln2),  lse = (M2w + mrw) ln2 - logp   (natural-log units).
+__global__ void corr_finalize_l2_kernel(int P, int nsplit, const float* __restrict__ pm,
+                                        const float* __restrict__ pM2, const float* __restrict__ pl,
+                                        const int32_t* __restrict__ pbi, int32_t* __restrict__ idx,
+                                        float* __restrict__ logp, float* __restrict__ lse) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= P) return;
+  double mrw = pm[q], M2w = pM2[q], M2f = pM2[q], l = pl[q];
+  int bi = pbi[q];
+  for (int s = 1; s < nsplit; ++s) {
+    const size_t o = (size_t)s * P + q;
+    const double mr = pm[o], M2 = pM2[o], ls = pl[o];
+    if (M2 + mr > M2w + mrw) { mrw = mr; M2w = M2; bi = pbi[o]; }  // ascending splits: ties keep the lower key
+    if (M2 > M2f) { l = l * exp2(M2f - M2) + ls; M2f = M2; }
+    else l += ls * exp2(M2 - M2f);
+  }
+  const double ln2 = 0.6931471805599453094;
+  const double lp = -(log(l) + ((M2f - M2w) - mrw) * ln2);
+  idx[q] = bi;
+  if (logp) logp[q] = (float)lp;
+  if (lse) lse[q] = (float)((M2w + mrw) * ln2 - lp);
+}
+
 // ------------------------------------------------------------------------------------ bf16
 // Keys are staged through LDS once per workgroup (coalesced 16-byte global loads, XOR-swizzled
 // image, ds_read_b128 in MFMA operand layout) and shared by the workgroup's four waves.
 // (Tried and rejected, measured on MI355X: every wave streaming its own A fragments straight from
 // global memory — no LDS, no barrier — is bound by the CU's vector L1: 245 ns per tile against
 // 202 ns here, with the epilogue entirely hidden behind the loads.)
-template <int DK, int QB>  // D = 16 * DK, DK in {1, 2, 4, 8}; QB 32-query blocks per wave
-__global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
+#ifndef ISR_BF16_WAVES
+#define ISR_BF16_WAVES 1
+#endif
+template <int DK, int QB, bool LOG2 = false>  // D = 16 * DK, DK in {1, 2, 4, 8}; QB 32-query blocks per wave
+__global__ __launch_bounds__(kThreads, (DK <= 4 && !LOG2) ? ISR_BF16_WAVES : 1) void corr_bf16_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
     int32_t* __restrict__ pbi) {
@@ -195,9 +327,13 @@ __global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
   }
 
   LaneState st[QB];
+  L2State s2[QB];
+  f32x16 cinit[QB];                     // LOG2: -M2 of the lane's query, the C operand of each chain
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     st[qb].m = -__builtin_inff(); st[qb].M2 = kNoM2; st[qb].l = 0.f; st[qb].bi = 0;
+    s2[qb].mr = -__builtin_inff(); s2[qb].M2 = 0.f; s2[qb].l = 0.f; s2[qb].bi = 0;
+    cinit[qb] = splat16(0.f);
   }
 
   const int k0 = split * split_len;
@@ -275,13 +411,15 @@ __global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
       }
       const int kb = k0 + stage * kTK + sub * 32;
       const int krow0 = kb + 4 * h;
-      if (FULL) {
-        update_max(acc[w & 1], krow0, st[qb]);
-        acc[(w + 1) & 1] = exp_and_next_mfma<DK>(acc[w & 1], st[qb], a, bq[qbn]);
-      } else if (kb < k1) {  // block-uniform
-        if (kb + 32 > k1) mask_tail(acc[w & 1], krow0, k1);
-        update_max(acc[w & 1], krow0, st[qb]);
-        acc[(w + 1) & 1] = exp_and_next_mfma<DK>(acc[w & 1], st[qb], a, bq[qbn]);
+      if (FULL || kb < k1) {  // block-uniform
+        if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], krow0, k1);
+        if (LOG2) {
+          update_max_l2(acc[w & 1], krow0, s2[qb], cinit[qb]);
+          acc[(w + 1) & 1] = exp_and_next_mfma_l2<DK>(acc[w & 1], s2[qb], a, bq[qbn], cinit[qbn]);
+        } else {
+          update_max(acc[w & 1], krow0, st[qb]);
+          acc[(w + 1) & 1] = exp_and_next_mfma<DK>(acc[w & 1], st[qb], a, bq[qbn]);
+        }
       }
     }
   };
@@ -290,7 +428,10 @@ __global__ __launch_bounds__(kThreads) void corr_bf16_kernel(
   if (nfull < nstage) stage_body(nfull, std::false_type{});
 
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) store_partial(st[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
+  for (int qb = 0; qb < QB; ++qb) {
+    if (LOG2) store_partial_l2(s2[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
+    else store_partial(st[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
+  }
 }
 
 // ------------------------------------------------------------------------------------- f32
@@ -454,11 +595,11 @@ int slots_for(int dtype, int D) {
   // cached per (dtype, padded D): the occupancy query costs tens of microseconds
   static int cache[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   int v = 0;
-  if (dtype == ISR_DTYPE_BF16) v = (D <= 16) ? 0 : (D <= 32) ? 1 : (D <= 64) ? 2 : 3;
+  if (dtype != ISR_DTYPE_F32) v = (D <= 16) ? 0 : (D <= 32) ? 1 : (D <= 64) ? 2 : 3;
   else v = (D <= 8) ? 0 : (D <= 16) ? 1 : (D <= 32) ? 2 : 3;
-  int& c = cache[dtype == ISR_DTYPE_BF16 ? 0 : 1][v];
+  int& c = cache[dtype != ISR_DTYPE_F32 ? 0 : 1][v];
   if (c == 0) {
-    if (dtype == ISR_DTYPE_BF16) {
+    if (dtype != ISR_DTYPE_F32) {
       c = v == 0 ? resident_slots(corr_bf16_kernel<1, kQBbf16>) : v == 1 ? resident_slots(corr_bf16_kernel<2, kQBbf16>)
         : v == 2 ? resident_slots(corr_bf16_kernel<4, kQBbf16>) : resident_slots(corr_bf16_kernel<8, 2>);
     } else {
@@ -492,7 +633,7 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     return ISR_ERR_WORKSPACE;
   }
   hipStream_t stream = isr::as_stream(stream_);
-  const int qb_wave = (dtype == ISR_DTYPE_BF16 && D <= 64) ? kQBbf16 : 2;
+  const int qb_wave = (dtype != ISR_DTYPE_F32 && D <= 64) ? kQBbf16 : 2;
   const CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * qb_wave * 32);
   isr::Workspace w(ws, ws_bytes);
   float* pm = w.take<float>((size_t)p.nsplit * P);
@@ -501,19 +642,29 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
   int32_t* pbi = w.take<int32_t>((size_t)p.nsplit * P);
   const dim3 grid(p.qblocks, p.nsplit);
 
-  if (dtype == ISR_DTYPE_BF16) {
+  if (dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2) {
     ISR_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128,
                 "isr_corr_argmax(bf16): D=%d must be 16, 32, 64 or 128 (zero-pad the columns)", D);
     ISR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0),
                 "isr_corr_argmax(bf16): rows must be 16-byte aligned (ldq=%d ldk=%d)", ldq, ldk);
     const uint16_t* q = static_cast<const uint16_t*>(Q);
     const uint16_t* k = static_cast<const uint16_t*>(K);
+#define ISR_LAUNCH_BF16(DKv, QBv)                                                                         \
+  do {                                                                                                    \
+    if (dtype == ISR_DTYPE_BF16_LOG2)                                                                     \
+      corr_bf16_kernel<DKv, QBv, true><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, \
+                                                                      pm, pM2, pl, pbi);                   \
+    else                                                                                                  \
+      corr_bf16_kernel<DKv, QBv, false><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, \
+                                                                       pm, pM2, pl, pbi);                  \
+  } while (0)
     switch (D) {
-      case 16: corr_bf16_kernel<1, kQBbf16><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
-      case 32: corr_bf16_kernel<2, kQBbf16><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
-      case 64: corr_bf16_kernel<4, kQBbf16><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
-      default: corr_bf16_kernel<8, 2><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi); break;
+      case 16: ISR_LAUNCH_BF16(1, kQBbf16); break;
+      case 32: ISR_LAUNCH_BF16(2, kQBbf16); break;
+      case 64: ISR_LAUNCH_BF16(4, kQBbf16); break;
+      default: ISR_LAUNCH_BF16(8, 2); break;
     }
+#undef ISR_LAUNCH_BF16
   } else if (dtype == ISR_DTYPE_F32) {
     ISR_REQUIRE(D <= 64, "isr_corr_argmax(f32): D=%d > 64", D);
     const float* q = static_cast<const float*>(Q);
@@ -527,7 +678,10 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     return ISR_ERR_ARG;
   }
   ISR_CHECK_LAUNCH("corr kernel");
-  corr_finalize_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, p.nsplit, pm, pM2, pl, pbi, idx, logp, lse);
+  if (dtype == ISR_DTYPE_BF16_LOG2)
+    corr_finalize_l2_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, p.nsplit, pm, pM2, pl, pbi, idx, logp, lse);
+  else
+    corr_finalize_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, p.nsplit, pm, pM2, pl, pbi, idx, logp, lse);
   ISR_CHECK_LAUNCH("corr_finalize_kernel");
   return ISR_OK;
 }

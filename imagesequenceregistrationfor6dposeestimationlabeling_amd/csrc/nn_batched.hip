@@ -269,8 +269,12 @@ NNPlan make_plan(int Nq, int Nt, int B) {
   NNPlan p;
   p.rq = (Nq >= 4 * kThreads) ? 4 : 1;
   p.qblocks = (Nq + p.rq * kThreads - 1) / (p.rq * kThreads);
-  // aim for >= 2048 resident blocks (256 CUs x 8) before splitting the target range
-  const long want = 2048;
+  // 256 CUs x 8 workgroups are resident at once; aim for several such rounds so the last,
+  // partly filled round is a small share of the launch (ISR_NN_WANT_BLOCKS: tuning hook)
+#ifndef ISR_NN_WANT_BLOCKS
+#define ISR_NN_WANT_BLOCKS 8192
+#endif
+  const long want = ISR_NN_WANT_BLOCKS;
   long ns = (want + (long)p.qblocks * B - 1) / ((long)p.qblocks * B);
   const int max_split = (Nt + kTile - 1) / kTile;
   if (ns < 1) ns = 1;

@@ -138,11 +138,23 @@ def _pad_cols(t: torch.Tensor, D: int) -> torch.Tensor:
     return out
 
 
-def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = False):
+LOG2E = 1.4426950408889634
+
+
+def prescale_queries_log2(queries: torch.Tensor) -> torch.Tensor:
+    """f32 descriptors -> bf16(queries * log2 e): the input of corr_argmax(..., log2_prescaled=True).
+    One rounding, as for a plain .bfloat16(); a conversion, not part of the measured path."""
+    return (queries.to(torch.float32) * LOG2E).to(torch.bfloat16)
+
+
+def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = False,
+                log2_prescaled: bool = False):
     """isr_corr_argmax.  queries (P,D), keys (N,D); bf16 tensors take the bf16 MFMA path, f32
     tensors the exact f32 MFMA path (f16/f64 are converted to f32).  Zero columns are appended
     where the kernel needs a padded D (exact: they add 0 to every logit).
-    Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32] on the device."""
+    log2_prescaled: the bf16 queries already carry a factor log2(e) (prescale_queries_log2): the
+    kernel works in log2 units with the -M2 reference folded into the MFMA contraction; outputs are
+    still natural-log.  Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32] on the device."""
     dev = require_cuda(queries, keys)
     if queries.ndim != 2 or keys.ndim != 2 or queries.shape[1] != keys.shape[1]:
         raise ValueError(f"queries {tuple(queries.shape)} / keys {tuple(keys.shape)} must be (P,D),(N,D)")
@@ -151,11 +163,13 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     if P == 0 or N == 0:
         raise ValueError("empty queries or keys")
     if queries.dtype == torch.bfloat16 and keys.dtype == torch.bfloat16:
-        dtype = _capi.DTYPE_BF16
+        dtype = _capi.DTYPE_BF16_LOG2 if log2_prescaled else _capi.DTYPE_BF16
         Dp = next((d for d in (16, 32, 64, 128) if d >= D), None)
         if Dp is None:
             raise ValueError(f"bf16 path supports D <= 128, got {D}")
     else:
+        if log2_prescaled:
+            raise ValueError("log2_prescaled needs bf16 queries and keys")
         dtype = _capi.DTYPE_F32
         queries, keys = queries.to(torch.float32), keys.to(torch.float32)
         Dp = D

@@ -20,6 +20,7 @@ class SequenceModel:
     """First-sequence model as exported by genFeat.py:223-228 (vert1_scaled / feat1_scaled)."""
     keys: torch.Tensor   # (N, D) descriptors on the device, bf16 (MFMA bf16 path) or f32 (exact path)
     pts: torch.Tensor    # (N, 3) f32 surface points, mm
+    log2_queries: bool = False   # bf16 queries carry a log2(e) prescale (ops.prescale_queries_log2)
 
 
 @dataclass
@@ -42,7 +43,7 @@ def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    idx, logp = ops.corr_argmax(queries, model.keys)
+    idx, logp = ops.corr_argmax(queries, model.keys, log2_prescaled=model.log2_queries)
     if timing is not None:
         e1.record()
         timing.append((e0, e1))
@@ -86,7 +87,7 @@ def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: f
     out = []
     for j, (q, pix) in enumerate(images):
         with torch.cuda.stream(k1_stream):
-            idx, logp = ops.corr_argmax(q, model.keys)
+            idx, logp = ops.corr_argmax(q, model.keys, log2_prescaled=model.log2_queries)
             done = torch.cuda.Event()
             done.record(k1_stream)
         s = side[j % len(side)]
@@ -124,7 +125,8 @@ def register_block(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
     for g0 in range(0, n, group):
         g1 = min(n, g0 + group)
         with torch.cuda.stream(k1_stream):
-            idx_g, logp_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys)
+            idx_g, logp_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys,
+                                             log2_prescaled=model.log2_queries)
             done = torch.cuda.Event()
             done.record(k1_stream)
         for j in range(g0, g1):

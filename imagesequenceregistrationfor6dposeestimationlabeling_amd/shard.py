@@ -89,20 +89,28 @@ def allgather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
 
 
 def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
-    """Initialise torch.distributed from torchrun's environment.  Returns (rank, world, local_rank)."""
+    """Initialise torch.distributed from torchrun's environment.  Returns (rank, world, local_rank).
+    Backend: argument, else $ISR_DIST_BACKEND, else "nccl" (= RCCL) when a HIP device is visible.
+    The local rank is folded onto the visible devices, so a gloo rehearsal of N ranks can share the
+    one GPU of a test box (RCCL itself needs one device per rank)."""
     size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    dev_index = local % ndev if ndev else 0
     if size > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = backend or os.environ.get("ISR_DIST_BACKEND") or ("nccl" if ndev else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+            if size > ndev:
+                raise RuntimeError(f"RCCL needs one device per rank: WORLD_SIZE={size}, {ndev} device(s) visible")
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend, device_id=torch.device("cuda", dev_index))
         else:
+            if ndev:
+                torch.cuda.set_device(dev_index)
             dist.init_process_group(backend)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
-    return rank, size, local
+    elif ndev:
+        torch.cuda.set_device(dev_index)
+    return rank, size, dev_index

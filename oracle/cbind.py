@@ -86,8 +86,9 @@ def corr_argmax_f32(Q, K):
     return dict(idx=idx, maxlogit=mx, lse=lse, top2=top2)
 
 
-def corr_argmax_bf16(Qbits, Kbits):
-    """orc_corr_argmax_bf16 on uint16 bf16 bit patterns -> idx i32, maxlogit/lse/top2 f64."""
+def corr_argmax_bf16(Qbits, Kbits, logit_scale=1.0):
+    """orc_corr_argmax_bf16 on uint16 bf16 bit patterns -> idx i32, maxlogit/lse/top2 f64.
+    logit_scale = ln 2 when the queries were pre-multiplied by log2(e) (ISR_DTYPE_BF16_LOG2)."""
     Q = np.ascontiguousarray(Qbits, np.uint16)
     K = np.ascontiguousarray(Kbits, np.uint16)
     P, D = Q.shape
@@ -98,8 +99,8 @@ def corr_argmax_bf16(Qbits, Kbits):
     top2 = np.zeros(P)
     f = lib().orc_corr_argmax_bf16
     f.restype = None
-    f.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p] * 4
-    f(_p(Q, np.uint16), _p(K, np.uint16), P, N, D, D, D, _p(idx, np.int32), _p(mx, np.float64),
+    f.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_double] + [C.c_void_p] * 4
+    f(_p(Q, np.uint16), _p(K, np.uint16), P, N, D, D, D, float(logit_scale), _p(idx, np.int32), _p(mx, np.float64),
       _p(lse, np.float64), _p(top2, np.float64))
     return dict(idx=idx, maxlogit=mx, lse=lse, top2=top2)
 

@@ -153,10 +153,11 @@ static inline float bf16_to_f32(uint16_t h) {
  * getCors, bf16 inputs (uint16 bit patterns).  bf16 x bf16 products are exact in f32/f64; the
  * MFMA's internal summation order is not documented, so the oracle sums in f64 (error ~1e-16)
  * and the test allows an index mismatch only where the f64 margin top1-top2 is below the f32
- * accumulation noise.  maxlogit/top2/lse are f64.
+ * accumulation noise.  maxlogit/top2/lse are f64, in natural-log units: logit = logit_scale * <q,k>.
  */
 void orc_corr_argmax_bf16(const uint16_t* Q, const uint16_t* K, int P, int N, int D, int ldq,
-                          int ldk, int32_t* idx, double* maxlogit, double* lse, double* top2) {
+                          int ldk, double logit_scale, int32_t* idx, double* maxlogit, double* lse,
+                          double* top2) {
 #pragma omp parallel for schedule(static)
   for (int p = 0; p < P; ++p) {
     const uint16_t* q = Q + (size_t)p * ldq;
@@ -169,6 +170,7 @@ void orc_corr_argmax_bf16(const uint16_t* Q, const uint16_t* K, int P, int N, in
       const uint16_t* k = K + (size_t)n * ldk;
       double acc = 0.0;
       for (int d = 0; d < D; ++d) acc += (double)qf[d] * (double)bf16_to_f32(k[d]);
+      acc *= logit_scale; /* 1, or ln 2 when the queries carry a log2(e) prescale (ISR_DTYPE_BF16_LOG2) */
       row[n] = acc;
       if (acc > m) { m2 = m; m = acc; bi = n; }
       else if (acc > m2) m2 = acc;

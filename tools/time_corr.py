@@ -1,5 +1,5 @@
 """Quick K1 timing on the GPU box: python tools/time_corr.py [P N D]."""
-import sys, time
+import sys
 import torch
 sys.path.insert(0, ".")
 from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
@@ -11,16 +11,18 @@ K = torch.randn(N, D, device=dev, generator=g)
 K = 8.0 * K / K.norm(dim=1, keepdim=True)
 gt = torch.randint(N, (P,), device=dev, generator=g)
 Q = K[gt] + 0.35 * torch.randn(P, D, device=dev, generator=g)
-Qb, Kb = Q.bfloat16(), K.bfloat16()
-for name, q, k in (("planted", Qb, Kb), ("random", torch.randn(P, D, device=dev, generator=g).bfloat16(), Kb)):
-    idx, logp = ops.corr_argmax(q, k)
+Kb = K.bfloat16()
+cases = [("planted bf16", Q.bfloat16(), False), ("planted bf16-log2", ops.prescale_queries_log2(Q), True),
+         ("random bf16", torch.randn(P, D, device=dev, generator=g).bfloat16(), False)]
+for name, q, l2 in cases:
+    idx, logp = ops.corr_argmax(q, Kb, log2_prescaled=l2)
     torch.cuda.synchronize()
-    if name == "planted":
-        print("recovered planted:", (idx.long() == gt).float().mean().item())
+    if name.startswith("planted"):
+        print(name, "recovered planted:", (idx.long() == gt).float().mean().item())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(10):
-        ops.corr_argmax(q, k)
+        ops.corr_argmax(q, Kb, log2_prescaled=l2)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print(f"{name}: P={P} N={N} D={D}  {ms:.3f} ms  {2.0*P*N*D/ms*1e-9:.1f} TFLOP/s  {P*N/ms*1e-9:.2f} Texp/s")
