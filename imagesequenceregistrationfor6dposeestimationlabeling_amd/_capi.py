@@ -54,6 +54,13 @@ SIGNATURES = {
     "isr_nn_batched_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_nn_batched": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                             _sz, _vp]),
+    "isr_ep_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_ep_pool_corr": (_i, [_vp, _i, _i, _vp, _vp]),
+    "isr_ep_sample_workspace_bytes": (_sz, [_i, _i]),
+    "isr_ep_sample": (_i, [_vp, _vp, _i, _i, _d, _i, _u64, _vp, _vp, _sz, _vp]),
+    "isr_ep_p3p": (_i, [_vp, _i, _i, _vp, _vp, _i, _u64, _vp, _vp, _vp]),
+    "isr_zbuf_score_workspace_bytes": (_sz, [_i, _i]),
+    "isr_zbuf_score": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_add_metric": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
     "isr_rel_pose_table": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }

@@ -1,0 +1,417 @@
+// estimate_pose.hip — device stages of estimate_pose(), the SurfEmb-style sample-and-score pose
+// estimator (poseEstSurf.py:11-261; a6/a7 of SURVEY.md §8).
+//
+//   isr_ep_prepare      poseEstSurf.py:47-69   logsigmoid / max-pool / avg-pool of the mask logits,
+//                                              avg-pooled queries
+//   isr_ep_pool_corr    poseEstSurf.py:97-107  3x3 spatial max-pool of the (n x m) log-correspondence
+//                                              matrix (the reference loops over key chunks "to avoid oom")
+//   isr_ep_sample       poseEstSurf.py:111-119 inversion sampling of (pixel, key) pairs from corr^alpha
+//                                              WITHOUT the 4.4e8-element cumsum: f64 row / chunk sums,
+//                                              then a 3-level search per sample
+//   isr_ep_p3p          poseEstSurf.py:133-144 the 10 000-iteration Python loop over cv2.solveP3P:
+//                                              one thread per sample, all roots, ordered by the 4th
+//                                              point, Philox pick
+//   isr_zbuf_score      poseEstSurf.py:182-237 batch_score: project every vertex, z-buffer by
+//                                              atomicMin on packed (ordered z, vertex) u64 (replaces
+//                                              torch_scatter.scatter_min), mask / coordinate scores
+// The (n x m) matrix itself comes from isr_corr_logsoftmax.  RNG is explicit (Philox4x32-10): the
+// reference uses torch.rand on the device and an unseeded np.random.randint.
+#include "isr_common.hpp"
+#include "p3p_device.hpp"
+
+namespace {
+
+using namespace isr_p3p;
+
+__device__ __forceinline__ float logsigmoidf(float x) {  // torch: min(x, 0) - log1p(exp(-|x|))
+  return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}
+
+// ---------------------------------------------------------------- prepare: masks and queries
+__global__ void ep_mask_kernel(const float* __restrict__ lgts, int r, int s, int res, float* __restrict__ lp0,
+                               float* __restrict__ nlp0, float* __restrict__ mask_prob) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= res * res) return;
+  const int oy = o / res, ox = o % res;
+  float mx = -__builtin_inff(), nmx = -__builtin_inff(), sum = 0.f;
+  for (int dy = 0; dy < s; ++dy)
+    for (int dx = 0; dx < s; ++dx) {
+      const float x = lgts[(size_t)(oy * s + dy) * r + ox * s + dx];
+      mx = fmaxf(mx, logsigmoidf(x));
+      nmx = fmaxf(nmx, logsigmoidf(-x));
+      sum += x;
+    }
+  lp0[o] = mx;
+  nlp0[o] = nmx;
+  const float avg = sum / (float)(s * s);
+  mask_prob[o] = 1.f / (1.f + expf(-avg));
+}
+
+__global__ void ep_pool3_kernel(const float* __restrict__ a0, const float* __restrict__ b0, int res, int do_pool,
+                                float* __restrict__ a, float* __restrict__ b) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= res * res) return;
+  if (!do_pool) { a[o] = a0[o]; b[o] = b0[o]; return; }
+  const int oy = o / res, ox = o % res;
+  float ma = -__builtin_inff(), mb = -__builtin_inff();
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int y = oy + dy, x = ox + dx;
+      if (y >= 0 && y < res && x >= 0 && x < res) {
+        ma = fmaxf(ma, a0[y * res + x]);
+        mb = fmaxf(mb, b0[y * res + x]);
+      }
+    }
+  a[o] = ma;
+  b[o] = mb;
+}
+
+__global__ void ep_queries_kernel(const float* __restrict__ qimg, int r, int e, int s, int res, float* __restrict__ q) {
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)res * res * e) return;
+  const int c = (int)(t % e);
+  const int o = (int)(t / e);
+  const int oy = o / res, ox = o % res;
+  float sum = 0.f;
+  for (int dy = 0; dy < s; ++dy)
+    for (int dx = 0; dx < s; ++dx) sum += qimg[((size_t)(oy * s + dy) * r + ox * s + dx) * e + c];
+  q[(size_t)o * e + c] = sum / (float)(s * s);
+}
+
+// ------------------------------------------------------- 3x3 spatial max-pool of corr_log (n x m)
+__global__ void ep_pool_corr_kernel(const float* __restrict__ in, int res, int m, float* __restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  if (k >= m) return;
+  const int oy = o / res, ox = o % res;
+  float mx = -__builtin_inff();
+  for (int dy = -1; dy <= 1; ++dy)
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int y = oy + dy, x = ox + dx;
+      if (y >= 0 && y < res && x >= 0 && x < res) mx = fmaxf(mx, in[(size_t)(y * res + x) * m + k]);
+    }
+  out[(size_t)o * m + k] = mx;
+}
+
+// ------------------------------------------------------------------------ inversion sampling
+// weight of (pixel o, key k): (exp(corr_log) * mask_prob)^alpha, evaluated in f64 from the f32
+// inputs as exp(alpha * corr_log) * mask_prob^alpha so that a CPU restatement agrees to ~1e-16.
+constexpr int kChunk = 512;
+
+__device__ __forceinline__ double ep_weight(float cl, double mpa, double alpha) { return exp(alpha * (double)cl) * mpa; }
+
+__global__ void ep_chunk_sums_kernel(const float* __restrict__ corr_log, const float* __restrict__ mask_prob, int m,
+                                     int nchunk, double alpha, double* __restrict__ chunk_sums) {
+  __shared__ double red[4];
+  const int o = blockIdx.y, c = blockIdx.x;
+  const double mpa = pow((double)mask_prob[o], alpha);
+  double s = 0.0;
+  for (int j = threadIdx.x; j < kChunk; j += 256) {
+    const int k = c * kChunk + j;
+    if (k < m) s += ep_weight(corr_log[(size_t)o * m + k], mpa, alpha);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) chunk_sums[(size_t)o * nchunk + c] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// one thread per row: row sum (chunks in order); then thread 0 of block 0 is NOT used for the
+// row cumulative — a second tiny kernel does the serial inclusive scan over rows.
+__global__ void ep_row_sums_kernel(const double* __restrict__ chunk_sums, int n, int nchunk, double* __restrict__ row_sums) {
+  const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= n) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunk; ++c) s += chunk_sums[(size_t)o * nchunk + c];
+  row_sums[o] = s;
+}
+
+__global__ void ep_row_scan_kernel(const double* __restrict__ row_sums, int n, double* __restrict__ row_cum) {
+  if (blockIdx.x || threadIdx.x) return;
+  double s = 0.0;
+  for (int o = 0; o < n; ++o) { s += row_sums[o]; row_cum[o] = s; }
+}
+
+// sample (s, j): u = (x + 0.5) / 2^32 of Philox(counter = (s,1,0,0)); index = first flat position
+// whose inclusive cumulative weight reaches u * total (np.searchsorted, side='left').
+__global__ void ep_sample_kernel(const float* __restrict__ corr_log, const float* __restrict__ mask_prob, int n, int m,
+                                 int nchunk, double alpha, const double* __restrict__ chunk_sums,
+                                 const double* __restrict__ row_sums, const double* __restrict__ row_cum, int n_samples,
+                                 uint32_t seed_lo, uint32_t seed_hi, int64_t* __restrict__ corr_idx) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_samples * 4) return;
+  const int s = t >> 2, j = t & 3;
+  uint32_t rnd[4];
+  philox4x32_10((uint32_t)s, 1u, 0u, 0u, seed_lo, seed_hi, rnd);
+  const double u = ((double)rnd[j] + 0.5) * (1.0 / 4294967296.0);
+  const double target = u * row_cum[n - 1];
+  // row: first o with row_cum[o] >= target
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (row_cum[mid] >= target) hi = mid; else lo = mid + 1;
+  }
+  const int o = lo;
+  double rem = target - (o ? row_cum[o - 1] : 0.0);
+  // chunk: first c whose inclusive in-row cumulative reaches rem
+  int c = 0;
+  double acc = 0.0;
+  for (; c < nchunk - 1; ++c) {
+    const double nx = acc + chunk_sums[(size_t)o * nchunk + c];
+    if (nx >= rem) break;
+    acc = nx;
+  }
+  rem -= acc;
+  const double mpa = pow((double)mask_prob[o], alpha);
+  int k = c * kChunk;
+  const int kend = min(m, k + kChunk);
+  double a2 = 0.0;
+  for (; k < kend - 1; ++k) {
+    a2 += ep_weight(corr_log[(size_t)o * m + k], mpa, alpha);
+    if (a2 >= rem) break;
+  }
+  corr_idx[t] = (int64_t)o * m + k;
+}
+
+// ------------------------------------------------------------------------------------- P3P
+__global__ void ep_p3p_kernel(const int64_t* __restrict__ corr_idx, int res, int m, const float* __restrict__ obj_pts,
+                              Cam cam, int S, uint32_t seed_lo, uint32_t seed_hi, double* __restrict__ poses,
+                              uint8_t* __restrict__ ok_out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  int64_t ci[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) ci[j] = corr_idx[4 * (size_t)s + j];
+  const bool distinct = ci[0] != ci[1] && ci[0] != ci[2] && ci[0] != ci[3] && ci[1] != ci[2] && ci[1] != ci[3] && ci[2] != ci[3];
+  V3 X[4];
+  double uu[4], vv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pix = (int)(ci[j] / m), k = (int)(ci[j] % m);
+    uu[j] = (double)(pix % res);
+    vv[j] = (double)(pix / res);
+    X[j] = {(double)obj_pts[3 * (size_t)k], (double)obj_pts[3 * (size_t)k + 1], (double)obj_pts[3 * (size_t)k + 2]};
+  }
+  double* out = poses + 12 * (size_t)s;
+  uint8_t ok = 0;
+  if (distinct) {
+    P3PIn in;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { in.x[j] = X[j]; in.y[j] = bearing(cam, uu[j], vv[j]); }
+    double lam[4][3];
+    const int n = p3p_depths(in, lam);
+    double cand[4][12], err[4];
+    int nv = 0;
+    for (int i = 0; i < n; ++i) {
+      if (!pose_from_depths(in, lam[i], cand[nv])) continue;
+      double e2;
+      err[nv] = reproj_err2(cam, cand[nv], X[3], uu[3], vv[3], &e2) ? e2 : 1e300;
+      ++nv;
+    }
+    if (nv > 0) {
+      // order by the 4th point's reprojection error (stable insertion sort of indices)
+      int ord[4] = {0, 1, 2, 3};
+      for (int a = 1; a < nv; ++a) {
+        const int x = ord[a];
+        int b = a - 1;
+        while (b >= 0 && err[ord[b]] > err[x]) { ord[b + 1] = ord[b]; --b; }
+        ord[b + 1] = x;
+      }
+      uint32_t rnd[4];
+      philox4x32_10((uint32_t)s, 2u, 0u, 0u, seed_lo, seed_hi, rnd);
+      const int pick = (int)(((uint64_t)rnd[0] * (uint64_t)nv) >> 32);
+      const int sel = ord[pick];
+      ok = 1;
+      for (int q = 0; q < 12; ++q) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v = (i == sel) ? cand[i][q] : v;  // no runtime-indexed register array
+        out[q] = v;
+      }
+    }
+  }
+  if (!ok)
+    for (int q = 0; q < 12; ++q) out[q] = 0.0;
+  ok_out[s] = ok;
+}
+
+// --------------------------------------------------------------------------- z-buffer scoring
+__device__ __forceinline__ uint32_t ordered_u32(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+__device__ __forceinline__ float unordered_f32(uint32_t u) {
+  return __uint_as_float(u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
+struct K9f { float k[9]; };
+
+__global__ void zbuf_project_kernel(const float* __restrict__ pts, int m, const float* __restrict__ Rt, int B, K9f K,
+                                    int res, unsigned long long* __restrict__ zbuf) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (v >= m) return;
+  const float* T = Rt + 12 * (size_t)b;  // uniform per block row: scalar loads
+  const float x = pts[3 * (size_t)v], y = pts[3 * (size_t)v + 1], z = pts[3 * (size_t)v + 2];
+  // obj_pts @ R^T + t, then @ K^T, in f32 as the reference (torch f32 matmuls)
+  const float cx = x * T[0] + y * T[1] + z * T[2] + T[3];
+  const float cy = x * T[4] + y * T[5] + z * T[6] + T[7];
+  const float cz = x * T[8] + y * T[9] + z * T[10] + T[11];
+  const float ix = cx * K.k[0] + cy * K.k[1] + cz * K.k[2];
+  const float iy = cx * K.k[3] + cy * K.k[4] + cz * K.k[5];
+  const float iz = cx * K.k[6] + cy * K.k[7] + cz * K.k[8];
+  const float ux = rintf(ix / iz), uy = rintf(iy / iz);  // torch.round_: half to even
+  if (!(ux >= 0.f) || !(ux < (float)res) || !(uy >= 0.f) || !(uy < (float)res)) return;  // ignore bin (NaN too)
+  const int pix = (int)uy * res + (int)ux;
+  const unsigned long long key = ((unsigned long long)ordered_u32(cz) << 32) | (unsigned)v;
+  atomicMin(&zbuf[(size_t)b * res * res + pix], key);
+}
+
+// one block per pose: mask score = mean over ALL pixels of (hit ? mask_log_prob : neg_mask_log_prob) / ln 2,
+// coord score = mean over hit pixels of corr_log[pixel, nearest vertex] / ln m  (-inf without hits)
+__global__ __launch_bounds__(256) void zbuf_score_kernel(const unsigned long long* __restrict__ zbuf, int n, int m,
+                                                         const float* __restrict__ mlp, const float* __restrict__ nmlp,
+                                                         const float* __restrict__ corr_log, float* __restrict__ pose_score,
+                                                         float* __restrict__ mask_score, float* __restrict__ coord_score) {
+  __shared__ double red[3][4];
+  const int b = blockIdx.x;
+  double sm = 0.0, sc = 0.0, cnt = 0.0;
+  for (int pix = threadIdx.x; pix < n; pix += 256) {
+    const unsigned long long key = zbuf[(size_t)b * n + pix];
+    bool hit = false;
+    if (key != ~0ull) {
+      const float z = unordered_f32((uint32_t)(key >> 32));
+      if (z > 0.f) {
+        hit = true;
+        sc += (double)corr_log[(size_t)pix * m + (uint32_t)key];
+        cnt += 1.0;
+      }
+    }
+    sm += (double)(hit ? mlp[pix] : nmlp[pix]);
+  }
+  double v[3] = {sm, sc, cnt};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double s = v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tm = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    const double tc = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    const double tn = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+    const float ms = (float)(tm / (double)n / 0.6931471805599453);
+    const float cs = tn > 0.0 ? (float)(tc / tn / log((double)m)) : -__builtin_inff();
+    mask_score[b] = ms;
+    coord_score[b] = cs;
+    pose_score[b] = ms + cs;
+  }
+}
+
+}  // namespace
+
+extern "C" int isr_ep_prepare(const float* mask_lgts, const float* query_img, int r, int e, int scale, int max_pool,
+                              float* mask_log_prob, float* neg_mask_log_prob, float* mask_prob, float* queries,
+                              void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(mask_lgts && query_img && mask_log_prob && neg_mask_log_prob && mask_prob && queries,
+              "isr_ep_prepare: null pointer");
+  ISR_REQUIRE(r > 0 && e > 0 && scale > 0 && r / scale > 0, "isr_ep_prepare: r=%d e=%d scale=%d", r, e, scale);
+  const int res = r / scale, n = res * res;
+  if (!ws || ws_bytes < 2 * sizeof(float) * (size_t)n + 512) {
+    isr::set_error("isr_ep_prepare: workspace %zu < %zu", ws_bytes, 2 * sizeof(float) * (size_t)n + 512);
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  isr::Workspace w(ws, ws_bytes);
+  float* lp0 = w.take<float>(n);
+  float* nlp0 = w.take<float>(n);
+  ep_mask_kernel<<<(n + 255) / 256, 256, 0, stream>>>(mask_lgts, r, scale, res, lp0, nlp0, mask_prob);
+  ep_pool3_kernel<<<(n + 255) / 256, 256, 0, stream>>>(lp0, nlp0, res, max_pool, mask_log_prob, neg_mask_log_prob);
+  const long tq = (long)n * e;
+  ep_queries_kernel<<<(unsigned)((tq + 255) / 256), 256, 0, stream>>>(query_img, r, e, scale, res, queries);
+  ISR_CHECK_LAUNCH("ep_prepare kernels");
+  return ISR_OK;
+}
+
+extern "C" int isr_ep_pool_corr(const float* corr_log, int res, int m, float* pooled, isr_stream_t stream) {
+  ISR_REQUIRE(corr_log && pooled && corr_log != pooled, "isr_ep_pool_corr: null or aliased pointer");
+  ISR_REQUIRE(res > 0 && m > 0 && res * res <= 65535, "isr_ep_pool_corr: res=%d m=%d", res, m);
+  ep_pool_corr_kernel<<<dim3((m + 255) / 256, res * res), 256, 0, isr::as_stream(stream)>>>(corr_log, res, m, pooled);
+  ISR_CHECK_LAUNCH("ep_pool_corr_kernel");
+  return ISR_OK;
+}
+
+extern "C" size_t isr_ep_sample_workspace_bytes(int n, int m) {
+  if (n <= 0 || m <= 0) return 0;
+  const size_t nchunk = ((size_t)m + kChunk - 1) / kChunk;
+  return isr::align_up(sizeof(double) * n * nchunk, 256) + 2 * isr::align_up(sizeof(double) * n, 256) + 512;
+}
+
+extern "C" int isr_ep_sample(const float* corr_log, const float* mask_prob, int n, int m, double alpha, int n_samples,
+                             uint64_t seed, int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(corr_log && mask_prob && corr_idx, "isr_ep_sample: null pointer");
+  ISR_REQUIRE(n > 0 && m > 0 && n_samples > 0 && n <= 65535, "isr_ep_sample: n=%d m=%d n_samples=%d", n, m, n_samples);
+  if (!ws || ws_bytes < isr_ep_sample_workspace_bytes(n, m)) {
+    isr::set_error("isr_ep_sample: workspace %zu < %zu", ws_bytes, isr_ep_sample_workspace_bytes(n, m));
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  const int nchunk = (m + kChunk - 1) / kChunk;
+  isr::Workspace w(ws, ws_bytes);
+  double* chunk_sums = w.take<double>((size_t)n * nchunk);
+  double* row_sums = w.take<double>(n);
+  double* row_cum = w.take<double>(n);
+  ep_chunk_sums_kernel<<<dim3(nchunk, n), 256, 0, stream>>>(corr_log, mask_prob, m, nchunk, alpha, chunk_sums);
+  ep_row_sums_kernel<<<(n + 255) / 256, 256, 0, stream>>>(chunk_sums, n, nchunk, row_sums);
+  ep_row_scan_kernel<<<1, 64, 0, stream>>>(row_sums, n, row_cum);
+  ep_sample_kernel<<<(n_samples * 4 + 255) / 256, 256, 0, stream>>>(corr_log, mask_prob, n, m, nchunk, alpha, chunk_sums,
+                                                                   row_sums, row_cum, n_samples, (uint32_t)seed,
+                                                                   (uint32_t)(seed >> 32), corr_idx);
+  ISR_CHECK_LAUNCH("ep_sample kernels");
+  return ISR_OK;
+}
+
+extern "C" int isr_ep_p3p(const int64_t* corr_idx, int res, int m, const float* obj_pts, const double* Kcam, int S,
+                          uint64_t seed, double* poses, uint8_t* ok, isr_stream_t stream) {
+  ISR_REQUIRE(corr_idx && obj_pts && Kcam && poses && ok, "isr_ep_p3p: null pointer");
+  ISR_REQUIRE(res > 0 && m > 0 && S > 0, "isr_ep_p3p: res=%d m=%d S=%d", res, m, S);
+  Cam cam;
+  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_ep_p3p: singular camera matrix");
+  ep_p3p_kernel<<<(S + 63) / 64, 64, 0, isr::as_stream(stream)>>>(corr_idx, res, m, obj_pts, cam, S, (uint32_t)seed,
+                                                                 (uint32_t)(seed >> 32), poses, ok);
+  ISR_CHECK_LAUNCH("ep_p3p_kernel");
+  return ISR_OK;
+}
+
+extern "C" size_t isr_zbuf_score_workspace_bytes(int B, int res) {
+  if (B <= 0 || res <= 0) return 0;
+  return sizeof(unsigned long long) * (size_t)B * res * res + 512;
+}
+
+extern "C" int isr_zbuf_score(const float* obj_pts, int m, const float* Rt, int B, const double* Kcam, int res,
+                              const float* mask_log_prob, const float* neg_mask_log_prob, const float* corr_log,
+                              float* pose_score, float* mask_score, float* coord_score, void* ws, size_t ws_bytes,
+                              isr_stream_t stream_) {
+  ISR_REQUIRE(obj_pts && Rt && Kcam && mask_log_prob && neg_mask_log_prob && corr_log && pose_score && mask_score &&
+                  coord_score, "isr_zbuf_score: null pointer");
+  ISR_REQUIRE(m > 0 && B > 0 && B <= 65535 && res > 0, "isr_zbuf_score: m=%d B=%d res=%d", m, B, res);
+  if (!ws || ws_bytes < isr_zbuf_score_workspace_bytes(B, res)) {
+    isr::set_error("isr_zbuf_score: workspace %zu < %zu", ws_bytes, isr_zbuf_score_workspace_bytes(B, res));
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  const int n = res * res;
+  isr::Workspace w(ws, ws_bytes);
+  unsigned long long* zbuf = w.take<unsigned long long>((size_t)B * n);
+  ISR_CHECK_HIP(hipMemsetAsync(zbuf, 0xFF, sizeof(unsigned long long) * (size_t)B * n, stream));
+  K9f K;
+  for (int i = 0; i < 9; ++i) K.k[i] = (float)Kcam[i];
+  zbuf_project_kernel<<<dim3((m + 255) / 256, B), 256, 0, stream>>>(obj_pts, m, Rt, B, K, res, zbuf);
+  zbuf_score_kernel<<<B, 256, 0, stream>>>(zbuf, n, m, mask_log_prob, neg_mask_log_prob, corr_log, pose_score, mask_score,
+                                           coord_score);
+  ISR_CHECK_LAUNCH("zbuf kernels");
+  return ISR_OK;
+}

@@ -1,0 +1,174 @@
+"""estimate_pose() with the reference's signature (poseEstSurf.py:11-15, returns :258-261), the device
+stages in csrc/estimate_pose.hip + isr_corr_logsoftmax.
+
+What moved to the device: mask / query pooling, the (n x m) log-softmax correspondence matrix and its
+3x3 spatial max-pool, inversion sampling (no 4.4e8-element cumsum), the 10 000-iteration cv2.solveP3P
+Python loop (one thread per sample), and batch_score's scatter_min z-buffer.  What stays on the host,
+as in the reference: the pruning masks (NumPy on <= 10 000 poses, poseEstSurf.py:147-169) and the
+slicing to max_pose_evaluations.  `seed` is an addition: the reference draws torch.rand on the device
+and an unseeded np.random.randint.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from . import ops
+from ._capi import IsrError, check, current_stream, lib, ptr, require_cuda
+from .registration import SOLVEPNP_AP3P, _dev
+
+
+def _k_scaled(K, scale):
+    K = np.asarray(K, np.float64).copy()         # the reference copies K too (poseEstSurf.py:42)
+    K[:2, 2] += 0.5
+    K[:2] /= scale
+    K[:2, 2] -= 0.5
+    return K
+
+
+def _kptr(K):
+    arr = (ctypes.c_double * 9)(*np.asarray(K, np.float64).reshape(9).tolist())
+    return arr, ctypes.cast(arr, ctypes.c_void_p)
+
+
+def prepare(mask_lgts: torch.Tensor, query_img: torch.Tensor, scale: int = 3, max_pool: bool = True):
+    """isr_ep_prepare -> mask_log_prob (n,), neg_mask_log_prob (n,), mask_prob (n,), queries (n,e), res."""
+    dev = require_cuda(mask_lgts, query_img)
+    ml = mask_lgts.to(torch.float32).contiguous()
+    qi = query_img.to(torch.float32).contiguous()
+    r, e = ml.shape[0], qi.shape[-1]
+    if ml.shape != (r, r) or qi.shape != (r, r, e):
+        raise ValueError(f"mask_lgts {tuple(ml.shape)} / query_img {tuple(qi.shape)} must be (r,r) / (r,r,e)")
+    res = r // scale
+    n = res * res
+    mlp = torch.empty(n, dtype=torch.float32, device=dev)
+    nmlp = torch.empty(n, dtype=torch.float32, device=dev)
+    mp = torch.empty(n, dtype=torch.float32, device=dev)
+    q = torch.empty((n, e), dtype=torch.float32, device=dev)
+    ws = ops.workspace(dev, 8 * n + 1024, "ep")
+    with torch.cuda.device(dev):
+        rc = lib().isr_ep_prepare(ptr(ml), ptr(qi), r, e, scale, int(bool(max_pool)), ptr(mlp), ptr(nmlp), ptr(mp),
+                                  ptr(q), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_ep_prepare")
+    return mlp, nmlp, mp, q, res
+
+
+def pool_corr(corr_log: torch.Tensor, res: int) -> torch.Tensor:
+    dev = require_cuda(corr_log)
+    out = torch.empty_like(corr_log)
+    with torch.cuda.device(dev):
+        rc = lib().isr_ep_pool_corr(ptr(corr_log), res, corr_log.shape[1], ptr(out), current_stream(dev))
+    check(rc, "isr_ep_pool_corr")
+    return out
+
+
+def sample(corr_log: torch.Tensor, mask_prob: torch.Tensor, alpha: float, n_samples: int, seed: int) -> torch.Tensor:
+    dev = require_cuda(corr_log, mask_prob)
+    n, m = corr_log.shape
+    idx = torch.empty((n_samples, 4), dtype=torch.int64, device=dev)
+    L = lib()
+    ws = ops.workspace(dev, L.isr_ep_sample_workspace_bytes(n, m), "ep_sample")
+    with torch.cuda.device(dev):
+        rc = L.isr_ep_sample(ptr(corr_log), ptr(mask_prob), n, m, float(alpha), int(n_samples),
+                             seed & 0xFFFFFFFFFFFFFFFF, ptr(idx), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_ep_sample")
+    return idx
+
+
+def p3p_samples(corr_idx: torch.Tensor, res: int, m: int, obj_pts: torch.Tensor, K, seed: int):
+    dev = require_cuda(corr_idx, obj_pts)
+    S = corr_idx.shape[0]
+    poses = torch.empty((S, 3, 4), dtype=torch.float64, device=dev)
+    ok = torch.empty(S, dtype=torch.uint8, device=dev)
+    keep, kp = _kptr(K)
+    with torch.cuda.device(dev):
+        rc = lib().isr_ep_p3p(ptr(corr_idx), res, m, ptr(obj_pts), kp, S, seed & 0xFFFFFFFFFFFFFFFF, ptr(poses), ptr(ok),
+                              current_stream(dev))
+    check(rc, "isr_ep_p3p")
+    return poses, ok
+
+
+def zbuf_score(obj_pts, R, t, K, res, mask_log_prob, neg_mask_log_prob, corr_log):
+    """batch_score (poseEstSurf.py:182-237) for R (B,3,3), t (B,3) f32 on the device -> 3 x (B,) f32."""
+    dev = require_cuda(obj_pts, R, t)
+    B, m = R.shape[0], obj_pts.shape[0]
+    Rt = torch.cat([R.to(torch.float32), t.to(torch.float32)[:, :, None]], dim=2).contiguous()
+    out = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3)]
+    L = lib()
+    ws = ops.workspace(dev, L.isr_zbuf_score_workspace_bytes(B, res), "zbuf")
+    keep, kp = _kptr(K)
+    with torch.cuda.device(dev):
+        rc = L.isr_zbuf_score(ptr(obj_pts), m, ptr(Rt), B, kp, res, ptr(mask_log_prob), ptr(neg_mask_log_prob),
+                              ptr(corr_log), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(ws), ws.numel(),
+                              current_stream(dev))
+    check(rc, "isr_zbuf_score")
+    return out
+
+
+def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses=10000,
+                  max_pose_evaluations=1000, down_sample_scale=3, alpha=1.5, dist_2d_min=0.1,
+                  pnp_method=SOLVEPNP_AP3P, pose_batch_size=500, max_pool=True, avg_queries=True, do_prune=True,
+                  visualize=False, poses=None, debug=False, returnPoints=False, *, seed=0):
+    """poseEstSurf.py:11-261.  mask_lgts (r,r), query_img (r,r,e), obj_pts (m,3), obj_keys (m,e) on the
+    device (host arrays are uploaded); obj_normals a NumPy (m,3) array as in the reference (:121).
+    Returns R (n_poses,3,3) f32, t (n_poses,3) f32, pose_scores, mask_scores, coord_scores (device),
+    dist_2d, size_mask, normals_mask (NumPy, pre-prune length) [+ p3dCp, p2dCp if returnPoints]."""
+    del pnp_method
+    if not avg_queries:
+        raise IsrError("estimate_pose(avg_queries=False) — the patch-wise variant (poseEstSurf.py:72-96) is not built")
+    if visualize:
+        raise IsrError("estimate_pose(visualize=True) needs cv2.imshow; not available")
+    mask_lgts, query_img = _dev(mask_lgts, torch.float32), _dev(query_img, torch.float32)
+    obj_pts_d, obj_keys_d = _dev(obj_pts, torch.float32).contiguous(), _dev(obj_keys, torch.float32).contiguous()
+    dev = mask_lgts.device
+    m = obj_keys_d.shape[0]
+    Ks = _k_scaled(K, down_sample_scale)
+    mlp, nmlp, mprob, queries, res = prepare(mask_lgts, query_img, down_sample_scale, max_pool)
+    corr_raw = ops.corr_logsoftmax(queries, obj_keys_d)                        # (n, m) f32
+    corr_log = pool_corr(corr_raw, res) if max_pool else corr_raw
+    dist_2d = size_mask = normals_mask = None
+    p3dCp = p2dCp = None
+    if poses is None:
+        corr_idx = sample(corr_raw, mprob, alpha, max_poses, seed)
+        poses_d, ok = p3p_samples(corr_idx, res, m, obj_pts_d, Ks, seed)
+        ci = corr_idx.cpu().numpy()
+        pmask = ok.cpu().numpy().astype(bool)
+        poses = poses_d.cpu().numpy()
+        p2d_idx, p3d_idx = ci // m, ci % m
+        p2d = np.stack([p2d_idx % res, p2d_idx // res], axis=-1).astype(np.float32)       # img_pts[p2d_idx].float()
+        p3d = obj_pts_d.cpu().numpy()[p3d_idx]
+        n3d = np.asarray(obj_normals)[p3d_idx[:, :3]]
+        poses, p2d, p3d, n3d = [a[pmask] for a in (poses, p2d, p3d, n3d)]
+        # pruning, verbatim NumPy (poseEstSurf.py:147-169)
+        dist_2d = np.linalg.norm(p2d[:, :3, None] - p2d[:, None, :3], axis=-1).max(axis=(1, 2)) if len(p2d) else np.zeros(0)
+        dist_2d_mask = dist_2d >= dist_2d_min * res
+        z = poses[:, 2, 3]
+        z_min = Ks[0, 0] * obj_diameter / (res * 20)
+        z_max = Ks[0, 0] * obj_diameter / (res * 0.5)
+        size_mask = (z_min < z) & (z < z_max)
+        Rt = poses[:, :3, :3].transpose(0, 2, 1)
+        n3d_cam = n3d @ Rt
+        p3d_cam = p3d[:, :3] @ Rt + poses[:, None, :3, 3]
+        normals_mask = np.all((n3d_cam * p3d_cam).sum(axis=-1) < 0, axis=-1)
+        if do_prune:
+            keep = dist_2d_mask & size_mask & normals_mask
+            poses, p3dCp, p2dCp = poses[keep], p3d[keep], p2d[keep]
+    poses = np.asarray(poses)[slice(None, max_pose_evaluations)]
+    n_poses = len(poses)
+    if debug:
+        print('n_poses', n_poses)
+    R = torch.from_numpy(np.ascontiguousarray(poses[:, :3, :3])).float().to(dev)
+    t = torch.from_numpy(np.ascontiguousarray(poses[:, :3, 3])).float().to(dev)
+    pose_scores = torch.empty(n_poses, device=dev)
+    mask_scores = torch.empty(n_poses, device=dev)
+    coord_scores = torch.empty(n_poses, device=dev)
+    for l in range(0, n_poses, pose_batch_size):
+        ps, ms, cs = zbuf_score(obj_pts_d, R[l:l + pose_batch_size], t[l:l + pose_batch_size], Ks, res, mlp, nmlp, corr_log)
+        pose_scores[l:l + pose_batch_size] = ps
+        mask_scores[l:l + pose_batch_size] = ms
+        coord_scores[l:l + pose_batch_size] = cs
+    if returnPoints:
+        return R, t, pose_scores, mask_scores, coord_scores, dist_2d, size_mask, normals_mask, p3dCp, p2dCp
+    return R, t, pose_scores, mask_scores, coord_scores, dist_2d, size_mask, normals_mask

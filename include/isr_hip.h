@@ -148,6 +148,43 @@ int isr_nn_batched(const float* qry, int Nq, const float* tgt, int Nt, const dou
                    int32_t* n_in, int32_t* nn_idx, double* nn_d, double* cov, void* ws,
                    size_t ws_bytes, isr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * a6 / a7  estimate_pose(): the SurfEmb-style sample-and-score estimator, poseEstSurf.py:11-261
+ * (stages; the host driver pose_est_surf.estimate_pose keeps the reference's signature).
+ *
+ * isr_ep_prepare   :47-69   mask_lgts (r,r), query_img (r,r,e) f32 -> res = r / scale, n = res^2:
+ *                  mask_log_prob / neg_mask_log_prob (n) = [3x3-max-pooled] max_pool(logsigmoid(+-lgts)),
+ *                  mask_prob (n) = sigmoid(avg_pool(lgts)), queries (n,e) = avg_pool(query_img).
+ *                  ws >= 2*n*4 + 512 bytes.
+ * isr_ep_pool_corr :97-107  pooled[o][k] = max over the 3x3 pixel neighbourhood of corr_log[.][k].
+ * isr_ep_sample    :111-119 corr_idx (n_samples,4) i64 = flat (pixel*m + key) indices drawn with
+ *                  probability ~ (exp(corr_log) * mask_prob)^alpha by inversion of Philox uniforms
+ *                  ((x+0.5)/2^32, counter (s,1,0,0)); no (n*m) cumulative array is formed.
+ * isr_ep_p3p       :133-144 per sample: P3P (f64) on the first three correspondences, roots ordered by
+ *                  the 4th point's reprojection error, one picked by Philox (counter (s,2,0,0));
+ *                  samples that repeat a correspondence are rejected.  poses (S,12) f64, ok (S) u8.
+ *                  Pixel coordinates are (idx % res, idx / res) as img_pts at :56-59.
+ * isr_zbuf_score   :182-237 batch_score for B poses (Rt (B,12) f32): z-buffer by atomicMin on packed
+ *                  (ordered z, vertex) u64 — lowest vertex on equal z — then
+ *                  mask_score = mean_n(hit ? mask_log_prob : neg_mask_log_prob)/ln 2,
+ *                  coord_score = mean_hit(corr_log[pixel, vertex])/ln m (-inf without hits).
+ * Kcam: host, 9 doubles, ALREADY divided by the down-sample scale (poseEstSurf.py:42-45).
+ */
+int isr_ep_prepare(const float* mask_lgts, const float* query_img, int r, int e, int scale, int max_pool,
+                   float* mask_log_prob, float* neg_mask_log_prob, float* mask_prob, float* queries,
+                   void* ws, size_t ws_bytes, isr_stream_t stream);
+int isr_ep_pool_corr(const float* corr_log, int res, int m, float* pooled, isr_stream_t stream);
+size_t isr_ep_sample_workspace_bytes(int n, int m);
+int isr_ep_sample(const float* corr_log, const float* mask_prob, int n, int m, double alpha, int n_samples,
+                  uint64_t seed, int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream);
+int isr_ep_p3p(const int64_t* corr_idx, int res, int m, const float* obj_pts, const double* Kcam, int S,
+               uint64_t seed, double* poses, uint8_t* ok, isr_stream_t stream);
+size_t isr_zbuf_score_workspace_bytes(int B, int res);
+int isr_zbuf_score(const float* obj_pts, int m, const float* Rt, int B, const double* Kcam, int res,
+                   const float* mask_log_prob, const float* neg_mask_log_prob, const float* corr_log,
+                   float* pose_score, float* mask_score, float* coord_score, void* ws, size_t ws_bytes,
+                   isr_stream_t stream);
+
 /* a8  ADD(verts, gtR, gtT, R, T)   inference.py:116-117
  * mean_out[b] = mean_v || Ta[b] v - Tb[b] v ||  (f64; Ta/Tb (B,12) f64 [R|t], NULL = identity). */
 int isr_add_metric(const float* verts, int V, const double* Ta, const double* Tb, int B,
