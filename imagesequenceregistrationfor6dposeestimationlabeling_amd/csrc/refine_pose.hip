@@ -1,0 +1,118 @@
+// refine_pose.hip — a16: the objective of refine_pose() (pose_refine.py:58-91) and its gradient.
+//
+//   p_img  = (K_crop [R|t]) X,  p = p_img[:2] / p_img[2]
+//   score  = -( mean_i <keys_i, bilinear(query_img, p_i)> - mean_i bilinear(denom_img, p_i) ) / 2
+// with F.grid_sample(align_corners=False, padding_mode='border', mode='bilinear') on
+// p_norm = (p + 0.5) * 2 / res - 1, i.e. the sample position in pixel units is p itself (pixel
+// centres at integers) clamped to [0, res-1].  The reference differentiates this with autograd and
+// a cv2.Rodrigues round trip; only the translation is live there (pose_refine.py:73-76 builds R from
+// a constant), so the analytic gradient returned here is d score / d t.
+// One thread per visible surface point, f64 accumulation, fixed-shape tree reduction.
+#include "isr_common.hpp"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kBlocks = 64;
+
+struct P34 { double p[12]; double k[9]; };
+
+__global__ __launch_bounds__(kThreads) void refine_obj_kernel(const float* __restrict__ X, const float* __restrict__ keys,
+                                                              int N, int e, const float* __restrict__ qimg,
+                                                              const float* __restrict__ denom, int res, P34 P,
+                                                              double* __restrict__ partial) {
+  __shared__ double red[kThreads / 64][5];
+  double acc[5] = {0, 0, 0, 0, 0};  // sum nominator, sum denominator, d/dt (3) of (nom - den)
+  for (int i = blockIdx.x * kThreads + threadIdx.x; i < N; i += kBlocks * kThreads) {
+    const double x = X[3 * (size_t)i], y = X[3 * (size_t)i + 1], z = X[3 * (size_t)i + 2];
+    const double px = P.p[0] * x + P.p[1] * y + P.p[2] * z + P.p[3];
+    const double py = P.p[4] * x + P.p[5] * y + P.p[6] * z + P.p[7];
+    const double pz = P.p[8] * x + P.p[9] * y + P.p[10] * z + P.p[11];
+    const double ipz = 1.0 / pz;
+    const double u = px * ipz, v = py * ipz;
+    // border padding: clamp, zero gradient outside
+    const double hi = (double)(res - 1);
+    const double uc = fmin(fmax(u, 0.0), hi), vc = fmin(fmax(v, 0.0), hi);
+    const double gu = (u > 0.0 && u < hi) ? 1.0 : 0.0, gv = (v > 0.0 && v < hi) ? 1.0 : 0.0;
+    int x0 = (int)floor(uc), y0 = (int)floor(vc);
+    x0 = x0 > res - 2 ? res - 2 : x0;
+    y0 = y0 > res - 2 ? res - 2 : y0;
+    if (res < 2) { x0 = 0; y0 = 0; }
+    const int x1 = res < 2 ? 0 : x0 + 1, y1 = res < 2 ? 0 : y0 + 1;
+    const double wx = uc - x0, wy = vc - y0;
+    const size_t o00 = (size_t)y0 * res + x0, o10 = (size_t)y0 * res + x1, o01 = (size_t)y1 * res + x0,
+                 o11 = (size_t)y1 * res + x1;
+    double nom = 0.0, dnx = 0.0, dny = 0.0;
+    for (int c = 0; c < e; ++c) {
+      const double k = keys[(size_t)i * e + c];
+      const double v00 = qimg[o00 * e + c], v10 = qimg[o10 * e + c], v01 = qimg[o01 * e + c], v11 = qimg[o11 * e + c];
+      nom += k * ((1 - wy) * ((1 - wx) * v00 + wx * v10) + wy * ((1 - wx) * v01 + wx * v11));
+      dnx += k * ((1 - wy) * (v10 - v00) + wy * (v11 - v01));
+      dny += k * ((1 - wx) * (v01 - v00) + wx * (v11 - v10));
+    }
+    const double d00 = denom[o00], d10 = denom[o10], d01 = denom[o01], d11 = denom[o11];
+    const double den = (1 - wy) * ((1 - wx) * d00 + wx * d10) + wy * ((1 - wx) * d01 + wx * d11);
+    const double ddx = (1 - wy) * (d10 - d00) + wy * (d11 - d01);
+    const double ddy = (1 - wx) * (d01 - d00) + wx * (d11 - d10);
+    const double fx = (dnx - ddx) * gu, fy = (dny - ddy) * gv;  // d(nom - den)/d(u, v)
+    acc[0] += nom;
+    acc[1] += den;
+    // d(u,v)/dt = (K_row0 - u K_row2, K_row1 - v K_row2) / pz
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      acc[2 + j] += (fx * (P.k[j] - u * P.k[6 + j]) + fy * (P.k[3 + j] - v * P.k[6 + j])) * ipz;
+  }
+#pragma unroll
+  for (int q = 0; q < 5; ++q) {
+    double s = acc[q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 5)
+    partial[(size_t)blockIdx.x * 5 + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ void refine_obj_reduce_kernel(const double* __restrict__ partial, int N, double* __restrict__ out) {
+  if (threadIdx.x >= 5 || blockIdx.x) return;
+  double s = 0.0;
+  for (int b = 0; b < kBlocks; ++b) s += partial[(size_t)b * 5 + threadIdx.x];
+  __shared__ double v[5];
+  v[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double n = (double)N;
+    out[0] = -(v[0] / n - v[1] / n) / 2.0;
+    out[1] = -(v[2] / n) / 2.0;
+    out[2] = -(v[3] / n) / 2.0;
+    out[3] = -(v[4] / n) / 2.0;
+  }
+}
+
+}  // namespace
+
+extern "C" int isr_refine_objective(const float* X, const float* keys, int N, int e, const float* query_img,
+                                    const float* denom_img, int res, const double* Kcrop, const double* Rt,
+                                    double* out4, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(X && keys && query_img && denom_img && Kcrop && Rt && out4, "isr_refine_objective: null pointer");
+  ISR_REQUIRE(N > 0 && e > 0 && res > 0, "isr_refine_objective: N=%d e=%d res=%d", N, e, res);
+  const size_t need = sizeof(double) * kBlocks * 5 + 256;
+  if (!ws || ws_bytes < need) {
+    isr::set_error("isr_refine_objective: workspace %zu < %zu", ws_bytes, need);
+    return ISR_ERR_WORKSPACE;
+  }
+  P34 P;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c)
+      P.p[4 * r + c] = Kcrop[3 * r] * Rt[c] + Kcrop[3 * r + 1] * Rt[4 + c] + Kcrop[3 * r + 2] * Rt[8 + c];
+  for (int i = 0; i < 9; ++i) P.k[i] = Kcrop[i];
+  hipStream_t stream = isr::as_stream(stream_);
+  isr::Workspace w(ws, ws_bytes);
+  double* partial = w.take<double>((size_t)kBlocks * 5);
+  refine_obj_kernel<<<kBlocks, kThreads, 0, stream>>>(X, keys, N, e, query_img, denom_img, res, P, partial);
+  refine_obj_reduce_kernel<<<1, 64, 0, stream>>>(partial, N, out4);
+  ISR_CHECK_LAUNCH("refine objective kernels");
+  return ISR_OK;
+}

@@ -1,0 +1,92 @@
+"""refine_pose() with the reference's signature (pose_refine.py:21-104).
+
+The caller-supplied objects are used exactly as the reference uses them: `renderer.render(obj_idx,
+K_crop, R, t[:,None])` for the visible object coordinates, `neural_radiance_field.batched_customForward`
+for their key descriptors, `obj_.scale / .offset / .diameter`.  What runs in HIP kernels: the
+log-sum-exp denominator image (K1's `lse` output over the sampled keys — no (H*W x 10 960) matrix)
+and the bilinear objective with its analytic translation gradient (isr_refine_objective) — the
+reference builds both with torch autograd and a cv2.Rodrigues round trip per evaluation.  BFGS stays
+scipy.optimize.minimize on the host, as in the reference.  As there, only the translation is
+optimised (the objective's rotation is a constant, pose_refine.py:73-76): R is returned unchanged.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+from scipy.optimize import minimize
+
+from . import ops
+from ._capi import check, current_stream, lib, ptr, require_cuda
+from .registration import _dev
+
+
+class RefineObjective:
+    """score(t), grad(t) of pose_refine.py:70-91 for a fixed rotation, evaluated on the device."""
+
+    def __init__(self, coord_obj: torch.Tensor, keys_masked: torch.Tensor, query_img: torch.Tensor,
+                 denom_img: torch.Tensor, K_crop, R):
+        self.dev = require_cuda(coord_obj, keys_masked, query_img, denom_img)
+        self.X = coord_obj.to(torch.float32).contiguous()
+        self.keys = keys_masked.to(torch.float32).contiguous()
+        self.q = query_img.to(torch.float32).contiguous()
+        self.den = denom_img.to(torch.float32).reshape(query_img.shape[0], query_img.shape[1]).contiguous()
+        self.K = (ctypes.c_double * 9)(*np.asarray(K_crop, np.float64).reshape(9).tolist())
+        self.R = np.asarray(R, np.float64).reshape(3, 3)
+        self.out = torch.empty(4, dtype=torch.float64, device=self.dev)
+        self.ws = ops.workspace(self.dev, 1 << 16, "refine_obj")
+
+    def _eval(self, t):
+        Rt = np.concatenate([self.R, np.asarray(t, np.float64).reshape(3, 1)], axis=1).reshape(12)
+        rt = (ctypes.c_double * 12)(*Rt.tolist())
+        N, e = self.keys.shape
+        with torch.cuda.device(self.dev):
+            rc = lib().isr_refine_objective(ptr(self.X), ptr(self.keys), N, e, ptr(self.q), ptr(self.den),
+                                            self.q.shape[0], ctypes.cast(self.K, ctypes.c_void_p),
+                                            ctypes.cast(rt, ctypes.c_void_p), ptr(self.out), ptr(self.ws),
+                                            self.ws.numel(), current_stream(self.dev))
+        check(rc, "isr_refine_objective")
+        return self.out.cpu().numpy()
+
+    def __call__(self, pose, return_grad=False):
+        """pose: the reference's 6-vector (rvec ignored, t = pose[3:])."""
+        o = self._eval(np.asarray(pose, np.float64)[3:])
+        if return_grad:
+            return np.concatenate([np.zeros(3), o[1:]])       # autograd leaves the unused rvec slots at 0
+        return float(o[0])
+
+
+def denominator_image(query_img: torch.Tensor, keys_sampled: torch.Tensor) -> torch.Tensor:
+    """pose_refine.py:56: logsumexp(query_img @ keys_sampled.T, -1) -> (H, W, 1), via K1's lse output."""
+    H, W, e = query_img.shape
+    _, _, lse = ops.corr_argmax(query_img.reshape(H * W, e).to(torch.float32), keys_sampled.to(torch.float32),
+                                want_lse=True)
+    return lse.reshape(H, W, 1)
+
+
+def refine_pose(R, t, query_img, renderer, obj_idx, K_crop, obj_, neural_radiance_field, keys_verts,
+                interpolation='bilinear', n_samples_denom=10960, method='BFGS', *, generator=None):
+    """pose_refine.py:21-104.  Returns (R, t (3,), result.fun)."""
+    if interpolation != 'bilinear':
+        raise ValueError("only interpolation='bilinear' is built (the reference's default)")
+    query_img = _dev(query_img, torch.float32)
+    h, w, _ = query_img.shape
+    assert h == w
+    dev = query_img.device
+    t = np.asarray(t, np.float64).reshape(3)
+    coord_img = renderer.render(obj_idx, K_crop, R, np.expand_dims(t, axis=1))
+    coord_img = coord_img.cpu().numpy() if isinstance(coord_img, torch.Tensor) else np.asarray(coord_img)
+    mask = coord_img[..., 3] == 1.
+    coord_norm_masked = torch.from_numpy(np.ascontiguousarray(coord_img[..., :3][mask])).to(dev)
+    coord_masked = coord_norm_masked * obj_.scale + torch.from_numpy(np.asarray(obj_.offset)).to(dev)
+    coord_nerf = torch.from_numpy((coord_masked.cpu().numpy() * 1.8 / obj_.diameter).astype("float32")).to(dev)
+    feat = neural_radiance_field.batched_customForward(coord_nerf).detach().clone()
+    keys_masked = feat[..., :feat.shape[-1] - 1]                                   # drop the silhouette channel
+    keys_verts = _dev(keys_verts, torch.float32)
+    perm = torch.randperm(len(keys_verts), device=dev, generator=generator)[:n_samples_denom]
+    denom_img = denominator_image(query_img, keys_verts[perm])
+    obj = RefineObjective(coord_masked.float(), keys_masked.float(), query_img, denom_img, K_crop, R)
+    pose = np.array([0, 0, 0, t[0], t[1], t[2]], dtype=np.float64)
+    result = minimize(fun=obj, x0=pose, jac=lambda p: obj(p, return_grad=True), method=method)
+    return R, result.x[3:], result.fun

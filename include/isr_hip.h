@@ -185,6 +185,18 @@ int isr_zbuf_score(const float* obj_pts, int m, const float* Rt, int B, const do
                    float* pose_score, float* mask_score, float* coord_score, void* ws, size_t ws_bytes,
                    isr_stream_t stream);
 
+/* a16  refine_pose objective   pose_refine.py:58-91
+ * out4 (device, 4 f64) = { score, d score / d t (3) } with
+ *   score = -( mean_i <keys_i, bilinear(query_img, p_i)> - mean_i bilinear(denom_img, p_i) ) / 2,
+ *   p_i = pixel of X_i under Kcrop [R|t]; bilinear sampling as F.grid_sample(align_corners=False,
+ *   padding_mode='border') on (p + 0.5) * 2 / res - 1.  X (N,3) object coordinates, keys (N,e),
+ *   query_img (res,res,e), denom_img (res,res) all f32; Kcrop (9) and Rt (12, [R|t]) HOST doubles.
+ *   The reference's rotation is constant inside the objective (pose_refine.py:73-76), so only the
+ *   translation gradient exists.  ws >= 64*5*8 + 256 bytes. */
+int isr_refine_objective(const float* X, const float* keys, int N, int e, const float* query_img,
+                         const float* denom_img, int res, const double* Kcrop, const double* Rt,
+                         double* out4, void* ws, size_t ws_bytes, isr_stream_t stream);
+
 /* a8  ADD(verts, gtR, gtT, R, T)   inference.py:116-117
  * mean_out[b] = mean_v || Ta[b] v - Tb[b] v ||  (f64; Ta/Tb (B,12) f64 [R|t], NULL = identity). */
 int isr_add_metric(const float* verts, int V, const double* Ta, const double* Tb, int B,

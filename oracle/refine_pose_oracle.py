@@ -1,0 +1,40 @@
+"""TEST INFRASTRUCTURE, NOT PRODUCT — the objective of refine_pose (pose_refine.py:58-91) as the
+reference writes it: torch F.grid_sample + autograd on the CPU (pinned: these are the reference's
+own torch calls; cv2.Rodrigues is replaced by passing R directly — the reference feeds it a constant
+rvec, so only t is differentiated there too)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def sample(img, p_img_norm, interpolation="bilinear"):
+    samples = F.grid_sample(img.permute(2, 0, 1)[None], p_img_norm[None, None], align_corners=False,
+                            padding_mode="border", mode=interpolation)
+    return samples[0, :, 0].T
+
+
+def objective(t, R, coord_masked, keys_masked, query_img, denom_img, K_crop, return_grad=False):
+    """pose_refine.py:70-91 with pose[3:] = t.  All tensors torch-CPU f32."""
+    res = query_img.shape[0]
+    tt = torch.tensor(np.asarray(t, np.float64), dtype=torch.float32, requires_grad=return_grad)
+    Rt = torch.cat((torch.from_numpy(np.asarray(R, np.float64)).float(), tt[:, None]), dim=1)
+    P = torch.from_numpy(np.asarray(K_crop, np.float64)).float() @ Rt
+    X = torch.cat((coord_masked, torch.ones(len(coord_masked), 1)), dim=1).float()
+    p_img = X @ P.T
+    p_img = p_img[..., :2] / p_img[..., 2:]
+    p_norm = (p_img + 0.5) * (2 / res) - 1
+    q = sample(query_img, p_norm)
+    log_nom = (keys_masked * q).sum(dim=-1)
+    log_den = sample(denom_img, p_norm)[:, 0]
+    score = -(log_nom.mean() - log_den.mean()) / 2
+    if return_grad:
+        score.backward()
+        return score.item(), tt.grad.detach().numpy().astype(np.float64)
+    return score.item()
+
+
+def denominator_image(query_img, keys_sampled):
+    """pose_refine.py:56."""
+    return torch.logsumexp(query_img @ keys_sampled.T, dim=-1, keepdim=True)
