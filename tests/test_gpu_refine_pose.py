@@ -91,9 +91,14 @@ def test_objective_value_and_gradient(cuda0):
         assert abs(v - rv) < 2e-5 * max(1.0, abs(rv))
         assert np.all(g[:3] == 0)
         np.testing.assert_allclose(g[3:], rg, rtol=2e-3, atol=2e-6)       # autograd runs in f32
-    # far off the crop: everything clamps to the border, gradient vanishes
-    far = np.concatenate([np.zeros(3), s["t"] + np.array([4000.0, 0, 0])])
-    assert np.allclose(obj(far, return_grad=True), 0.0)
+    # far off the crop in x: samples clamp to the right border (padding_mode='border'), the x part of
+    # the gradient vanishes, the y part still follows the border column — as autograd says
+    tf = s["t"] + np.array([4000.0, 0, 0])
+    far = np.concatenate([np.zeros(3), tf])
+    gf = obj(far, return_grad=True)
+    _, rgf = ro.objective(tf, s["R"], coord, keys_masked, s["query"], denom, s["K"], return_grad=True)
+    assert gf[3] == 0 and abs(rgf[0]) < 1e-9
+    np.testing.assert_allclose(gf[4:], rgf[1:], rtol=5e-3, atol=2e-6)
 
 
 def test_refine_pose_recovers_translation(cuda0):
