@@ -191,7 +191,8 @@ def main():
         poses, status = sequence.stack_poses(res)
         poses_all = shard.allgather_rows(poses, n_total)
         best, ch = sequence.pick_by_chamfer(pts, poses_all, R_gt, t_gt, n_total)
-        out = {"picked_pair": best, "pair_chamfer": ch, "registered": int(status.sum().item())}
+        out = {"picked_pair": best, "pair_chamfer": ch, "registered_this_rank": int(status.sum().item()),
+               "images_this_rank": int(status.numel())}
         if rank == 0:
             pose = poses_all[best].reshape(3, 4).cpu().numpy()
             src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)   # icp.py:68

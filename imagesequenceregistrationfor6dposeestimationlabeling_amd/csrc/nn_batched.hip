@@ -23,6 +23,8 @@
 // CPU statement of the same arithmetic.
 #include "isr_common.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 constexpr int kThreads = 256;
@@ -226,7 +228,7 @@ __global__ void nn_reduce_kernel(const double* __restrict__ part_sums, int nblk,
   if (k == 1 && sum_d2) sum_d2[b] = s;
   if (k == 2 && n_in) n_in[b] = (int32_t)s;
   if (k >= 3 && cov) cov[(size_t)b * 16 + (k - 3)] = s;
-  if (k == 3 && cov) cov[(size_t)b * 16 + 15] = 0.0;
+  if (k == 2 && cov) cov[(size_t)b * 16 + 15] = s;  // the count again, so one copy of cov carries everything
 }
 
 
@@ -268,13 +270,17 @@ constexpr size_t kPartBudget = size_t(192) << 20;  // bytes of per-query partial
 NNPlan make_plan(int Nq, int Nt, int B) {
   NNPlan p;
   p.rq = (Nq >= 4 * kThreads) ? 4 : 1;
+  // tuning hook (experiments only): ISR_NN_PLAN="rq,want_blocks"
+  static const char* env = getenv("ISR_NN_PLAN");
+  long want_env = 0;
+  if (env) { int rq = 0; if (sscanf(env, "%d,%ld", &rq, &want_env) >= 1 && (rq == 1 || rq == 4)) p.rq = rq; }
   p.qblocks = (Nq + p.rq * kThreads - 1) / (p.rq * kThreads);
   // 256 CUs x 8 workgroups are resident at once; aim for several such rounds so the last,
   // partly filled round is a small share of the launch (ISR_NN_WANT_BLOCKS: tuning hook)
 #ifndef ISR_NN_WANT_BLOCKS
 #define ISR_NN_WANT_BLOCKS 8192
 #endif
-  const long want = ISR_NN_WANT_BLOCKS;
+  const long want = want_env > 0 ? want_env : ISR_NN_WANT_BLOCKS;
   long ns = (want + (long)p.qblocks * B - 1) / ((long)p.qblocks * B);
   const int max_split = (Nt + kTile - 1) / kTile;
   if (ns < 1) ns = 1;

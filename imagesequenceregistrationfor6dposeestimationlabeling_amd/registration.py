@@ -220,12 +220,24 @@ def choose_best(chamferdis):
 
 # ------------------------------------------------------------------------------ a14 / a15 ICP
 def _eval(src, tgt, threshold, T):
-    r = ops.nn_batched(src, tgt, _dev(np.asarray(T, np.float64)[:3, :].reshape(1, 12)), None,
-                       radius=float(threshold), want_cov=True)
-    n = int(r.n_in.item())
-    cov = r.cov.cpu().numpy()[0]
-    fitness = n / src.shape[0]
-    rmse = float(np.sqrt(r.sum_d2.item() / n)) if n else 0.0
+    """One NN(radius) pass of source under T against target; ONE device->host copy brings back
+    {sum d, sum d^2} and the 16 Kabsch sums (slot 15 = inlier count)."""
+    dev = src.device
+    Tq = torch.from_numpy(np.ascontiguousarray(np.asarray(T, np.float64)[:3, :].reshape(1, 12))).to(dev)
+    buf = torch.empty(18, dtype=torch.float64, device=dev)       # [sum_d, sum_d2, cov(16)]
+    Nq, Nt = src.shape[0], tgt.shape[0]
+    L = ops.lib()
+    ws = ops.workspace(dev, L.isr_nn_batched_workspace_bytes(Nq, Nt, 1), "nn")
+    base = buf.data_ptr()
+    with torch.cuda.device(dev):
+        rc = L.isr_nn_batched(ops.ptr(src), Nq, ops.ptr(tgt), Nt, ops.ptr(Tq), None, 1, float(threshold), base, base + 8,
+                              None, None, None, base + 16, ops.ptr(ws), ws.numel(), ops.current_stream(dev))
+    ops.check(rc, "isr_nn_batched")
+    h = buf.cpu().numpy()
+    cov = h[2:]
+    n = int(cov[15])
+    fitness = n / Nq
+    rmse = float(np.sqrt(h[1] / n)) if n else 0.0
     return fitness, rmse, n, cov
 
 

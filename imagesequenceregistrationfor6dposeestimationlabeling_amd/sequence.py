@@ -152,6 +152,12 @@ def stack_poses(results: list[ImageResult]) -> tuple[torch.Tensor, torch.Tensor]
             torch.cat([r.status for r in results]))
 
 
+def _orthonormal(R, tol=1e-9) -> bool:
+    """R2 inv(R1) = R2 R1^T exactly when R1 is orthonormal (then np.linalg.inv and the transpose agree
+    to rounding); scene_gt rotations with few printed digits fall back to the general inverse."""
+    return bool(np.all(np.abs(np.einsum("nij,nkj->nik", R, R) - np.eye(3)) < tol))
+
+
 def pick_by_chamfer(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.ndarray, t_gt_all: np.ndarray,
                     n_total: int) -> tuple[int, float]:
     """verfication.py:61-108 sharded: this rank evaluates the consecutive pairs it owns, then one
@@ -162,8 +168,11 @@ def pick_by_chamfer(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.nda
     best = (None, 0)
     if hi > lo:
         Rp = poses_all.reshape(-1, 3, 4)[lo:hi + 1, :, :3].cpu().numpy()
-        Rrel = np.stack([registration.calculate_relative_pose(R_gt_all[i], t_gt_all[i], R_gt_all[i + 1],
-                                                              t_gt_all[i + 1])[0] for i in range(lo, hi)])
+        # rotation block of [R2|T2] inv([R1|T1]) (verfication.py:9-19) for every owned pair at once
+        Rg = np.asarray(R_gt_all, np.float64)
+        Rrel = np.einsum("nij,nkj->nik", Rg[lo + 1:hi + 1], Rg[lo:hi]) if _orthonormal(Rg[lo:hi]) else np.stack(
+            [registration.calculate_relative_pose(R_gt_all[i], t_gt_all[i], R_gt_all[i + 1], t_gt_all[i + 1])[0]
+             for i in range(lo, hi)])
         ch = registration.chamfer_pairs(pc1, Rp, Rrel)
         i, v = registration.choose_best(ch)
         best = (float(np.float32(v)), lo + i)

@@ -138,7 +138,7 @@ int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int
  *   sum_d[b]  = sum of d over counted queries (f64)      n_in[b] = number counted
  *   sum_d2[b] = sum of d^2
  *   nn_idx[b*Nq+q] (-1 if not counted), nn_d[b*Nq+q] (f64 distance of the nearest target)
- *   cov[b*16 + ..] = { sum q'(3), sum t'(3), sum q' t'^T (9, row-major), unused } over counted
+ *   cov[b*16 + ..] = { sum q'(3), sum t'(3), sum q' t'^T (9, row-major), count } over counted
  *                     pairs — the Kabsch inputs of one point-to-point ICP step.
  * Reductions use fixed-shape trees (no float atomics): results are run-to-run reproducible.
  */
