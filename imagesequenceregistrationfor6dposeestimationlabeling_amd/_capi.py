@@ -63,6 +63,8 @@ SIGNATURES = {
     "isr_zbuf_score": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_refine_objective": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_add_metric": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp]),
+    "isr_icp_workspace_bytes": (_sz, [_i, _i]),
+    "isr_icp_point_to_point": (_i, [_vp, _i, _vp, _i, _d, _i, _d, _d, _vp, _vp, _vp, _sz, _vp]),
     "isr_rel_pose_table": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 

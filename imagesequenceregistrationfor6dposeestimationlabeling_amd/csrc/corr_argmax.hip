@@ -33,7 +33,6 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kQB = 2;                       // 32-query blocks per wave (f32 kernel)
-constexpr int kQPerBlock = kWaves * kQB * 32;  // 256 queries per workgroup (f32 kernel)
 #ifndef ISR_BF16_QB
 #define ISR_BF16_QB 2
 #endif

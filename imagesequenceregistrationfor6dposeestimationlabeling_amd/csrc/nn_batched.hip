@@ -48,8 +48,9 @@ template <int RQ>
 __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     const float* __restrict__ qry, int Nq, const float* __restrict__ tgt, int Nt,
     const double* __restrict__ Tq, const double* __restrict__ Tt, int split_len, int nsplit,
-    float* __restrict__ part_d2, int32_t* __restrict__ part_idx) {
+    float* __restrict__ part_d2, int32_t* __restrict__ part_idx, const int32_t* __restrict__ skip) {
   __shared__ __attribute__((aligned(16))) float lds[2][3][kTile];
+  if (skip && *skip) return;  // device-side ICP loop: converged, later iterations are no-ops
 
   const int tid = threadIdx.x;
   const int b = blockIdx.z;
@@ -152,8 +153,10 @@ __global__ __launch_bounds__(kThreads) void nn_finalize_kernel(
     const float* __restrict__ qry, int Nq, const float* __restrict__ tgt,
     const double* __restrict__ Tq, const double* __restrict__ Tt, int nsplit, double radius,
     const float* __restrict__ part_d2, const int32_t* __restrict__ part_idx, int b0,
-    int32_t* __restrict__ nn_idx, double* __restrict__ nn_d, double* __restrict__ part_sums) {
+    int32_t* __restrict__ nn_idx, double* __restrict__ nn_d, double* __restrict__ part_sums,
+    const int32_t* __restrict__ skip) {
   __shared__ double red[kThreads / 64][kNV];
+  if (skip && *skip) return;
   const int tid = threadIdx.x;
   const int bl = blockIdx.y;  // batch item inside this chunk
   const int b = b0 + bl;
@@ -256,6 +259,110 @@ __global__ __launch_bounds__(kThreads) void add_metric_kernel(const float* __res
   if (threadIdx.x == 0) out[b] = (((red[0] + red[1]) + red[2]) + red[3]) / (double)V;
 }
 
+
+// ------------------------------------------------------------------------------- K4 ICP loop
+// registration_icp(source, target, threshold, init, PointToPoint) of icp.py:101-103, enqueued as
+// max_iter + 1 evaluation passes with NO host round trip: after each pass one thread reduces the
+// block sums, applies Open3D's stopping rule (|d fitness| < rel_fitness and |d rmse| < rel_rmse, or
+// the iteration budget) and, if it continues, composes T <- dT T where dT is the rigid fit of the
+// matched pairs (Horn's closed form: largest eigenvector of the 4x4 quaternion matrix by cyclic
+// Jacobi — always a proper rotation, equal to the SVD/Kabsch solution).  A device flag turns the
+// remaining launches into no-ops once the rule fires.
+struct IcpState {
+  double prev_fit, prev_rmse;
+  int32_t iter, done;
+};
+
+__device__ void jacobi4_largest(double A[4][4], double q[4]) {
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 4; ++p)
+      for (int r = p + 1; r < 4; ++r) off += A[p][r] * A[p][r];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int r = p + 1; r < 4; ++r) {
+        if (A[p][r] == 0.0) continue;
+        const double theta = (A[r][r] - A[p][p]) / (2.0 * A[p][r]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < 4; ++k) {  // A <- A J
+          const double akp = A[k][p], akr = A[k][r];
+          A[k][p] = c * akp - sn * akr;
+          A[k][r] = sn * akp + c * akr;
+        }
+        for (int k = 0; k < 4; ++k) {  // A <- J^T A
+          const double apk = A[p][k], ark = A[r][k];
+          A[p][k] = c * apk - sn * ark;
+          A[r][k] = sn * apk + c * ark;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double vkp = V[k][p], vkr = V[k][r];
+          V[k][p] = c * vkp - sn * vkr;
+          V[k][r] = sn * vkp + c * vkr;
+        }
+      }
+  }
+  int best = 0;
+  for (int k = 1; k < 4; ++k)
+    if (A[k][k] > A[best][best]) best = k;
+  for (int k = 0; k < 4; ++k) q[k] = V[k][best];
+}
+
+__global__ void icp_update_kernel(const double* __restrict__ part_sums, int nblk, int Ns, int max_iter,
+                                  double rel_fitness, double rel_rmse, double* __restrict__ T,
+                                  IcpState* __restrict__ st, double* __restrict__ result) {
+  __shared__ double v[kNV];
+  if (st->done) return;
+  if (threadIdx.x < kNV) {
+    double s = 0.0;
+    for (int i = 0; i < nblk; ++i) s += part_sums[(size_t)i * kNV + threadIdx.x];
+    v[threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  const double n = v[2];
+  const double fit = n / (double)Ns;
+  const double rmse = n > 0 ? sqrt(v[1] / n) : 0.0;
+  const int it = st->iter;
+  result[0] = fit; result[1] = rmse; result[2] = (double)it; result[3] = n;
+  const bool conv = it > 0 && fabs(st->prev_fit - fit) < rel_fitness && fabs(st->prev_rmse - rmse) < rel_rmse;
+  if (conv || it >= max_iter || n < 3) { st->done = 1; return; }
+  st->prev_fit = fit; st->prev_rmse = rmse; st->iter = it + 1;
+  // rigid fit of the matched pairs: S = sum (q - mq)(t - mt)^T
+  double mq[3], mt[3], S[3][3];
+  for (int a = 0; a < 3; ++a) { mq[a] = v[3 + a] / n; mt[a] = v[6 + a] / n; }
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) S[a][b] = v[9 + 3 * a + b] - n * mq[a] * mt[b];
+  double N4[4][4] = {
+      {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+      {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+      {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+      {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
+  double q[4];
+  jacobi4_largest(N4, q);
+  const double nq = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] * nq, x = q[1] * nq, y = q[2] * nq, z = q[3] * nq;
+  const double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                          {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                          {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+  double U[3][4];
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) U[a][b] = R[a][b];
+    U[a][3] = mt[a] - (R[a][0] * mq[0] + R[a][1] * mq[1] + R[a][2] * mq[2]);
+  }
+  double Tn[12];
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 4; ++b)
+      Tn[4 * a + b] = U[a][0] * T[b] + U[a][1] * T[4 + b] + U[a][2] * T[8 + b] + (b == 3 ? U[a][3] : 0.0);
+  for (int k = 0; k < 12; ++k) T[k] = Tn[k];
+}
+
+__global__ void icp_init_kernel(IcpState* st, double* T) {
+  st->prev_fit = 0; st->prev_rmse = 0; st->iter = 0; st->done = 0;
+  T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
 struct NNPlan {
   int rq;          // queries per lane
   int qblocks;     // search grid.x
@@ -337,20 +444,20 @@ extern "C" int isr_nn_batched(const float* qry, int Nq, const float* tgt, int Nt
     const dim3 grid(p.qblocks, p.nsplit, nb);
     if (p.rq == 4)
       nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len,
-                                                         p.nsplit, part_d2, part_idx);
+                                                         p.nsplit, part_d2, part_idx, nullptr);
     else
       nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len,
-                                                         p.nsplit, part_d2, part_idx);
+                                                         p.nsplit, part_d2, part_idx, nullptr);
     ISR_CHECK_LAUNCH("nn_search_kernel");
     const dim3 fgrid(p.fblocks, nb);
     if (cov)
       nn_finalize_kernel<true><<<fgrid, kThreads, 0, stream>>>(qry, Nq, tgt, Tq, Tt, p.nsplit,
                                                                radius, part_d2, part_idx, b0,
-                                                               nn_idx, nn_d, part_sums);
+                                                               nn_idx, nn_d, part_sums, nullptr);
     else
       nn_finalize_kernel<false><<<fgrid, kThreads, 0, stream>>>(qry, Nq, tgt, Tq, Tt, p.nsplit,
                                                                 radius, part_d2, part_idx, b0,
-                                                                nn_idx, nn_d, part_sums);
+                                                                nn_idx, nn_d, part_sums, nullptr);
     ISR_CHECK_LAUNCH("nn_finalize_kernel");
   }
   if (sum_d || sum_d2 || n_in || cov) {
@@ -368,5 +475,43 @@ extern "C" int isr_add_metric(const float* verts, int V, const double* Ta, const
   ISR_REQUIRE(V > 0 && B > 0, "isr_add_metric: V=%d B=%d", V, B);
   add_metric_kernel<<<B, kThreads, 0, isr::as_stream(stream)>>>(verts, V, Ta, Tb, mean_out);
   ISR_CHECK_LAUNCH("add_metric_kernel");
+  return ISR_OK;
+}
+
+extern "C" size_t isr_icp_workspace_bytes(int Ns, int Nt) {
+  if (Ns <= 0 || Nt <= 0) return 0;
+  return isr_nn_batched_workspace_bytes(Ns, Nt, 1) + 1024;
+}
+
+extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt, int Nt, double threshold,
+                                      int max_iter, double rel_fitness, double rel_rmse, double* T_io,
+                                      double* result, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(src && tgt && T_io && result, "isr_icp_point_to_point: null pointer");
+  ISR_REQUIRE(Ns > 0 && Nt > 0 && max_iter >= 0 && threshold > 0, "isr_icp_point_to_point: Ns=%d Nt=%d max_iter=%d", Ns, Nt, max_iter);
+  if (!ws || ws_bytes < isr_icp_workspace_bytes(Ns, Nt)) {
+    isr::set_error("isr_icp_point_to_point: workspace %zu < %zu", ws_bytes, isr_icp_workspace_bytes(Ns, Nt));
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  const NNPlan p = make_plan(Ns, Nt, 1);
+  isr::Workspace w(ws, ws_bytes);
+  float* part_d2 = w.take<float>((size_t)p.nsplit * Ns);
+  int32_t* part_idx = w.take<int32_t>((size_t)p.nsplit * Ns);
+  double* part_sums = w.take<double>((size_t)p.fblocks * kNV);
+  IcpState* st = w.take<IcpState>(1);
+  icp_init_kernel<<<1, 1, 0, stream>>>(st, T_io);
+  const dim3 grid(p.qblocks, p.nsplit, 1), fgrid(p.fblocks, 1);
+  for (int it = 0; it <= max_iter; ++it) {
+    if (p.rq == 4)
+      nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
+                                                         part_d2, part_idx, &st->done);
+    else
+      nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
+                                                         part_d2, part_idx, &st->done);
+    nn_finalize_kernel<true><<<fgrid, kThreads, 0, stream>>>(src, Ns, tgt, T_io, nullptr, p.nsplit, threshold, part_d2,
+                                                             part_idx, 0, nullptr, nullptr, part_sums, &st->done);
+    icp_update_kernel<<<1, 64, 0, stream>>>(part_sums, p.fblocks, Ns, max_iter, rel_fitness, rel_rmse, T_io, st, result);
+  }
+  ISR_CHECK_LAUNCH("icp kernels");
   return ISR_OK;
 }

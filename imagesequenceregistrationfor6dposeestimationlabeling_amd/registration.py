@@ -250,37 +250,28 @@ def evaluate_registration(source, target, threshold, init=None):
     return f, r
 
 
-def _kabsch_from_sums(n, cov):
-    """Rigid update from the fused sums {sum q, sum t, sum q t^T}: Umeyama without scale."""
-    mq, mt = cov[0:3] / n, cov[3:6] / n
-    H = cov[6:15].reshape(3, 3) - n * np.outer(mq, mt)      # sum (q-mq)(t-mt)^T
-    U, _, Vt = np.linalg.svd(H)
-    d = np.sign(np.linalg.det(Vt.T @ U.T))
-    R = Vt.T @ np.diag([1.0, 1.0, d]) @ U.T
-    upd = np.eye(4)
-    upd[:3, :3] = R
-    upd[:3, 3] = mt - R @ mq
-    return upd
-
-
 def icp_point_to_point(source, target, threshold, init=None, max_iter=30, rel_fitness=1e-6,
                        rel_rmse=1e-6):
     """icp.py:101-103 open3d registration_icp(source, target, threshold, init,
     TransformationEstimationPointToPoint()) with the library defaults (30 iterations, relative
-    fitness / rmse 1e-6).  Each iteration: one fused NN(radius)+covariance kernel pass, then the
-    3x3 SVD on the host.  Returns (T (4,4) f64, fitness, inlier_rmse)."""
-    src, tgt = _dev(source, torch.float32), _dev(target, torch.float32)
-    T = np.eye(4) if init is None else np.asarray(init, np.float64).copy()
-    fit, rmse, n, cov = _eval(src, tgt, threshold, T)
-    for _ in range(max_iter):
-        if n < 3:
-            break
-        T = _kabsch_from_sums(n, cov) @ T
-        pf, pr = fit, rmse
-        fit, rmse, n, cov = _eval(src, tgt, threshold, T)
-        if abs(pf - fit) < rel_fitness and abs(pr - rmse) < rel_rmse:
-            break
-    return T, fit, rmse
+    fitness / rmse 1e-6).  The loop — NN(radius) + Kabsch sums, stopping rule, rigid update — runs
+    on the device without host round trips (isr_icp_point_to_point); one copy brings back T and
+    the final (fitness, inlier_rmse).  Returns (T (4,4) f64, fitness, inlier_rmse)."""
+    src, tgt = _dev(source, torch.float32).contiguous(), _dev(target, torch.float32).contiguous()
+    dev = src.device
+    T0 = np.eye(4) if init is None else np.asarray(init, np.float64)
+    buf = torch.empty(20, dtype=torch.float64, device=dev)        # T (16) | result (4)
+    buf[:16] = torch.from_numpy(np.ascontiguousarray(T0.reshape(16))).to(dev)
+    L = ops.lib()
+    ws = ops.workspace(dev, L.isr_icp_workspace_bytes(src.shape[0], tgt.shape[0]), "icp")
+    base = buf.data_ptr()
+    with torch.cuda.device(dev):
+        rc = L.isr_icp_point_to_point(ops.ptr(src), src.shape[0], ops.ptr(tgt), tgt.shape[0], float(threshold),
+                                      int(max_iter), float(rel_fitness), float(rel_rmse), base, base + 128,
+                                      ops.ptr(ws), ws.numel(), ops.current_stream(dev))
+    ops.check(rc, "isr_icp_point_to_point")
+    h = buf.cpu().numpy()
+    return h[:16].reshape(4, 4).copy(), float(h[16]), float(h[17])
 
 
 def final_chamfer(source, target, T, cad_points):

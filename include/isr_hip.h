@@ -202,6 +202,17 @@ int isr_refine_objective(const float* X, const float* keys, int N, int e, const 
 int isr_add_metric(const float* verts, int V, const double* Ta, const double* Tb, int B,
                    double* mean_out, isr_stream_t stream);
 
+/* a14  registration_icp(source, target, threshold, init, PointToPoint)   icp.py:101-103
+ * The whole loop on the device, no host round trip: up to max_iter + 1 evaluation passes (K3 with
+ * radius + Kabsch sums), after each the stopping rule |d fitness| < rel_fitness and |d rmse| <
+ * rel_rmse (Open3D defaults 1e-6, 30 iterations) and the rigid update T <- dT T (Horn's closed form).
+ * T_io: device, 16 f64 row-major 4x4 (init in, result out; the bottom row is rewritten as 0 0 0 1).
+ * result: device, 4 f64 = { fitness, inlier_rmse, iterations done, correspondences }. */
+size_t isr_icp_workspace_bytes(int Ns, int Nt);
+int isr_icp_point_to_point(const float* src, int Ns, const float* tgt, int Nt, double threshold,
+                           int max_iter, double rel_fitness, double rel_rmse, double* T_io,
+                           double* result, void* ws, size_t ws_bytes, isr_stream_t stream);
+
 /* a10 / a12  relative-pose tables, rows [i0, i1) of the n x n table, written as (i1-i0, n, 12) f64.
  * mode 0: compute_rel_poses       choosePose.py:43-51  ->  [R_i^T R_j | t_j - t_i]
  * mode 1: calculate_relative_pose verfication.py:9-19  ->  [R_j|t_j] * inv([R_i|t_i])
