@@ -232,8 +232,9 @@ def main():
         k1 = flop / max(calls, 1) / (k1_ms * 1e-3) if calls else 0.0
         traffic = None
         pmc = ROOT / "profiles" / "k1_hbm_traffic.json"
-        if pmc.exists():
-            traffic = json.loads(pmc.read_text()).get("hbm_bytes_per_launch")
+        if pmc.exists() and (P, N, D) == (307200, 20000, 64):   # measured for this configuration only
+            rec = json.loads(pmc.read_text()).get("per_launch", {}).get(str(max(args.group, 1)))
+            traffic = rec["hbm_bytes"] if rec else None
         ncalls, nms, pairs = timing.get("nn_batched", (0, 0.0, 0.0))
         line = {
             "metric": "registered images/sec (T-LESS obj 1-like, synthetic) + final Chamfer error",
