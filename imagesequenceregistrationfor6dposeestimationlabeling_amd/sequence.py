@@ -178,3 +178,27 @@ def pick_by_chamfer(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.nda
         best = (float(np.float32(v)), lo + i)
     val, idx = shard.allreduce_min_pair(best[0], best[1])
     return idx, val
+
+
+def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, top: int = 50):
+    """choosePose.py:79-151 sharded by rows: every rank holds all n predicted and GT
+    poses, builds rows block_range(n, rank, world) of the two relative-pose tables on the device
+    (compute_rel_poses, choosePose.py:43-51), evaluates its rows of
+        error[i][j] = ADDS(modelVerts, gt_rel[i][j], pred_rel[i][j]) < 0.1 * diameter
+    with the batched NN kernel, and all-gathers the int32 row sums; argmax / top-50 are then computed
+    identically on every rank (ties -> lower index).  Returns (image_id, top indices, local error rows)."""
+    rank, size = shard.world()
+    n = len(R_gt)
+    lo, hi = shard.block_range(n, rank, size)
+    gt_rel = registration.relative_pose_table(R_gt, t_gt, "choose", rows=(lo, hi)) if hi > lo else np.zeros((0, n, 4, 4))
+    pr_rel = registration.relative_pose_table(R_pred, t_pred, "choose", rows=(lo, hi)) if hi > lo else np.zeros((0, n, 4, 4))
+    if hi > lo:
+        err, _ = registration.vote_error_rows(model_verts, surface_pts, gt_rel, pr_rel, diameter)
+    else:
+        err = np.zeros((0, n))
+    sums_local = torch.from_numpy(err.sum(axis=1).astype(np.int32))[:, None]
+    if size > 1:
+        sums_local = sums_local.to(shard._coll_device())
+    sums = shard.allgather_rows(sums_local, n)[:, 0].cpu().numpy().astype(np.float64)
+    image_id = int(np.argmax(sums))
+    return image_id, np.argsort(-sums, kind="stable")[:top], err

@@ -58,3 +58,23 @@ def test_pick_by_chamfer_matches_reference_loop(cuda0):
     Rrel = np.array([ro.calculate_relative_pose(R[i], t[i], R[i + 1], t[i + 1])[0] for i in range(len(imgs) - 1)])
     ch = ro.chamfer_pairs(pts.astype(np.float64), Rp, Rrel)
     assert idx == int(np.argmin(ch)) and abs(val - ch.min()) < 1e-4
+
+
+def test_vote_choose_image_matches_reference_double_loop(cuda0):
+    """sequence.vote_choose_image (world size 1) = choosePose.py:98-151 in the oracle."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence
+    from oracle import registration_oracle as ro
+    rng = np.random.default_rng(12)
+    S = synth.bumpy_ellipsoid(rng, 1500)
+    V = synth.bumpy_ellipsoid(rng, 600)
+    diam = synth.diameter(S)
+    n = 7
+    Rg, tg = synth.random_poses(rng, n)
+    P = [synth.perturb_pose(rng, Rg[i], tg[i], 3.0 if i not in (2, 5) else 50.0, 2.0) for i in range(n)]
+    Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
+    img, top, err = sequence.vote_choose_image(V, S, Rg, tg, Rp, tp, diam)
+    rerr, _ = ro.vote(V.astype(np.float64), S.astype(np.float64), ro.rel_pose_table(Rg, tg), ro.rel_pose_table(Rp, tp), diam)
+    assert np.array_equal(err, rerr)
+    sums = rerr.sum(1)
+    assert img == int(np.argmax(sums)) and img not in (2, 5)
+    assert list(top) == list(np.argsort(-sums, kind="stable")[:50])

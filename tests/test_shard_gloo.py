@@ -72,3 +72,29 @@ def test_world2_gather_and_min_reduce(n):
         for r in range(size):
             v, i = ret[r]
             assert i == int(np.argmin(ch)) and v == float(ch.min())
+
+
+def _vote_worker(rank, size, port, n, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size))
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        # the row-sum exchange of sequence.vote_choose_image, with the device part replaced by a table
+        err = (np.arange(n)[:, None] * 7 + np.arange(n)[None] * 3) % 5 < 2
+        lo, hi = shard.block_range(n, rank, size)
+        local = torch.from_numpy(err[lo:hi].sum(1).astype(np.int32))[:, None]
+        sums = shard.allgather_rows(local, n)[:, 0].numpy()
+        ret[rank] = (int(np.argmax(sums)), np.argsort(-sums.astype(np.float64), kind="stable")[:5].tolist(), sums.tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_vote_row_sums():
+    size, port, n = 2, _free_port(), 11
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_vote_worker, args=(size, port, n, ret), nprocs=size, join=True)
+        err = (np.arange(n)[:, None] * 7 + np.arange(n)[None] * 3) % 5 < 2
+        sums = err.sum(1)
+        for r in range(size):
+            assert ret[r][2] == sums.tolist() and ret[r][0] == int(np.argmax(sums))
+        assert ret[0] == ret[1]
