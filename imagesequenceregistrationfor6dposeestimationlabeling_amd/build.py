@@ -35,6 +35,13 @@ HIPCC_FLAGS = [
     "-Wno-unused-function",
 ]
 
+# Per-source additions.  corr_argmax.hip: NaN-free logits are a precondition of the path (finite
+# descriptors), and without the flag every fmaxf on a raw MFMA result costs an extra
+# `v_max_f32 x, x, x` (sNaN quieting) in a loop that is bound by VALU issue.
+EXTRA_FLAGS = {
+    "corr_argmax.hip": ["-fno-honor-nans"],
+}
+
 
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
@@ -66,7 +73,7 @@ def build_hip(force: bool = False, verbose: bool = False, jobs: int = 4) -> Path
         src, obj = pair
         if not (force or _stale(obj, [src] + headers)):
             return None
-        cmd = [hipcc, *HIPCC_FLAGS, "-c", str(src), "-o", str(obj)]
+        cmd = [hipcc, *HIPCC_FLAGS, *EXTRA_FLAGS.get(src.name, []), "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

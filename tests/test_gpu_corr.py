@@ -151,3 +151,67 @@ def test_corr_bf16_log2_extreme_logits(cuda0, oracle_lib):
     assert np.array_equal(idx.cpu().numpy(), o["idx"])
     np.testing.assert_allclose(logp.cpu().numpy(), o["maxlogit"] - o["lse"], atol=1e-4)
     np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=3e-6, atol=1e-3)
+
+
+def _check_log2(ops, oracle_lib, cuda0, Q, K, atol=3e-5, exact=False):
+    qb, kb = ops.prescale_queries_log2(torch.from_numpy(Q)), torch.from_numpy(K).bfloat16()
+    idx, logp, lse = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0), want_lse=True, log2_prescaled=True)
+    torch.cuda.synchronize()
+    o = oracle_lib.corr_argmax_bf16(_bits(qb), _bits(kb), logit_scale=np.log(2.0))
+    got = idx.cpu().numpy()
+    bad = np.nonzero(got != o["idx"])[0]
+    if exact:
+        assert len(bad) == 0
+    margin = o["maxlogit"] - o["top2"]
+    noise = 2e-5 * np.maximum(1.0, np.abs(o["maxlogit"]))
+    assert (margin[bad] <= noise[bad]).all(), f"{len(bad)} mismatches, margins {margin[bad][:5]}"
+    assert len(bad) <= max(1, len(got) // 500)
+    scale = np.maximum(1.0, np.abs(o["lse"]))
+    assert np.max(np.abs(logp.cpu().numpy() - (o["maxlogit"] - o["lse"]))) <= atol
+    assert np.max(np.abs(lse.cpu().numpy() - o["lse"]) / scale) <= atol
+    return o
+
+
+def test_corr_bf16_log2_reference_bumps(cuda0, oracle_lib):
+    """Direct-sum kernel: logits that keep growing along the key scan make the wave's reference S
+    move several times (each bump rescales l by an exact power of two); maxima end near +400 log2
+    units, far outside what an unreferenced f32 sum could hold."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(21)
+    P, N, D = 700, 6000, 64
+    base = rng.normal(0, 1, (N, D))
+    base /= np.linalg.norm(base, axis=1, keepdims=True)
+    K = (base * (2.0 + 14.0 * np.arange(N)[:, None] / N)).astype(np.float32)     # |k| grows 2 -> 16
+    gt = rng.integers(N, size=P)
+    Q = (18.0 * base[gt] + 0.5 * rng.normal(0, 1, (P, D))).astype(np.float32)
+    o = _check_log2(ops, oracle_lib, cuda0, Q, K, atol=4e-5)
+    assert o["maxlogit"].max() * np.log2(np.e) > 250.0
+
+
+def test_corr_bf16_log2_mixed_fallback(cuda0, oracle_lib):
+    """Neighbouring queries whose maxima are hundreds of log2 units apart cannot share one wave
+    reference: those workgroups raise their flag and are redone by the per-query-reference kernel,
+    the others keep the direct result.  Also: very negative logits, and one huge late key (a jump
+    past the overflow guard inside one stage)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(22)
+    P, N, D = 1024, 3000, 64
+    Q, K, gt = _planted(rng, P, N, D, tau=5.0)
+    Q[256:512:2] *= 0.02            # wave-mates with maxima ~0.5 and ~36 nats: still one reference
+    Q[512:768:2] *= 12.0            # ~430 nats next to ~36: flagged
+    Q[768:] = -Q[768:] - 6.0 * np.sign(K).mean(0)    # everything far below zero
+    K[2900] *= 40.0                 # a late key that dwarfs everything for queries aligned with it
+    Q[100] = K[2900] / 40.0
+    _check_log2(ops, oracle_lib, cuda0, Q, K, atol=2e-4)     # logits of +-600 log2 units: f32 ulp 6e-5
+
+
+def test_corr_bf16_log2_ties_lowest_key(cuda0, oracle_lib):
+    """Duplicate keys: the recorded tile is the first to reach the maximum and the row recovery
+    takes the lowest register, so the lowest key index wins exactly as in the oracle."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(23)
+    P, N, D = 300, 1500, 32
+    Q, K, gt = _planted(rng, P, N, D, tau=5.0)
+    K[700:1400] = K[:700]           # every key of the first 700 appears again 700 rows later
+    o = _check_log2(ops, oracle_lib, cuda0, Q, K, exact=True)
+    assert (o["idx"] < 700).mean() > 0.8 and not ((o["idx"] >= 700) & (o["idx"] < 1400)).any()

@@ -13,7 +13,9 @@ gt = torch.randint(N, (P,), device=dev, generator=g)
 Q = K[gt] + 0.35 * torch.randn(P, D, device=dev, generator=g)
 Kb = K.bfloat16()
 cases = [("planted bf16", Q.bfloat16(), False), ("planted bf16-log2", ops.prescale_queries_log2(Q), True),
-         ("random bf16", torch.randn(P, D, device=dev, generator=g).bfloat16(), False)]
+         ("random bf16", torch.randn(P, D, device=dev, generator=g).bfloat16(), False),
+         ("random bf16-log2", ops.prescale_queries_log2(torch.randn(P, D, device=dev, generator=g)), True),
+         ("planted(0.6x) bf16-log2", ops.prescale_queries_log2(0.6 * Q), True)]
 for name, q, l2 in cases:
     idx, logp = ops.corr_argmax(q, Kb, log2_prescaled=l2)
     torch.cuda.synchronize()
