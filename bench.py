@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the images are pipelined over")
     ap.add_argument("--group", type=int, default=16, help="images per K1 launch (1 = one launch per image)")
     ap.add_argument("--refine-iters", type=int, default=6, help="Gauss-Newton refit iterations after RANSAC")
+    ap.add_argument("--k1", choices=("log2", "natural"), default="log2",
+                    help="log2: descriptors multiplied by log2(e) before their one rounding to bf16 "
+                         "(ISR_DTYPE_BF16_LOG2, the direct-sum kernel); natural: plain bf16 (ISR_DTYPE_BF16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg")
     return ap.parse_args()
@@ -80,15 +83,17 @@ def make_model(dev, N, D):
     return keys_f32, torch.from_numpy(pts).to(dev), upper, lower, cad
 
 
-def make_image(dev, keys_f32, pts, Kcam, R, t, P, seed):
+def make_image(dev, keys_f32, pts, Kcam, R, t, P, seed, log2_domain=True):
     """Device-side twin of synth.image_case (same recipe, torch RNG): planted descriptors with
-    30 % wrong matches, pixel = projection of the true point + 0.5 px noise."""
+    30 % wrong matches, pixel = projection of the true point + 0.5 px noise.  log2_domain: the f32
+    descriptors are multiplied by log2(e) BEFORE the one rounding to bf16 (ISR_DTYPE_BF16_LOG2)."""
     N = keys_f32.shape[0]
     g = torch.Generator(device=dev).manual_seed(1000 + seed)
     gt_geo = torch.randint(N, (P,), device=dev, generator=g)
     out = torch.rand(P, device=dev, generator=g) < 0.3
     gt_match = torch.where(out, torch.randint(N, (P,), device=dev, generator=g), gt_geo)
-    Q = (keys_f32[gt_match] + 0.35 * torch.randn(P, keys_f32.shape[1], device=dev, generator=g)).bfloat16()
+    Q = keys_f32[gt_match] + 0.35 * torch.randn(P, keys_f32.shape[1], device=dev, generator=g)
+    Q = ops.prescale_queries_log2(Q) if log2_domain else Q.bfloat16()
     Rt = torch.from_numpy(np.concatenate([R, t[:, None]], 1)).to(dev)
     Xc = pts[gt_geo].double() @ Rt[:, :3].T + Rt[:, 3]
     p = Xc @ torch.from_numpy(Kcam).to(dev).T
@@ -104,7 +109,7 @@ def cpu_baseline(args, keys_bf16, pts, Q0, pix0, Kcam, upper, lower, cad, R_gt, 
     torch.set_num_threads(cores)
     P, N = Q0.shape[0], keys_bf16.shape[0]
     Ps = min(P, 16384)
-    q = Q0[:Ps].float().cpu()
+    q = Q0[:Ps].float().cpu() / (ops.LOG2E if args.k1 == "log2" else 1.0)
     k = keys_bf16.float().cpu()
     t0 = time.perf_counter()
     idx, vals = ro.getCors_chunked(q, k, chunk=4096)
@@ -168,7 +173,7 @@ def main():
     Kcam = synth.camera(args.width, args.height)
     keys_f32, pts, upper, lower, cad = make_model(dev, N, D)
     keys = keys_f32.bfloat16().contiguous()
-    model = sequence.SequenceModel(keys=keys, pts=pts)
+    model = sequence.SequenceModel(keys=keys, pts=pts, log2_queries=args.k1 == "log2")
     rng = np.random.default_rng(99)
     R_gt, t_gt = synth.random_poses(rng, n_total)          # every rank knows every GT pose (scene_gt.json)
     lo, hi = shard.block_range(n_total, rank, world)
@@ -176,7 +181,7 @@ def main():
     Q_all = torch.empty((n_local, P, D), dtype=torch.bfloat16, device=dev)
     pix_all = torch.empty((n_local, P, 2), dtype=torch.float32, device=dev)
     for j, i in enumerate(range(lo, hi)):
-        Q_all[j], pix_all[j] = make_image(dev, keys_f32, pts, Kcam, R_gt[i], t_gt[i], P, i)
+        Q_all[j], pix_all[j] = make_image(dev, keys_f32, pts, Kcam, R_gt[i], t_gt[i], P, i, args.k1 == "log2")
     images = [(Q_all[j], pix_all[j]) for j in range(n_local)]
     torch.cuda.synchronize()
 
@@ -248,7 +253,9 @@ def main():
                        "images_per_gpu": n_local, "P": P, "N": N, "D": D, "hypotheses": args.itr,
                        "parallelism": f"image-sharded x{world}"},
             "final_chamfer": last.get("final_chamfer"), "last_step": last,
-            "roofline": {"kernel": "corr_bf16_kernel (K1 getCors: MFMA GEMM + online LSE + argmax)",
+            "roofline": {"kernel": ("corr_bf16_direct_kernel" if args.k1 == "log2" else "corr_bf16_kernel")
+                                   + " (K1 getCors: MFMA GEMM + online LSE + argmax)",
+                         "k1_domain": args.k1,
                          "bound": "mfma", "achieved": k1 * 1e-12, "peak": PEAK_BF16_MFMA * 1e-12,
                          "unit": "TFLOP/s", "frac": k1 / PEAK_BF16_MFMA, "traffic": traffic,
                          "ms_per_launch": k1_ms, "launches": calls,

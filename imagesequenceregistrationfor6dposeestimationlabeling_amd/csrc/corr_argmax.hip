@@ -21,6 +21,9 @@
 //
 // dtype bf16: v_mfma_f32_32x32x16_bf16.  dtype f32: v_mfma_f32_32x32x2_f32, which is bit for bit
 // a k-ordered fmaf chain — oracle/isr_oracle.c:orc_corr_argmax_f32 reproduces its logits exactly.
+// dtype bf16-log2 (queries prescaled by log2 e): corr_bf16_direct_kernel, the VALU-minimal loop
+// (wave-uniform reference in the MFMA C operand, record-only arg-max, post-loop row recovery),
+// with corr_bf16_kernel<.., LOG2> as its flagged per-workgroup fallback.
 #include "isr_common.hpp"
 
 #include <type_traits>
@@ -489,7 +492,8 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   constexpr int NCH = 2 * DK;
   constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;
   constexpr int CHUNKS = kTK * NCH;
-  constexpr int NLD = (CHUNKS + kThreads - 1) / kThreads;
+  constexpr int NLD = CHUNKS / kThreads;
+  static_assert(CHUNKS % kThreads == 0, "every thread stages the same number of chunks");
   __shared__ uint4 lds[2][CHUNKS];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -513,18 +517,25 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   const int k0 = split * split_len;
   const int k1 = min(N, k0 + split_len);
   const int nstage = (k1 - k0 + kTK - 1) / kTK;
+  const int nfull = (k1 - k0) / kTK;                  // stages whose kTK keys all exist
 
+  // Key rows come through a raw buffer descriptor over this key range: one 32-bit offset per load,
+  // and rows beyond the range read as zero in hardware (no predicates in the loop).
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint16_t*>(K + (size_t)k0 * ldk), 0, (k1 - k0) * ldk * 2, 0x00020000);
+  int koff[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int ci = tid + i * kThreads;
+    koff[i] = ((ci / NCH) * ldk + 8 * (ci % NCH)) * 2;
+  }
   uint4 stg[NLD];
   auto gload = [&](int stage) {
+    const int so = stage * kTK * ldk * 2;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
-      const int ci = tid + i * kThreads;
-      const int row = ci / NCH, c = ci % NCH;
-      const int key = k0 + stage * kTK + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ci < CHUNKS && key < k1)
-        v = *reinterpret_cast<const uint4*>(K + (size_t)key * ldk + 8 * c);
-      stg[i] = v;
+      const auto v = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[i] + so, 0, 0);
+      stg[i] = *reinterpret_cast<const uint4*>(&v);
     }
   };
   auto lwrite = [&](int buf) {
@@ -532,7 +543,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     for (int i = 0; i < NLD; ++i) {
       const int ci = tid + i * kThreads;
       const int row = ci / NCH, c = ci % NCH;
-      if (ci < CHUNKS) lds[buf][row * NCH + (c ^ ((row / RPB) & (NCH - 1)))] = stg[i];
+      lds[buf][row * NCH + (c ^ ((row / RPB) & (NCH - 1)))] = stg[i];
     }
   };
   // A fragments of key sub-tile `sub` of LDS buffer `buf`.  One register set: a fragment's ds_read
@@ -633,7 +644,6 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       for (int i = 0; i < 16; ++i) acc[0][i] -= d;
     }
   };
-  const int nfull = (k1 - k0) / kTK;
   for (int stage = 0; stage < nfull; ++stage) stage_body(stage, std::true_type{});
   if (nfull < nstage) stage_body(nfull, std::false_type{});
 
@@ -924,6 +934,9 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
                 "isr_corr_argmax(bf16): D=%d must be 16, 32, 64 or 128 (zero-pad the columns)", D);
     ISR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0),
                 "isr_corr_argmax(bf16): rows must be 16-byte aligned (ldq=%d ldk=%d)", ldq, ldk);
+    ISR_REQUIRE(dtype != ISR_DTYPE_BF16_LOG2 || (long long)p.split_len * ldk * 2 < (1ll << 31),
+                "isr_corr_argmax(bf16 log2): a key range of %d rows x ldk=%d exceeds the 2 GiB buffer window",
+                p.split_len, ldk);
     const uint16_t* q = static_cast<const uint16_t*>(Q);
     const uint16_t* k = static_cast<const uint16_t*>(K);
 #define ISR_LAUNCH_BF16(DKv, QBv)                                                                         \

@@ -21,7 +21,10 @@ for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "corr_" not in k: continue
-        k = "corr_finalize" if "finalize" in k else k.split("(")[0][-40:]
+        if "finalize" in k: k = "corr_finalize"
+        elif "direct" in k: k = "corr_bf16_direct_kernel"
+        elif "corr_bf16_kernel" in k: k = "corr_bf16_kernel(fallback, log2)" if ("true" in k or "Lb1" in k) else "corr_bf16_kernel"
+        else: k = k.split("(")[0][-40:]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as g:
     for k, d in agg.items():

@@ -12,8 +12,11 @@ out = sys.argv[1]
 agg = collections.defaultdict(list)
 for f in glob.glob(out + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "corr_bf16_kernel" in r["Kernel_Name"] and "Lb1" not in r["Kernel_Name"] and "true" not in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for c, v in sorted(agg.items()):
-    print(f"{c:16s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+        k = r["Kernel_Name"]
+        if "corr_bf16_direct_kernel" in k: name = "direct"
+        elif "corr_bf16_kernel" in k and "Lb1" not in k and "true" not in k: name = "natural"
+        else: continue
+        agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (name, c), v in sorted(agg.items()):
+    print(f"{name:8s} {c:16s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
 PY

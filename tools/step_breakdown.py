@@ -10,7 +10,7 @@ dev = torch.device("cuda:0")
 P, N, D = 640 * 480, 20000, 64
 Kcam = synth.camera(640, 480)
 keys_f32, pts, upper, lower, cad = bench.make_model(dev, N, D)
-model = sequence.SequenceModel(keys=keys_f32.bfloat16().contiguous(), pts=pts)
+model = sequence.SequenceModel(keys=keys_f32.bfloat16().contiguous(), pts=pts, log2_queries=True)
 rng = np.random.default_rng(99)
 n = 64
 R_gt, t_gt = synth.random_poses(rng, n)
