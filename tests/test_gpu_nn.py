@@ -79,6 +79,73 @@ def test_nn_large_batch_vote_shape(cuda0, oracle_lib):
     np.testing.assert_allclose(g["sum_d"][sel], o["sum_d"], rtol=1e-12)
 
 
+def _both_paths(cuda0, q, t, Tq, Tt, radius):
+    """The same call through the uniform-grid search and through brute force (ISR_NN_GRID forces the
+    path; unset = size heuristic): everything must agree bit for bit."""
+    import os
+    out = {}
+    try:
+        for flag in ("1", "0"):
+            os.environ["ISR_NN_GRID"] = flag
+            out[flag] = _run(cuda0, q, t, Tq, Tt, radius)
+    finally:
+        os.environ.pop("ISR_NN_GRID", None)
+    g, b = out["1"], out["0"]
+    for k in ("nn_idx", "nn_d", "n_in", "sum_d", "sum_d2", "cov"):
+        assert np.array_equal(g[k], b[k]), k
+    return g
+
+
+def _surface(rng, n):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import synth
+    return np.ascontiguousarray(synth.tless_like(rng, n), np.float32)
+
+
+@pytest.mark.parametrize("radius", [-1.0, 4.0])
+def test_nn_grid_chamfer_pairs(cuda0, oracle_lib, radius):
+    """The pick's shape: one surface cloud under B pairs of nearby poses (verfication.py:61-102)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import synth
+    rng = np.random.default_rng(31)
+    pc = _surface(rng, 6000)
+    B = 8
+    Ta = _poses(rng, B)
+    Tb = Ta.copy()
+    for i in range(B):
+        R, t = synth.perturb_pose(rng, Ta[i, :, :3], Ta[i, :, 3], 3.0, 2.0)
+        Tb[i, :, :3], Tb[i, :, 3] = R, t
+    g = _both_paths(cuda0, pc, pc, Ta, Tb, radius)
+    _compare(g, oracle_lib.nn_batched(pc, pc, Ta, Tb, radius))
+
+
+def test_nn_grid_far_nonrigid_and_degenerate(cuda0, oracle_lib):
+    """Queries far outside the grid (brute-force pass), a target transform that is not rigid (item
+    goes to the brute-force pass), lattice ties with duplicated targets, and targets on a line."""
+    rng = np.random.default_rng(32)
+    pc = _surface(rng, 3000)
+    B = 4
+    Ta, Tb = _poses(rng, B), _poses(rng, B)
+    Ta[1, :, 3] += np.array([900.0, -400.0, 300.0])            # item 1: every query is far away
+    Tb[2, :, :3] *= 1.3                                         # item 2: scaled target
+    g = _both_paths(cuda0, pc[:2000], pc, Ta, Tb, -1.0)
+    _compare(g, oracle_lib.nn_batched(pc[:2000], pc, Ta, Tb, -1.0))
+
+    base = rng.integers(-6, 7, (1500, 3)).astype(np.float32)
+    t = np.concatenate([base, base])
+    q = rng.integers(-8, 9, (4200, 3)).astype(np.float32)
+    g = _both_paths(cuda0, q, t, None, None, -1.0)
+    _compare(g, oracle_lib.nn_batched(q, t))
+    assert (g["nn_idx"] < 1500).all()
+
+    line = np.zeros((2500, 3), np.float32)
+    line[:, 0] = np.linspace(-50, 50, 2500)
+    q = rng.normal(0, 30, (4100, 3)).astype(np.float32)
+    g = _both_paths(cuda0, q, line, None, None, 10.0)
+    _compare(g, oracle_lib.nn_batched(q, line, None, None, 10.0))
+    same = np.tile(np.array([[1.0, 2.0, 3.0]], np.float32), (2100, 1))
+    g = _both_paths(cuda0, q, same, None, None, -1.0)
+    assert (g["nn_idx"] == 0).all()
+
+
 def test_nn_rejects_cpu_tensors(hip_lib):
     from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
     from imagesequenceregistrationfor6dposeestimationlabeling_amd._capi import IsrError

@@ -1,20 +1,36 @@
-"""NN kernel timing: python tools/time_nn.py  (Chamfer-pair shape, ICP shape, vote shape)."""
-import sys
+"""NN timing: python tools/time_nn.py  (Chamfer-pair, ICP, vote and ADD-S shapes; uniform-grid search
+vs brute force; "near" = target pose a 3 deg / 2 mm perturbation of the query pose, "random" =
+independent random orientations)."""
+import os, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
 from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, synth
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
-def poses(B):
-    R, t = synth.random_poses(rng, B)
-    return torch.from_numpy(np.concatenate([R, t[:, :, None]], 2)).to(dev)
+def poses(B, near=None):
+    if near is None:
+        R, t = synth.random_poses(rng, B)
+    else:
+        R, t = np.empty((B, 3, 3)), np.empty((B, 3))
+        for i in range(B):
+            R[i], t[i] = synth.perturb_pose(rng, near[i, :, :3], near[i, :, 3], 3.0, 2.0)
+    return np.concatenate([R, t[:, :, None]], 2)
 for name, Nq, Nt, B in (("chamfer pairs", 20000, 20000, 63), ("icp step", 20000, 20000, 1), ("vote rows", 5000, 20000, 4096), ("adds", 5000, 20000, 1)):
-    q = torch.from_numpy(synth.tless_like(rng, Nq)).to(dev); t = torch.from_numpy(synth.tless_like(rng, Nt)).to(dev)
-    Tq, Tt = poses(B), poses(B)
-    ops.nn_batched(q, t, Tq, Tt); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5): ops.nn_batched(q, t, Tq, Tt, want_cov=(B == 1))
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
-    print(f"{name:14s} Nq={Nq} Nt={Nt} B={B}: {ms:.3f} ms  {Nq*Nt*B/ms*1e-9:.2f} Tpairs/s  {8*Nq*Nt*B/ms*1e-9/157.3*100:.1f}% of 157 TF (8 flop/pair)")
+    cloud = synth.tless_like(rng, max(Nq, Nt))
+    q = torch.from_numpy(np.ascontiguousarray(cloud[:Nq])).to(dev); t = torch.from_numpy(np.ascontiguousarray(cloud[:Nt])).to(dev)
+    Ta = poses(B)
+    for kind, Tb in (("near", poses(B, Ta)), ("random", poses(B))):
+        Tq, Tt = torch.from_numpy(Ta).to(dev), torch.from_numpy(Tb).to(dev)
+        res = {}
+        for path in ("1", "0"):
+            os.environ["ISR_NN_GRID"] = path
+            r = ops.nn_batched(q, t, Tq, Tt); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): r = ops.nn_batched(q, t, Tq, Tt, want_cov=(B == 1))
+            e1.record(); torch.cuda.synchronize()
+            res[path] = (e0.elapsed_time(e1) / 5, r.sum_d.cpu().numpy())
+        assert np.array_equal(res["1"][1], res["0"][1])
+        print(f"{name:14s} {kind:6s} Nq={Nq} Nt={Nt} B={B}: grid {res['1'][0]:8.3f} ms | brute {res['0'][0]:8.3f} ms "
+              f"({Nq*Nt*B/res['0'][0]*1e-9:.2f} Tpairs/s)  speed-up {res['0'][0]/res['1'][0]:.1f}x")
+os.environ.pop("ISR_NN_GRID", None)
