@@ -309,8 +309,9 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && !LOG2) ? ISR_BF16_WAVES : 1) 
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
     int32_t* __restrict__ pbi, const int32_t* __restrict__ flags) {
-  // LOG2: this kernel is the fallback of corr_bf16_direct_kernel; only flagged workgroups run.
-  if (LOG2 && flags && flags[blockIdx.y * gridDim.x + blockIdx.x] == 0) return;
+  // flags != nullptr: this kernel runs as the fallback of corr_bf16_direct_kernel — only the
+  // workgroups that kernel flagged do any work.
+  if (flags && flags[blockIdx.y * gridDim.x + blockIdx.x] == 0) return;
   constexpr int NCH = 2 * DK;                         // 16-byte chunks per key row
   constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;     // key rows per 256-byte LDS bank row
   constexpr int CHUNKS = kTK * NCH;                   // chunks per stage
@@ -484,7 +485,13 @@ __device__ __forceinline__ float tile_max_with(const f32x16& acc, float m) {
   return max3(max3(x0, x1, x2), max3(x3, x4, acc[15]), m);
 }
 
-template <int DK, int QB>
+// NAT = false: log2-unit logits (ISR_DTYPE_BF16_LOG2), reference in the MFMA C operand.
+// NAT = true:  natural-unit logits (ISR_DTYPE_BF16): the accumulator stays raw (C = 0) and the
+//   wave-uniform integer reference S (log2 units) enters through the one-rounding
+//   exp2(fma(s, log2 e, -S)) — one more VALU instruction per element than the log2 path, still
+//   without the per-query reference, its rescale branch and the in-loop arg-max update of
+//   corr_bf16_kernel.  The running maximum is then the raw logit itself.
+template <int DK, int QB, bool NAT>
 __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
@@ -575,12 +582,17 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   for (int s = 0; s < DK; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[0][s], acc[0], 0, 0, 0);
 
   // reference from the first tile (rows >= k1 of a short range are zero rows: logit 0, harmless here)
-  float S = ceilf(wave_max(tile_max_with(acc[0], -__builtin_inff()))) - kAnchor;
+  constexpr float kUnit = NAT ? kLog2e : 1.0f;         // log2 units per logit unit
+  float S = ceilf(wave_max(tile_max_with(acc[0], -__builtin_inff())) * kUnit) - kAnchor;
   S = fminf(fmaxf(S, -3.0e38f), 3.0e38f);
-  f32x16 cS = splat16(-S);
-  asm volatile("" : "+v"(cS));          // one resident tile, not sixteen moves per chain
+  f32x16 cS = splat16(NAT ? 0.f : -S);
+  if (!NAT) {
+    asm volatile("" : "+v"(cS));        // one resident tile, not sixteen moves per chain
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[0][i] -= S;
+    for (int i = 0; i < 16; ++i) acc[0][i] -= S;
+  }
+  float nS = -S;                        // NAT: the addend of the exp2 argument
+  float bump_at = NAT ? (S + kBump) * 0.6931471805599453f : kBump;   // running maximum that moves S
 
   auto stage_body = [&](int stage, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
@@ -600,7 +612,8 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], kb + 4 * h, k1);
         const f32x16& cur = acc[w & 1];
         f32x16& nxt = acc[(w + 1) & 1];
-        nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[qbn][0], cS, 0, 0, 0);
+        if (NAT) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[qbn][0], splat16(0.f), 0, 0, 0);
+        else nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[qbn][0], cS, 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < DK; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qbn][s], nxt, 0, 0, 0);
         if (qb == 0) {                                    // the chain above was the fragments' last reader
@@ -612,14 +625,15 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         st[qb].m = mn;
         float l = st[qb].l;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) l += __builtin_amdgcn_exp2f(cur[i]);
+        for (int i = 0; i < 16; ++i)
+          l += __builtin_amdgcn_exp2f(NAT ? __builtin_fmaf(cur[i], kLog2e, nS) : cur[i]);
         st[qb].l = l;
-        // issue order: the item's 42 VALU instructions (8 max3, 2 record, 16 exp2, 16 add) spread
-        // evenly behind the DK MFMAs of the next item.  The empty asm ties the item's results to a
-        // fixed point of the instruction stream: a stage is one basic block, and without it
-        // instruction selection sinks all eight epilogues below all eight MFMA chains (eight
-        // tiles live, 243 VGPRs, nothing overlapped).
-        constexpr int G = (42 + DK - 1) / DK;
+        // issue order: the item's 42 VALU instructions (8 max3, 2 record, 16 exp2, 16 add; NAT: 16
+        // fma more) spread evenly behind the DK MFMAs of the next item.  The empty asm ties the
+        // item's results to a fixed point of the instruction stream: a stage is one basic block, and
+        // without it instruction selection sinks all eight epilogues below all eight MFMA chains
+        // (eight tiles live, 243 VGPRs, nothing overlapped).
+        constexpr int G = ((NAT ? 58 : 42) + DK - 1) / DK;
 #pragma unroll
         for (int s = 0; s < DK; ++s) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -632,16 +646,24 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     }
     // reference upkeep, once per stage (wave-uniform, rare): acc[0] is the tile in flight
     const float mm = fmaxf(st[0].m, st[1].m);
-    if (__any(mm > kBump)) {
-      const float d = fminf(ceilf(wave_max(mm)) - kAnchor, 3.0e38f);
+    if (__any(mm > bump_at)) {
+      const float top = ceilf(wave_max(mm) * kUnit);      // log2 units; NAT: absolute, else relative to S
+      const float d = fminf(NAT ? top - kAnchor - S : top - kAnchor, 3.0e38f);
       S += d;
-      cS = splat16(-S);
-      asm volatile("" : "+v"(cS));
       const float sc = __builtin_amdgcn_exp2f(-d);
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) { st[qb].m -= d; st[qb].l *= sc; }   // an overflowed l stays inf
+      for (int qb = 0; qb < QB; ++qb) st[qb].l *= sc;     // an overflowed l stays inf
+      if (NAT) {
+        nS = -S;
+        bump_at = (S + kBump) * 0.6931471805599453f;
+      } else {
+        cS = splat16(-S);
+        asm volatile("" : "+v"(cS));
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][i] -= d;
+        for (int qb = 0; qb < QB; ++qb) st[qb].m -= d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] -= d;
+      }
     }
   };
   for (int stage = 0; stage < nfull; ++stage) stage_body(stage, std::true_type{});
@@ -650,7 +672,8 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   // ---- range check: any lane outside the direct-sum range sends the workgroup to the fallback
   bool bad = false;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) bad |= !(st[qb].m >= kLow && st[qb].l <= 3.0e38f);
+  for (int qb = 0; qb < QB; ++qb)
+    bad |= !((NAT ? __builtin_fmaf(st[qb].m, kLog2e, -S) : st[qb].m) >= kLow && st[qb].l <= 3.0e38f);
   const int any_bad = __syncthreads_or(bad ? 1 : 0);
   if (tid == 0) flags[blockIdx.y * gridDim.x + blockIdx.x] = any_bad;
   if (any_bad) return;   // block-uniform; the fallback kernel writes this workgroup's partials
@@ -881,12 +904,15 @@ int slots_for(int dtype, int D) {
   int& c = cache[dtype == ISR_DTYPE_F32 ? 1 : dtype == ISR_DTYPE_BF16_LOG2 ? 2 : 0][v];
   if (c == 0) {
     if (dtype == ISR_DTYPE_BF16_LOG2) {
-      c = v == 0 ? resident_slots(corr_bf16_direct_kernel<1, kQBbf16>)
-        : v == 1 ? resident_slots(corr_bf16_direct_kernel<2, kQBbf16>)
-        : v == 2 ? resident_slots(corr_bf16_direct_kernel<4, kQBbf16>) : resident_slots(corr_bf16_direct_kernel<8, 2>);
+      c = v == 0 ? resident_slots(corr_bf16_direct_kernel<1, kQBbf16, false>)
+        : v == 1 ? resident_slots(corr_bf16_direct_kernel<2, kQBbf16, false>)
+        : v == 2 ? resident_slots(corr_bf16_direct_kernel<4, kQBbf16, false>)
+                 : resident_slots(corr_bf16_direct_kernel<8, 2, false>);
     } else if (dtype != ISR_DTYPE_F32) {
-      c = v == 0 ? resident_slots(corr_bf16_kernel<1, kQBbf16>) : v == 1 ? resident_slots(corr_bf16_kernel<2, kQBbf16>)
-        : v == 2 ? resident_slots(corr_bf16_kernel<4, kQBbf16>) : resident_slots(corr_bf16_kernel<8, 2>);
+      c = v == 0 ? resident_slots(corr_bf16_direct_kernel<1, kQBbf16, true>)
+        : v == 1 ? resident_slots(corr_bf16_direct_kernel<2, kQBbf16, true>)
+        : v == 2 ? resident_slots(corr_bf16_direct_kernel<4, kQBbf16, true>)
+                 : resident_slots(corr_bf16_direct_kernel<8, 2, true>);
     } else {
       c = v == 0 ? resident_slots(corr_f32_kernel<8>) : v == 1 ? resident_slots(corr_f32_kernel<16>)
         : v == 2 ? resident_slots(corr_f32_kernel<32>) : resident_slots(corr_f32_kernel<64>);
@@ -934,21 +960,23 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
                 "isr_corr_argmax(bf16): D=%d must be 16, 32, 64 or 128 (zero-pad the columns)", D);
     ISR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0),
                 "isr_corr_argmax(bf16): rows must be 16-byte aligned (ldq=%d ldk=%d)", ldq, ldk);
-    ISR_REQUIRE(dtype != ISR_DTYPE_BF16_LOG2 || (long long)p.split_len * ldk * 2 < (1ll << 31),
-                "isr_corr_argmax(bf16 log2): a key range of %d rows x ldk=%d exceeds the 2 GiB buffer window",
+    ISR_REQUIRE((long long)p.split_len * ldk * 2 < (1ll << 31),
+                "isr_corr_argmax(bf16): a key range of %d rows x ldk=%d exceeds the 2 GiB buffer window",
                 p.split_len, ldk);
     const uint16_t* q = static_cast<const uint16_t*>(Q);
     const uint16_t* k = static_cast<const uint16_t*>(K);
 #define ISR_LAUNCH_BF16(DKv, QBv)                                                                         \
   do {                                                                                                    \
     if (dtype == ISR_DTYPE_BF16_LOG2) {                                                                   \
-      corr_bf16_direct_kernel<DKv, QBv><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, \
-                                                                       pm, pM2, pl, pbi, flags);           \
+      corr_bf16_direct_kernel<DKv, QBv, false><<<grid, kThreads, 0, stream>>>(                            \
+          q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi, flags);                                    \
       corr_bf16_kernel<DKv, QBv, true><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, \
                                                                       pm, pM2, pl, pbi, flags);            \
     } else {                                                                                              \
+      corr_bf16_direct_kernel<DKv, QBv, true><<<grid, kThreads, 0, stream>>>(                             \
+          q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi, flags);                                    \
       corr_bf16_kernel<DKv, QBv, false><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, \
-                                                                       pm, pM2, pl, pbi, nullptr);         \
+                                                                       pm, pM2, pl, pbi, flags);           \
     }                                                                                                     \
   } while (0)
     switch (D) {

@@ -153,11 +153,14 @@ def test_corr_bf16_log2_extreme_logits(cuda0, oracle_lib):
     np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=3e-6, atol=1e-3)
 
 
-def _check_log2(ops, oracle_lib, cuda0, Q, K, atol=3e-5, exact=False):
-    qb, kb = ops.prescale_queries_log2(torch.from_numpy(Q)), torch.from_numpy(K).bfloat16()
-    idx, logp, lse = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0), want_lse=True, log2_prescaled=True)
+def _check_log2(ops, oracle_lib, cuda0, Q, K, atol=3e-5, exact=False, log2=True):
+    """log2=True: ISR_DTYPE_BF16_LOG2 (queries prescaled); False: plain bf16 (natural units) —
+    both run corr_bf16_direct_kernel, with corr_bf16_kernel as the flagged fallback."""
+    qb = ops.prescale_queries_log2(torch.from_numpy(Q)) if log2 else torch.from_numpy(Q).bfloat16()
+    kb = torch.from_numpy(K).bfloat16()
+    idx, logp, lse = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0), want_lse=True, log2_prescaled=log2)
     torch.cuda.synchronize()
-    o = oracle_lib.corr_argmax_bf16(_bits(qb), _bits(kb), logit_scale=np.log(2.0))
+    o = oracle_lib.corr_argmax_bf16(_bits(qb), _bits(kb), logit_scale=np.log(2.0) if log2 else 1.0)
     got = idx.cpu().numpy()
     bad = np.nonzero(got != o["idx"])[0]
     if exact:
@@ -172,7 +175,8 @@ def _check_log2(ops, oracle_lib, cuda0, Q, K, atol=3e-5, exact=False):
     return o
 
 
-def test_corr_bf16_log2_reference_bumps(cuda0, oracle_lib):
+@pytest.mark.parametrize("log2", [True, False])
+def test_corr_bf16_log2_reference_bumps(cuda0, oracle_lib, log2):
     """Direct-sum kernel: logits that keep growing along the key scan make the wave's reference S
     move several times (each bump rescales l by an exact power of two); maxima end near +400 log2
     units, far outside what an unreferenced f32 sum could hold."""
@@ -184,11 +188,12 @@ def test_corr_bf16_log2_reference_bumps(cuda0, oracle_lib):
     K = (base * (2.0 + 14.0 * np.arange(N)[:, None] / N)).astype(np.float32)     # |k| grows 2 -> 16
     gt = rng.integers(N, size=P)
     Q = (18.0 * base[gt] + 0.5 * rng.normal(0, 1, (P, D))).astype(np.float32)
-    o = _check_log2(ops, oracle_lib, cuda0, Q, K, atol=4e-5)
+    o = _check_log2(ops, oracle_lib, cuda0, Q, K, atol=4e-5, log2=log2)
     assert o["maxlogit"].max() * np.log2(np.e) > 250.0
 
 
-def test_corr_bf16_log2_mixed_fallback(cuda0, oracle_lib):
+@pytest.mark.parametrize("log2", [True, False])
+def test_corr_bf16_log2_mixed_fallback(cuda0, oracle_lib, log2):
     """Neighbouring queries whose maxima are hundreds of log2 units apart cannot share one wave
     reference: those workgroups raise their flag and are redone by the per-query-reference kernel,
     the others keep the direct result.  Also: very negative logits, and one huge late key (a jump
@@ -202,10 +207,11 @@ def test_corr_bf16_log2_mixed_fallback(cuda0, oracle_lib):
     Q[768:] = -Q[768:] - 6.0 * np.sign(K).mean(0)    # everything far below zero
     K[2900] *= 40.0                 # a late key that dwarfs everything for queries aligned with it
     Q[100] = K[2900] / 40.0
-    _check_log2(ops, oracle_lib, cuda0, Q, K, atol=2e-4)     # logits of +-600 log2 units: f32 ulp 6e-5
+    _check_log2(ops, oracle_lib, cuda0, Q, K, atol=2e-4, log2=log2)     # logits of +-600 log2 units: f32 ulp 6e-5
 
 
-def test_corr_bf16_log2_ties_lowest_key(cuda0, oracle_lib):
+@pytest.mark.parametrize("log2", [True, False])
+def test_corr_bf16_log2_ties_lowest_key(cuda0, oracle_lib, log2):
     """Duplicate keys: the recorded tile is the first to reach the maximum and the row recovery
     takes the lowest register, so the lowest key index wins exactly as in the oracle."""
     from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
@@ -213,5 +219,5 @@ def test_corr_bf16_log2_ties_lowest_key(cuda0, oracle_lib):
     P, N, D = 300, 1500, 32
     Q, K, gt = _planted(rng, P, N, D, tau=5.0)
     K[700:1400] = K[:700]           # every key of the first 700 appears again 700 rows later
-    o = _check_log2(ops, oracle_lib, cuda0, Q, K, exact=True)
+    o = _check_log2(ops, oracle_lib, cuda0, Q, K, exact=True, log2=log2)
     assert (o["idx"] < 700).mean() > 0.8 and not ((o["idx"] >= 700) & (o["idx"] < 1400)).any()
