@@ -289,7 +289,9 @@ __global__ void corr_finalize_l2_kernel(int P, int nsplit, const float* __restri
     else l += ls * exp2(R - Rf);
   }
   const double ln2 = 0.6931471805599453094;
-  const double lp = -(log(l) + (Rf - mw) * ln2);
+  // <= 0 like log_softmax (the sum contains the maximum's own term); rounding of the shifted
+  // logits can leave it a few 1e-6 above
+  const double lp = fmin(0.0, -(log(l) + (Rf - mw) * ln2));
   idx[q] = bi;
   if (logp) logp[q] = (float)lp;
   if (lse) lse[q] = (float)(mw * ln2 - lp);
@@ -845,7 +847,7 @@ __global__ void corr_finalize_kernel(int P, int nsplit, const float* __restrict_
     merge_state(a, b);
   }
   const double ln2 = 0.6931471805599453094;
-  const double lp = -(log((double)a.l) + ((double)a.M2 * ln2 - (double)a.m));
+  const double lp = fmin(0.0, -(log((double)a.l) + ((double)a.M2 * ln2 - (double)a.m)));   // <= 0 like log_softmax
   idx[q] = a.bi;
   if (logp) logp[q] = (float)lp;
   if (lse) lse[q] = (float)((double)a.m - lp);
