@@ -59,7 +59,10 @@ _streams: dict[tuple, list] = {}
 def _stream_pool(dev: torch.device, n: int) -> list:
     key = (dev.index, n)
     if key not in _streams:
-        _streams[key] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        # stream 0 carries K1; the side streams carry the per-image chains of small dependent launches
+        # and get the higher priority: they need a few CUs for microseconds, and every microsecond
+        # they wait for a slot is serial latency (measured: +2 % images/s, K1-high: -4 %)
+        _streams[key] = [torch.cuda.Stream(device=dev, priority=0 if i == 0 else -1) for i in range(n)]
     return _streams[key]
 
 
