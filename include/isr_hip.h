@@ -37,9 +37,10 @@ extern "C" {
 
 #define ISR_DTYPE_BF16 0 /* bf16 inputs, v_mfma_f32_32x32x16_bf16, f32 accumulate */
 #define ISR_DTYPE_F32 1  /* f32 inputs, v_mfma_f32_32x32x2_f32: k-ordered fmaf chain, bit-exact */
-#define ISR_DTYPE_BF16_LOG2 2 /* bf16 inputs whose QUERIES were multiplied by log2(e) before rounding:
-                                logits are in log2 units inside the kernel (no multiply before exp2,
-                                the -M2 reference rides in the contraction); outputs stay natural-log */
+#define ISR_DTYPE_BF16_LOG2 2 /* bf16 inputs whose QUERIES were multiplied by log2(e) before their one
+                                rounding to bf16: logits are in log2 units inside the kernel (no multiply
+                                before exp2, the wave's log-sum-exp reference rides in the MFMA C
+                                operand) — the fastest path; outputs stay natural-log */
 
 typedef void* isr_stream_t; /* hipStream_t */
 
