@@ -684,10 +684,12 @@ NNPlan make_plan(int Nq, int Nt, int B) {
   long want_env = 0;
   if (env) { int rq = 0; if (sscanf(env, "%d,%ld", &rq, &want_env) >= 1 && (rq == 1 || rq == 4)) p.rq = rq; }
   p.qblocks = (Nq + p.rq * kThreads - 1) / (p.rq * kThreads);
-  // 256 CUs x 8 workgroups are resident at once; aim for several such rounds so the last,
-  // partly filled round is a small share of the launch (ISR_NN_WANT_BLOCKS: tuning hook)
+  // 256 CUs x 8 workgroups are resident at once; aim for two such rounds.  More key-range splits
+  // would even out the last round, but every split restarts its running minimum, and while a
+  // minimum is young the wave-uniform update path runs for most groups (tools/nn_plan_sweep.py:
+  // 63 pairs of 20 000^2 points: 3.67 ms at 8192 wanted blocks, 3.18 ms at 4096).
 #ifndef ISR_NN_WANT_BLOCKS
-#define ISR_NN_WANT_BLOCKS 8192
+#define ISR_NN_WANT_BLOCKS 4096
 #endif
   const long want = want_env > 0 ? want_env : ISR_NN_WANT_BLOCKS;
   long ns = (want + (long)p.qblocks * B - 1) / ((long)p.qblocks * B);
