@@ -129,8 +129,9 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
           const float dx = qx[r] - tx[v], dy = qy[r] - ty[v], dz = qz[r] - tz[v];
           d[v] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
         }
-        const float m = fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])),
-                              fminf(fminf(d[4], d[5]), fminf(d[6], d[7])));
+        // three v_min3 + one v_min (min-type ops issue at 0.6x the add rate: keep them few)
+        const float m = fminf(fminf(fminf(d[3], d[4]), d[5]),
+                              fminf(fminf(d[6], d[7]), fminf(fminf(d[0], d[1]), d[2])));
         if (__any(m < best[r])) {  // wave-uniform: rare after the first few tiles
 #pragma unroll
           for (int v = 0; v < kGroup; ++v) {
