@@ -66,6 +66,8 @@ def parse_args():
     ap.add_argument("--k1", choices=("log2", "natural"), default="log2",
                     help="log2: descriptors multiplied by log2(e) before their one rounding to bf16 "
                          "(ISR_DTYPE_BF16_LOG2, the direct-sum kernel); natural: plain bf16 (ISR_DTYPE_BF16)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="finish a step's ICP + final Chamfer before the next step's registration starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg")
     return ap.parse_args()
@@ -185,7 +187,8 @@ def main():
     images = [(Q_all[j], pix_all[j]) for j in range(n_local)]
     torch.cuda.synchronize()
 
-    def step(s: int):
+    def register_and_pick(s: int):
+        """Every rank: its block of images through a1-a5, the pose all-gather, the sharded Chamfer pick."""
         if args.group > 1:
             res = sequence.register_block(model, Q_all, pix_all, Kcam, itr=args.itr, reperr=2.0,
                                           seed0=(s << 20) + lo, refine_iters=args.refine_iters,
@@ -198,15 +201,57 @@ def main():
         best, ch = sequence.pick_by_chamfer(pts, poses_all, R_gt, t_gt, n_total)
         out = {"picked_pair": best, "pair_chamfer": ch, "registered_this_rank": int(status.sum().item()),
                "images_this_rank": int(status.numel())}
-        if rank == 0:
-            pose = poses_all[best].reshape(3, 4).cpu().numpy()
+        pose = poses_all[best].reshape(3, 4).cpu().numpy() if rank == 0 else None
+        return out, pose
+
+    tail_stream = torch.cuda.Stream(device=dev, priority=-1)
+
+    def icp_and_final(out: dict, pose: np.ndarray):
+        """Rank 0: ICP of the picked image's upper half onto the lower half + final Chamfer (a14, a15).
+        Runs on its own stream (and, pipelined, in a worker thread: device and stream are thread-local)."""
+        torch.cuda.set_device(dev)
+        best = out["picked_pair"]
+        with torch.cuda.stream(tail_stream):
             src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)   # icp.py:68
             init = np.linalg.inv(np.vstack([pose, [0, 0, 0, 1]]))                               # icp.py:88-92
             T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init)
-            out.update(final_chamfer=registration.final_chamfer(src, lower, T, cad), icp_fitness=fit,
-                       icp_rmse=rmse, rot_err_rad=synth.rot_angle(pose[:, :3], R_gt[best]),
-                       trans_err_mm=float(np.linalg.norm(pose[:, 3] - t_gt[best])))
+            fc = registration.final_chamfer(src, lower, T, cad)
+        return dict(out, final_chamfer=fc, icp_fitness=fit, icp_rmse=rmse,
+                    rot_err_rad=synth.rot_angle(pose[:, :3], R_gt[best]),
+                    trans_err_mm=float(np.linalg.norm(pose[:, 3] - t_gt[best])))
+
+    def step(s: int):
+        out, pose = register_and_pick(s)
+        if rank == 0:
+            tail_stream.wait_stream(torch.cuda.current_stream(dev))
+            out = icp_and_final(out, pose)
         return out
+
+    def run_steps(first: int, count: int):
+        """`count` steps.  Pipelined (default): the latency-bound ICP tail of batch s (31 small dependent
+        launch triples, a few CUs each) runs in a worker thread on a high-priority stream while the
+        main thread already registers batch s + 1 — batches are independent, all work of every step
+        is finished before this returns.  --no-pipeline runs the steps strictly one after the other."""
+        if args.no_pipeline or count <= 1:
+            last = None
+            for s in range(first, first + count):
+                last = step(s)
+            return last
+        from concurrent.futures import ThreadPoolExecutor
+        last, pending = None, None
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            for s in range(first, first + count):
+                out, pose = register_and_pick(s)
+                if pending is not None:
+                    last = pending.result()
+                if rank == 0:
+                    tail_stream.wait_stream(torch.cuda.current_stream(dev))
+                    pending = pool.submit(icp_and_final, out, pose)
+                else:
+                    last = out
+            if pending is not None:
+                last = pending.result()
+        return last
 
     def barrier():
         torch.cuda.synchronize()
@@ -214,14 +259,11 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        step(s)
+    run_steps(0, args.warmup)
     ops.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
-    last = None
-    for s in range(args.steps):
-        last = step(args.warmup + s)
+    last = run_steps(args.warmup, args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -251,7 +293,9 @@ def main():
                                     f"({args.itr} P3P hypotheses, 2 px); per step consecutive-pair Chamfer pick "
                                     f"(packed min all-reduce), ICP + final Chamfer on rank 0"),
                        "images_per_gpu": n_local, "P": P, "N": N, "D": D, "hypotheses": args.itr,
-                       "parallelism": f"image-sharded x{world}"},
+                       "parallelism": f"image-sharded x{world}",
+                       "step_overlap": ("none" if args.no_pipeline else
+                                        "rank 0's ICP + final Chamfer of batch s overlaps the registration of batch s+1")},
             "final_chamfer": last.get("final_chamfer"), "last_step": last,
             "roofline": {"kernel": ("corr_bf16_direct_kernel" if args.k1 == "log2" else "corr_bf16_kernel")
                                    + " (K1 getCors: MFMA GEMM + online LSE + argmax)",

@@ -27,6 +27,11 @@ KERNEL(k_exp, asm volatile("v_exp_f32 %0, %1" : "=v"(x[i]) : "v"(y[i]));)
 KERNEL(k_cmpsel, asm volatile("v_cmp_gt_f32 vcc, %1, %0\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(y[i]) : "vcc");)
 KERNEL(k_expadd, asm volatile("v_exp_f32 %1, %1\n v_add_f32 %0, %0, %1" : "+v"(x[i]), "+v"(y[i]));)
 KERNEL(k_min3, asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(y[i]), "v"(y[(i + 1) & 7]));)
+KERNEL(k_maxu, asm volatile("v_max_u32 %0, %0, %1" : "+v"(x[i]) : "v"(y[i]));)
+KERNEL(k_max3u, asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(y[i]), "v"(y[(i + 1) & 7]));)
+KERNEL(k_max3i, asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(y[i]), "v"(y[(i + 1) & 7]));)
+KERNEL(k_cmpu, asm volatile("v_cmp_gt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(y[i]) : "vcc");)
+KERNEL(k_med3, asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(y[i]), "v"(y[(i + 1) & 7]));)
 KERNEL(k_pkadd, asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(*(reinterpret_cast<double*>(x) + (i & 3))) : "v"(*(reinterpret_cast<double*>(y) + (i & 3))));)
 
 template <typename K>
@@ -62,5 +67,10 @@ int main() {
   run("cmp+cndmask", k_cmpsel, 2);
   run("exp+add", k_expadd, 2);
   run("v_pk_add_f32", k_pkadd, 1);
+  run("v_max_u32", k_maxu, 1);
+  run("v_max3_u32", k_max3u, 1);
+  run("v_max3_i32", k_max3i, 1);
+  run("cmp_u32+cnd", k_cmpu, 2);
+  run("v_med3_f32", k_med3, 1);
   return 0;
 }
