@@ -66,6 +66,7 @@ def parse_args():
     ap.add_argument("--k1", choices=("log2", "natural"), default="log2",
                     help="log2: descriptors multiplied by log2(e) before their one rounding to bf16 "
                          "(ISR_DTYPE_BF16_LOG2, the direct-sum kernel); natural: plain bf16 (ISR_DTYPE_BF16)")
+    ap.add_argument("--tau", type=float, default=5.0, help="descriptor norm |k| (softmax sharpness), see make_model")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish a step's ICP + final Chamfer before the next step's registration starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -73,12 +74,17 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_model(dev, N, D):
+def make_model(dev, N, D, tau=5.0):
+    """Keys with |k| = tau.  tau sets how peaked the softmax is: at tau = 8 (SURVEY's first suggestion) a
+    planted query beats the log-sum of the other 20 000 keys by > 30 nats, EVERY log-probability is 0
+    to f32 rounding, and the top-80 % cut (strict `>` on exact ties, inference.py:282-290) keeps
+    nothing — in the reference's own torch f32 log_softmax as much as here.  tau = 5 leaves a 10-nat
+    margin: log-probabilities spread over 1e-6 .. 1e-2 and the cut does real work."""
     rng = np.random.default_rng(20240)
     pts = synth.tless_like(rng, N)
     g = torch.Generator(device=dev).manual_seed(777)
     k = torch.randn(N, D, device=dev, generator=g)
-    keys_f32 = 8.0 * k / k.norm(dim=1, keepdim=True)
+    keys_f32 = tau * k / k.norm(dim=1, keepdim=True)
     cloud = synth.tless_like(rng, 4 * N)
     upper, lower = synth.split_halves(rng, cloud, N)
     cad = synth.tless_like(rng, 5000)
@@ -173,7 +179,7 @@ def main():
     P, N, D = args.width * args.height, args.keys, args.dim
     n_local, n_total = args.images, args.images * world
     Kcam = synth.camera(args.width, args.height)
-    keys_f32, pts, upper, lower, cad = make_model(dev, N, D)
+    keys_f32, pts, upper, lower, cad = make_model(dev, N, D, args.tau)
     keys = keys_f32.bfloat16().contiguous()
     model = sequence.SequenceModel(keys=keys, pts=pts, log2_queries=args.k1 == "log2")
     rng = np.random.default_rng(99)
