@@ -16,8 +16,9 @@
 //   M2 = ceil(m * log2 e)  (an integer, so exp2(fma(s, log2e, -M2)) has one rounding and every
 //                           rescale  l *= 2^(M2old - M2new)  is exact)
 //   l  = sum_n 2^(s_n log2e - M2)
-// Cost per 32x32 tile at D = 64: 4 MFMA (~140 cycles) vs 16 x (fma + v_exp_f32 + add) + 8 max3
-// (~230 cycles): the kernel is bound by the transcendental unit, see DESIGN.md.
+// Cost per 32x32 tile at D = 64: 4 MFMA (128 matrix-pipe cycles) against ~310 cycles of VALU issue
+// (16 v_exp_f32 at 8.3, 16 adds at 2.8, 8 v_max3 at 4.6, the MFMAs' own ~18 each): the loop is bound
+// by VALU issue, almost half of it the transcendental unit — DESIGN.md section 4 has the measurements.
 //
 // dtype bf16: v_mfma_f32_32x32x16_bf16.  dtype f32: v_mfma_f32_32x32x2_f32, which is bit for bit
 // a k-ordered fmaf chain — oracle/isr_oracle.c:orc_corr_argmax_f32 reproduces its logits exactly.
