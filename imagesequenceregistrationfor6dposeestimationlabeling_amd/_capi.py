@@ -44,6 +44,9 @@ SIGNATURES = {
     "isr_corr_logsoftmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "isr_select_top_workspace_bytes": (_sz, [_i]),
     "isr_select_top": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_select_top_dev": (_i, [_vp, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_prep_queries_workspace_bytes": (_sz, [_i, _i, _i]),
+    "isr_prep_queries": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "isr_pnp_ransac_workspace_bytes": (_sz, [_i, _i]),
     "isr_p3p_hypotheses": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp]),

@@ -24,6 +24,7 @@ struct SelState {
   uint32_t mask;       // which bits are fixed
   int32_t k;           // remaining rank inside the current bucket
   uint32_t thr_bits;   // float bits of thr once known
+  int32_t n;           // number of elements (<= capacity)
 };
 
 __device__ __forceinline__ uint32_t ordered(float f) {
@@ -41,6 +42,7 @@ __global__ __launch_bounds__(kThreads) void hist_kernel(const float* __restrict_
                                                         int32_t* __restrict__ hist) {
   constexpr int NB = 1 << BITS;
   __shared__ int32_t h[NB];
+  P = st->n;   // the element count: the host's P, or the device-side count (isr_select_top_dev)
   for (int i = threadIdx.x; i < NB; i += kThreads) h[i] = 0;
   __syncthreads();
   const uint32_t prefix = st->prefix, mask = st->mask;
@@ -93,6 +95,10 @@ __global__ void pick_kernel(const int32_t* __restrict__ hist, SelState* __restri
   }
   __syncthreads();
   const int32_t k = st->k;
+  if (LAST && st->n == 0 && t == 0) {               // empty input: keep nothing
+    st->thr_bits = __float_as_uint(__builtin_inff());
+    if (thr_out) *thr_out = __builtin_inff();
+  }
   // the unique bin b with cum[b-1] <= k < cum[b]
   for (int b = t; b < NB; b += 1024) {
     const int32_t lo = b ? cum[b - 1] : 0;
@@ -136,6 +142,7 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const float* __restrict
                                                          const SelState* __restrict__ st,
                                                          int32_t* __restrict__ block_counts) {
   const float thr = __uint_as_float(st->thr_bits);
+  P = st->n;
   const int i0 = blockIdx.x * kChunk + threadIdx.x * kPerThread;
   int c = 0;
 #pragma unroll
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const float* __restri
                                                            const int32_t* __restrict__ block_off,
                                                            int32_t* __restrict__ keep) {
   const float thr = __uint_as_float(st->thr_bits);
+  P = st->n;
   const int i0 = blockIdx.x * kChunk + threadIdx.x * kPerThread;
   bool f[kPerThread];
   int c = 0;
@@ -197,8 +205,31 @@ __global__ __launch_bounds__(kThreads) void scatter_kernel(const float* __restri
     if (f[e]) keep[o++] = i0 + e;
 }
 
-__global__ void init_state_kernel(SelState* st, int32_t k) {
-  st->prefix = 0; st->mask = 0; st->k = k; st->thr_bits = 0;
+// rank into the ascending order, with Python's negative-index semantics (inference.py:282-287):
+//   n > min_n: perc = int(frac n), sorted[-perc + 1];  otherwise sorted[-n + 1]
+__host__ __device__ inline long select_rank(long n, double frac, int min_n) {
+  if (n > min_n) {
+    const long perc = (long)(frac * (double)n);
+    if (perc == 1) return 0;                       // [-1 + 1] = [0]
+    return (perc >= 1) ? n - perc + 1 : 1;         // [-0 + 1] is index 1
+  }
+  return (n >= 2) ? 1 : 0;
+}
+
+// n_dev == nullptr: n = P (checked on the host).  Otherwise n = min(P, *n_dev); n = 0, or a rank the
+// reference would raise IndexError for, selects nothing: thr = +inf.
+__global__ void init_state_kernel(SelState* st, int P, const int32_t* __restrict__ n_dev, double frac, int min_n) {
+  int n = P;
+  if (n_dev) n = min(P, max(0, *n_dev));
+  const long rank = select_rank(n, frac, min_n);
+  st->prefix = 0; st->mask = 0; st->thr_bits = 0;
+  if (n <= 0 || rank < 0 || rank >= n) {
+    st->n = 0;                                     // every later pass sees an empty input
+    st->k = 0;
+  } else {
+    st->n = n;
+    st->k = (int32_t)rank;
+  }
 }
 
 __global__ void gather_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ keep,
@@ -224,21 +255,8 @@ extern "C" size_t isr_select_top_workspace_bytes(int P) {
   return 256 /*state*/ + 3 * isr::align_up(2048 * 4, 256) + isr::align_up(nblocks * 4, 256) + 256;
 }
 
-extern "C" int isr_select_top(const float* logp, int P, double frac, int min_n, int32_t* keep,
-                              int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
-                              isr_stream_t stream_) {
-  ISR_REQUIRE(logp && keep && M_dev, "isr_select_top: null pointer");
-  ISR_REQUIRE(P > 0, "isr_select_top: P=%d (the reference indexes an empty sort and raises)", P);
-  // rank into the ascending order, with Python's negative-index semantics
-  long rank;
-  if (P > min_n) {
-    const long perc = (long)(frac * (double)P);
-    rank = (perc >= 1) ? (long)P - perc + 1 : 1;  // [-0 + 1] is index 1
-    if (perc == 1) rank = 0;
-  } else {
-    rank = (P >= 2) ? 1 : 0;
-  }
-  ISR_REQUIRE(rank >= 0 && rank < P, "isr_select_top: rank %ld out of range for P=%d (IndexError in the reference)", rank, P);
+static int select_top_impl(const float* logp, int P, const int32_t* n_dev, double frac, int min_n, int32_t* keep,
+                           int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes, isr_stream_t stream_) {
   if (!ws || ws_bytes < isr_select_top_workspace_bytes(P)) {
     isr::set_error("isr_select_top: workspace %zu < %zu", ws_bytes, isr_select_top_workspace_bytes(P));
     return ISR_ERR_WORKSPACE;
@@ -253,7 +271,7 @@ extern "C" int isr_select_top(const float* logp, int P, double frac, int min_n, 
   int32_t* bc = w.take<int32_t>(nblocks);
 
   ISR_CHECK_HIP(hipMemsetAsync(h0, 0, (char*)bc - (char*)h0, stream));
-  init_state_kernel<<<1, 1, 0, stream>>>(st, (int32_t)rank);
+  init_state_kernel<<<1, 1, 0, stream>>>(st, P, n_dev, frac, min_n);
   hist_kernel<21, 11><<<nblocks, kThreads, 0, stream>>>(logp, P, st, h0);
   pick_kernel<21, 11, false><<<1, 1024, 0, stream>>>(h0, st, nullptr);
   hist_kernel<10, 11><<<nblocks, kThreads, 0, stream>>>(logp, P, st, h1);
@@ -265,6 +283,24 @@ extern "C" int isr_select_top(const float* logp, int P, double frac, int min_n, 
   scatter_kernel<<<nblocks, kThreads, 0, stream>>>(logp, P, st, bc, keep);
   ISR_CHECK_LAUNCH("select_top kernels");
   return ISR_OK;
+}
+
+extern "C" int isr_select_top(const float* logp, int P, double frac, int min_n, int32_t* keep,
+                              int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
+                              isr_stream_t stream_) {
+  ISR_REQUIRE(logp && keep && M_dev, "isr_select_top: null pointer");
+  ISR_REQUIRE(P > 0, "isr_select_top: P=%d (the reference indexes an empty sort and raises)", P);
+  const long rank = select_rank(P, frac, min_n);
+  ISR_REQUIRE(rank >= 0 && rank < P, "isr_select_top: rank %ld out of range for P=%d (IndexError in the reference)", rank, P);
+  return select_top_impl(logp, P, nullptr, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_);
+}
+
+extern "C" int isr_select_top_dev(const float* logp, int P_cap, const int32_t* n_dev, double frac, int min_n,
+                                  int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
+                                  isr_stream_t stream_) {
+  ISR_REQUIRE(logp && keep && M_dev && n_dev, "isr_select_top_dev: null pointer");
+  ISR_REQUIRE(P_cap > 0, "isr_select_top_dev: P_cap=%d", P_cap);
+  return select_top_impl(logp, P_cap, n_dev, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_);
 }
 
 extern "C" int isr_gather_corr(const int32_t* idx, const int32_t* keep, const int32_t* M_dev, int P,

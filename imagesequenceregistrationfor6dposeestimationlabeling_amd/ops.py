@@ -189,9 +189,10 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     return (idx, logp, lse) if want_lse else (idx, logp)
 
 
-def select_top(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500):
-    """isr_select_top: keep (P,) i32 (first M entries valid, ascending), M_dev (1,) i32, thr (1,) f32."""
-    dev = require_cuda(logp)
+def select_top(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500, n_dev: torch.Tensor | None = None):
+    """isr_select_top: keep (P,) i32 (first M entries valid, ascending), M_dev (1,) i32, thr (1,) f32.
+    n_dev: (1,) i32 on the device — only the first n_dev values are the input (isr_select_top_dev)."""
+    dev = require_cuda(logp, n_dev)
     logp = _f32c(logp).reshape(-1)
     P = logp.numel()
     keep = torch.empty(P, dtype=torch.int32, device=dev)
@@ -200,10 +201,48 @@ def select_top(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500):
     L = lib()
     ws = workspace(dev, L.isr_select_top_workspace_bytes(P), "select")
     with torch.cuda.device(dev), _timed("select_top", 4.0 * P):
-        rc = L.isr_select_top(ptr(logp), P, float(frac), int(min_n), ptr(keep), ptr(M_dev), ptr(thr),
-                              ptr(ws), ws.numel(), current_stream(dev))
+        if n_dev is None:
+            rc = L.isr_select_top(ptr(logp), P, float(frac), int(min_n), ptr(keep), ptr(M_dev), ptr(thr),
+                                  ptr(ws), ws.numel(), current_stream(dev))
+        else:
+            rc = L.isr_select_top_dev(ptr(logp), P, ptr(n_dev), float(frac), int(min_n), ptr(keep), ptr(M_dev),
+                                      ptr(thr), ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_select_top")
     return keep, M_dev, thr
+
+
+def prep_queries(feat: torch.Tensor, mask: torch.Tensor, c0: int = 0, D: int | None = None, step: int = 3,
+                 dtype: str = "bf16_log2"):
+    """isr_prep_queries: the network's channels-last feature map -> K1's query operand.
+    feat (H, W, C) or (1, H, W, C) f32; mask (H, W) or (H, W, k) uint8 (channel 0 is used, as
+    cropMask[:, :, 0]); dtype 'bf16' | 'bf16_log2' | 'f32'.
+    Returns Q (S, Dpad) [S = capacity = ceil(H/step) * ceil(W/step)], pix_xy (S, 2) f32, n_dev (1,) i32."""
+    dev = require_cuda(feat, mask)
+    feat = feat.reshape(feat.shape[-3:]) if feat.ndim == 4 else feat
+    feat = _f32c(feat)
+    H, W, C = feat.shape
+    D = C - c0 if D is None else D
+    if mask.dtype != torch.uint8:
+        mask = (mask != 0).to(torch.uint8)
+    mask = mask.contiguous()
+    stride = 1 if mask.ndim == 2 else mask.shape[2]
+    if tuple(mask.shape[:2]) != (H, W):
+        raise ValueError(f"mask {tuple(mask.shape)} does not match the feature map {(H, W)}")
+    code = {"bf16": _capi.DTYPE_BF16, "bf16_log2": _capi.DTYPE_BF16_LOG2, "f32": _capi.DTYPE_F32}[dtype]
+    Dpad = D if dtype == "f32" else (16 if D <= 16 else 32 if D <= 32 else 64 if D <= 64 else 128)
+    if D > 128 or (dtype == "f32" and D > 64):
+        raise ValueError(f"D={D} not supported by K1")
+    S = ((H + step - 1) // step) * ((W + step - 1) // step)
+    Q = torch.empty((S, Dpad), dtype=torch.float32 if dtype == "f32" else torch.bfloat16, device=dev)
+    pix = torch.zeros((S, 2), dtype=torch.float32, device=dev)
+    n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_prep_queries_workspace_bytes(H, W, step), "prep")
+    with torch.cuda.device(dev):
+        rc = L.isr_prep_queries(ptr(feat), H, W, C, int(c0), int(D), ptr(mask), int(stride), int(step), code, Dpad,
+                                ptr(Q), ptr(pix), ptr(n_dev), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_prep_queries")
+    return Q, pix, n_dev
 
 
 def gather_corr(idx, keep, M_dev, pts, pix_xy):

@@ -64,6 +64,21 @@ def getCors(queries, feats, leaves=1):
 
 
 # --------------------------------------------------------------------- a2 / a3 filter + assembly
+def masked_queries(imfeatsfull, cropMask, down_sample: int = 3, n_feat: int = 12):
+    """inference.py:248-279 as one call: `imfeats[:, ::ds, ::ds]`, `inputMask[::ds, ::ds]`,
+    `maskIds = torch.where(inputMask)`, `maskedfeats = imfeats[0][maskIds]`, `ep2d[:,0] = maskIds[1]`,
+    `ep2d[:,1] = maskIds[0]`.  imfeatsfull (1, H, W, >= n_feat) on the device, cropMask (H, W[, 3])
+    uint8 array or tensor.  Returns (maskedfeats (P, n_feat) f32 on the device, ep2d (P, 2) float64
+    NumPy) — the objects the reference builds; P comes to the host here, as it does there.  The fused
+    driver sequence.register_crop keeps it on the device."""
+    feat = _dev(imfeatsfull, torch.float32)
+    mask = torch.as_tensor(np.asarray(cropMask) if not isinstance(cropMask, torch.Tensor) else cropMask)
+    mask = mask.to(feat.device)
+    Q, pix, n_dev = ops.prep_queries(feat, mask, c0=0, D=n_feat, step=down_sample, dtype="f32")
+    n = int(n_dev.item())
+    return Q[:n], pix[:n].double().cpu().numpy()
+
+
 def filter_top(in1, frac=0.8, min_n=500):
     """inference.py:282-290: threshold at the reference's order statistic, keep strictly above.
     in1 (P,1) or (P,) log-probs on the device.  Returns nidx as a NumPy int64 array (the

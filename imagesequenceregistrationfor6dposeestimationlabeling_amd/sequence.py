@@ -53,6 +53,30 @@ def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
     return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp)
 
 
+def register_crop(model: SequenceModel, feat: torch.Tensor, mask: torch.Tensor, cam, c0: int = 0,
+                  n_feat: int | None = None, down_sample: int = 3, itr: int = 500, reperr: float = 2.0,
+                  seed: int = 0, refine_iters: int = 10) -> tuple[ImageResult, torch.Tensor]:
+    """inference.py:248-293 from the network output on: `feat` = imfeatsfull (1, H, W, C) or (H, W, C)
+    channels-last on the device, `mask` = cropMask (H, W[, 3]) uint8 on the device, `cam` the cropped
+    and down-sampled camera matrix (formats.crop_camera).  Sub-sampling, masking, the compaction of the
+    masked descriptors into K1's operand layout and the pixel list run on the device
+    (isr_prep_queries); the number of masked pixels never visits the host.  Returns the ImageResult
+    (arrays have the capacity ceil(H/ds) * ceil(W/ds); idx / logp rows past the count are padding) and
+    the device count n_dev."""
+    D = model.keys.shape[1] if n_feat is None else n_feat
+    if model.keys.dtype == torch.bfloat16:
+        dtype = "bf16_log2" if model.log2_queries else "bf16"
+    else:
+        dtype = "f32"
+    Q, pix, n_dev = ops.prep_queries(feat, mask, c0=c0, D=D, step=down_sample, dtype=dtype)
+    keys = model.keys if model.keys.shape[1] == Q.shape[1] else ops._pad_cols(model.keys, Q.shape[1])
+    idx, logp = ops.corr_argmax(Q, keys, log2_prescaled=model.log2_queries)
+    keep, M, _ = ops.select_top(logp, n_dev=n_dev)
+    p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix)
+    r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M)
+    return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp), n_dev
+
+
 _streams: dict[tuple, list] = {}
 
 

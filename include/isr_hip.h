@@ -73,6 +73,23 @@ int isr_corr_logsoftmax(const void* Q, const void* K, int P, int N, int D, int l
                         int dtype, float* out, int64_t ldo, isr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * hand-off from the descriptor network to K1
+ * replaces  imfeats[:, ::3, ::3]; inputMask[::3, ::3]; maskIds = torch.where(inputMask);
+ *           maskedfeats = imfeats[0][maskIds]; ep2d[:,0] = maskIds[1]; ep2d[:,1] = maskIds[0]
+ *           inference.py:248-279
+ * feat (H, W, C) f32 channels-last (the network output after movedim), descriptor = channels
+ * [c0, c0 + D); mask (H, W) bytes, `mask_pix_stride` bytes between pixels (3 for cropMask[:, :, 0] of
+ * an interleaved BGR mask), non-zero = inside; every `step`-th row and column.
+ * Q: capacity S = ceil(H/step) * ceil(W/step) rows of ldq elements (bf16 or f32 by dtype; with
+ *   ISR_DTYPE_BF16_LOG2 the values are multiplied by log2(e) before their one rounding), masked
+ *   pixels compacted in row-major order, all other rows and the columns [D, ldq) zero.
+ * pix_xy (S, 2) f32 = (column, row) in the subsampled grid; *n_dev = number of masked pixels. */
+size_t isr_prep_queries_workspace_bytes(int H, int W, int step);
+int isr_prep_queries(const float* feat, int H, int W, int C, int c0, int D, const uint8_t* mask,
+                     int mask_pix_stride, int step, int dtype, int ldq, void* Q, float* pix_xy,
+                     int32_t* n_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a2  top-80 % correspondence filter
  * replaces  torch.sort(in1[:,0])[0][-perc+1] ; torch.where(in1[:,0] > thr)   inference.py:282-290
  * n = P; if n > min_n: perc = (int)(frac*n), rank = n - perc + 1 else rank = 1  (0-based rank into
@@ -82,6 +99,13 @@ int isr_corr_logsoftmax(const void* Q, const void* K, int P, int N, int D, int l
 size_t isr_select_top_workspace_bytes(int P);
 int isr_select_top(const float* logp, int P, double frac, int min_n, int32_t* keep, int32_t* M_dev,
                    float* thr_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
+
+/* The same cut when the element count lives on the device (after isr_prep_queries): the first
+ * min(P_cap, *n_dev) values of logp are the input; a count of 0, or a rank the reference would
+ * raise IndexError for, keeps nothing (*M_dev = 0, thr = +inf).  Workspace as for P_cap. */
+int isr_select_top_dev(const float* logp, int P_cap, const int32_t* n_dev, double frac, int min_n,
+                       int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
+                       isr_stream_t stream);
 
 /* a3  correspondence assembly  (inference.py:274-280, 289-290)
  * p3d[m] = pts[idx[keep[m]]], p2d[m] = pix_xy[keep[m]]  for m < *M_dev.  pts (N,3), pix_xy (P,2)
