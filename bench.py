@@ -311,11 +311,15 @@ def main():
                          "ms_per_launch": k1_ms, "launches": calls,
                          "flop_per_launch": flop / max(calls, 1), "images_per_launch": max(args.group, 1),
                          "exp_per_s": flop / max(calls, 1) / (2.0 * D) / (k1_ms * 1e-3) if calls else 0.0},
-            "roofline_nn": {"kernel": "nn_search_kernel (K3 Chamfer/ICP brute-force NN)", "bound": "valu",
-                            "achieved": 8.0 * pairs / (nms * 1e-3) * 1e-12 if ncalls else 0.0,
-                            "peak": PEAK_FP32_VALU * 1e-12, "unit": "TFLOP/s (8 FLOP/pair convention)",
-                            "frac": 8.0 * pairs / (nms * 1e-3) / PEAK_FP32_VALU if ncalls else 0.0,
-                            "pairs_per_s": pairs / (nms * 1e-3) if ncalls else 0.0, "calls": ncalls},
+            # K3 is no longer one kernel at one rate: single-item calls (ICP steps, final Chamfer) scan every
+            # target (nn_search_kernel, VALU-bound), the batched Chamfer pick runs the block-cooperative grid
+            # search, which evaluates only the candidates near each query cell.  Reported: the rate in
+            # brute-force-EQUIVALENT pairs (B Nq Nt per call) — a throughput figure, not a roofline fraction.
+            "nn_stage": {"kernels": "nn_search_kernel (brute force, B < 4) / nn_tile_search_kernel (grid, batched pick)",
+                         "equivalent_pairs_per_s": pairs / (nms * 1e-3) if ncalls else 0.0, "calls": ncalls,
+                         "ms_per_step": nms / args.steps,
+                         "brute_force_valu_rate_pairs_per_s": 9.2e12,
+                         "note": "see profiles/r01_nn_grid_vs_brute.txt and DESIGN.md section 4 (K3/K4)"},
             "stage_ms_per_step": {k: v[1] / args.steps for k, v in timing.items()},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -80,20 +80,21 @@ def test_nn_large_batch_vote_shape(cuda0, oracle_lib):
 
 
 def _both_paths(cuda0, q, t, Tq, Tt, radius):
-    """The same call through the uniform-grid search and through brute force (ISR_NN_GRID forces the
-    path; unset = size heuristic): everything must agree bit for bit."""
+    """The same call through both grid searches and through brute force (ISR_NN_GRID forces the
+    path): everything must agree bit for bit."""
     import os
     out = {}
     try:
-        for flag in ("1", "0"):
+        for flag in ("2", "1", "0"):       # block-cooperative grid, per-query grid, brute force
             os.environ["ISR_NN_GRID"] = flag
             out[flag] = _run(cuda0, q, t, Tq, Tt, radius)
     finally:
         os.environ.pop("ISR_NN_GRID", None)
-    g, b = out["1"], out["0"]
-    for k in ("nn_idx", "nn_d", "n_in", "sum_d", "sum_d2", "cov"):
-        assert np.array_equal(g[k], b[k]), k
-    return g
+    b = out["0"]
+    for flag in ("2", "1"):
+        for k in ("nn_idx", "nn_d", "n_in", "sum_d", "sum_d2", "cov"):
+            assert np.array_equal(out[flag][k], b[k]), (flag, k)
+    return out["2"]
 
 
 def _surface(rng, n):

@@ -22,7 +22,7 @@ for name, Nq, Nt, B in (("chamfer pairs", 20000, 20000, 63), ("icp step", 20000,
     for kind, Tb in (("near", poses(B, Ta)), ("random", poses(B))):
         Tq, Tt = torch.from_numpy(Ta).to(dev), torch.from_numpy(Tb).to(dev)
         res = {}
-        for path in ("1", "0"):
+        for path in ("2", "1", "0"):
             os.environ["ISR_NN_GRID"] = path
             r = ops.nn_batched(q, t, Tq, Tt); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,7 +30,7 @@ for name, Nq, Nt, B in (("chamfer pairs", 20000, 20000, 63), ("icp step", 20000,
             for _ in range(5): r = ops.nn_batched(q, t, Tq, Tt, want_cov=(B == 1))
             e1.record(); torch.cuda.synchronize()
             res[path] = (e0.elapsed_time(e1) / 5, r.sum_d.cpu().numpy())
-        assert np.array_equal(res["1"][1], res["0"][1])
-        print(f"{name:14s} {kind:6s} Nq={Nq} Nt={Nt} B={B}: grid {res['1'][0]:8.3f} ms | brute {res['0'][0]:8.3f} ms "
-              f"({Nq*Nt*B/res['0'][0]*1e-9:.2f} Tpairs/s)  speed-up {res['0'][0]/res['1'][0]:.1f}x")
+        assert np.array_equal(res["1"][1], res["0"][1]) and np.array_equal(res["2"][1], res["0"][1])
+        print(f"{name:14s} {kind:6s} Nq={Nq} Nt={Nt} B={B}: tile-grid {res['2'][0]:8.3f} ms | lane-grid {res['1'][0]:8.3f} ms | "
+              f"brute {res['0'][0]:8.3f} ms ({Nq*Nt*B/res['0'][0]*1e-9:.2f} Tpairs/s)  brute/tile {res['0'][0]/res['2'][0]:.1f}x")
 os.environ.pop("ISR_NN_GRID", None)
