@@ -419,7 +419,7 @@ __device__ __forceinline__ float block_reduce_max(float v, float* red) {   // re
   return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
-__global__ __launch_bounds__(kThreads) void nn_tile_search_kernel(
+__global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
     const float4* __restrict__ qsorted, const QBlock* __restrict__ qtable, const GridDesc* __restrict__ gq,
     const int32_t* __restrict__ qbstart, int Nq, const GridDesc* __restrict__ g, const int32_t* __restrict__ start,
     const float4* __restrict__ sorted, int Nt, const double* __restrict__ Tq, const double* __restrict__ Tt, int nb,
@@ -537,14 +537,15 @@ __global__ __launch_bounds__(kThreads) void nn_tile_search_kernel(
       __syncthreads();
     };
 
-    // Box growth: scan the cells of the workgroup's own box (k = 0); then jump straight to the box
-    // whose margin k h covers the worst best-distance found so far (one more shell and every lane is
-    // final); while some lane has seen no target at all the margin doubles.  A shell that would list
-    // more than half of the cloud, or does not fit the run list, is replaced by the full scan.
+    // Box growth: scan the workgroup's own box grown by one cell (the box alone can never be final:
+    // its margin is zero); then jump straight to the box whose margin k h covers the worst
+    // best-distance found so far (one more shell and every lane is final); while some lane has seen
+    // no target at all the margin doubles.  A shell that would list more than half of the cloud, or
+    // does not fit the run list, is replaced by the full scan.
     bool done = false;
     if (rigid) {
       int px0 = 0, px1 = -1, py0 = 0, py1 = -1, pz0 = 0, pz1 = -1;     // previous (inner) cell box: empty
-      int k = 0;
+      int k = 1;
       const int kcap = stop_radius >= 0.f ? (int)ceilf((stop_radius + slack) / (0.985f * h)) + 1 : 0x3fffffff;
       for (int iter = 0; iter < 8 && !done; ++iter) {
         const int x0 = clampi(bx0 - k, nx), x1 = clampi(bx1 + k, nx), y0 = clampi(by0 - k, ny),
