@@ -126,12 +126,18 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
     const float* __restrict__ Pm, const uint8_t* __restrict__ ok, int H, float reperr,
     int32_t* __restrict__ n_inl) {
   __shared__ int32_t cnt[kHC];
+  __shared__ __attribute__((aligned(16))) float Ps[kHC][12];   // the block's projection matrices: one
+  __shared__ uint8_t oks[kHC];                                  // coalesced load, then LDS broadcasts
   const int M = *M_dev;
   const int base = blockIdx.x * (kScoreThreads * kCPL);
   if (base >= M) return;  // block-uniform
   const int h0 = blockIdx.y * kHC;
   const int h1 = min(H, h0 + kHC);
-  if (threadIdx.x < kHC) cnt[threadIdx.x] = 0;
+  if (threadIdx.x < kHC) {
+    cnt[threadIdx.x] = 0;
+    oks[threadIdx.x] = (h0 + (int)threadIdx.x < h1) ? ok[h0 + threadIdx.x] : 0;
+  }
+  for (int i = threadIdx.x; i < (h1 - h0) * 12; i += kScoreThreads) (&Ps[0][0])[i] = Pm[12 * (size_t)h0 + i];
   __syncthreads();
   float X[kCPL], Y[kCPL], Z[kCPL], U[kCPL], V[kCPL];
   bool valid[kCPL];
@@ -145,8 +151,8 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
   }
   const int lane = threadIdx.x & 63;
   for (int h = h0; h < h1; ++h) {
-    if (!ok[h]) continue;  // uniform
-    const float* P = Pm + 12 * (size_t)h;  // uniform address: scalar loads
+    if (!oks[h - h0]) continue;  // uniform
+    const float* P = Ps[h - h0];
     int c_wave = 0;
 #pragma unroll
     for (int c = 0; c < kCPL; ++c) {
