@@ -1015,7 +1015,9 @@ NNPlan make_plan(int Nq, int Nt, int B) {
   //    force once neighbours are more than a cell or two away.
   p.grid = false;
   p.tile = B >= 4 && Nq >= 1024 && Nt >= 4096 && (long)Nq * B >= (1L << 17);
-  if (const char* ge = getenv("ISR_NN_GRID")) { p.grid = ge[0] == '1'; p.tile = ge[0] == '2'; }
+  if (const char* ge = getenv("ISR_NN_GRID")) {
+    if (ge[0]) { p.grid = ge[0] == '1'; p.tile = ge[0] == '2'; }   // empty = unset
+  }
   if (p.grid || p.tile) {
     p.nsplit = 1;
     p.split_len = max_split * kTile;
