@@ -193,70 +193,70 @@ def main():
     images = [(Q_all[j], pix_all[j]) for j in range(n_local)]
     torch.cuda.synchronize()
 
-    def register_and_pick(s: int):
-        """Every rank: its block of images through a1-a5, the pose all-gather, the sharded Chamfer pick."""
-        if args.group > 1:
-            res = sequence.register_block(model, Q_all, pix_all, Kcam, itr=args.itr, reperr=2.0,
-                                          seed0=(s << 20) + lo, refine_iters=args.refine_iters,
-                                          n_streams=args.streams, group=args.group)
-        else:
-            res = sequence.register_images(model, images, Kcam, itr=args.itr, reperr=2.0, seed0=(s << 20) + lo,
-                                           refine_iters=args.refine_iters, n_streams=args.streams)
-        poses, status = sequence.stack_poses(res)
-        poses_all = shard.allgather_rows(poses, n_total)
-        best, ch = sequence.pick_by_chamfer(pts, poses_all, R_gt, t_gt, n_total)
-        out = {"picked_pair": best, "pair_chamfer": ch, "registered_this_rank": int(status.sum().item()),
-               "images_this_rank": int(status.numel())}
-        pose = poses_all[best].reshape(3, 4).cpu().numpy() if rank == 0 else None
-        return out, pose
+    def register(s: int):
+        """Every rank: its block of images through a1-a5.  Enqueue only — returns the device tensors and
+        an event that fires when the poses are complete.  Consecutive steps alternate between two
+        issuing streams: the driver makes its issuing stream wait for every chain of the step, and
+        the next step's first K1 launch must not inherit that wait."""
+        with torch.cuda.stream(reg_streams[s & 1]):
+            if args.group > 1:
+                res = sequence.register_block(model, Q_all, pix_all, Kcam, itr=args.itr, reperr=2.0,
+                                              seed0=(s << 20) + lo, refine_iters=args.refine_iters,
+                                              n_streams=args.streams, group=args.group)
+            else:
+                res = sequence.register_images(model, images, Kcam, itr=args.itr, reperr=2.0, seed0=(s << 20) + lo,
+                                               refine_iters=args.refine_iters, n_streams=args.streams)
+            poses, status = sequence.stack_poses(res)
+            ev = torch.cuda.Event()
+            ev.record(reg_streams[s & 1])
+        return poses, status, ev
 
+    reg_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     tail_stream = torch.cuda.Stream(device=dev, priority=-1)
 
-    def icp_and_final(out: dict, pose: np.ndarray):
-        """Rank 0: ICP of the picked image's upper half onto the lower half + final Chamfer (a14, a15).
-        Runs on its own stream (and, pipelined, in a worker thread: device and stream are thread-local)."""
+    def verify(poses, status, ev):
+        """Every rank: pose all-gather + sharded Chamfer pick (one packed all-reduce(MIN)); rank 0: ICP of
+        the picked image's upper half onto the lower half + final Chamfer (a13-a15).  Runs on its own
+        stream and, pipelined, in a worker thread (current device and stream are thread-local; this
+        thread issues the step's collectives, the main thread issues none inside the timed loop)."""
         torch.cuda.set_device(dev)
-        best = out["picked_pair"]
         with torch.cuda.stream(tail_stream):
-            src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)   # icp.py:68
-            init = np.linalg.inv(np.vstack([pose, [0, 0, 0, 1]]))                               # icp.py:88-92
-            T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init)
-            fc = registration.final_chamfer(src, lower, T, cad)
-        return dict(out, final_chamfer=fc, icp_fitness=fit, icp_rmse=rmse,
-                    rot_err_rad=synth.rot_angle(pose[:, :3], R_gt[best]),
-                    trans_err_mm=float(np.linalg.norm(pose[:, 3] - t_gt[best])))
-
-    def step(s: int):
-        out, pose = register_and_pick(s)
-        if rank == 0:
-            tail_stream.wait_stream(torch.cuda.current_stream(dev))
-            out = icp_and_final(out, pose)
+            tail_stream.wait_event(ev)
+            poses_all = shard.allgather_rows(poses, n_total)
+            best, ch = sequence.pick_by_chamfer(pts, poses_all, R_gt, t_gt, n_total)
+            out = {"picked_pair": best, "pair_chamfer": ch, "registered_this_rank": int(status.sum().item()),
+                   "images_this_rank": int(status.numel())}
+            if rank == 0:
+                pose = poses_all[best].reshape(3, 4).cpu().numpy()
+                src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)   # icp.py:68
+                init = np.linalg.inv(np.vstack([pose, [0, 0, 0, 1]]))                               # icp.py:88-92
+                T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init)
+                out.update(final_chamfer=registration.final_chamfer(src, lower, T, cad), icp_fitness=fit,
+                           icp_rmse=rmse, rot_err_rad=synth.rot_angle(pose[:, :3], R_gt[best]),
+                           trans_err_mm=float(np.linalg.norm(pose[:, 3] - t_gt[best])))
         return out
 
     def run_steps(first: int, count: int):
-        """`count` steps.  Pipelined (default): the latency-bound ICP tail of batch s (31 small dependent
-        launch triples, a few CUs each) runs in a worker thread on a high-priority stream while the
-        main thread already registers batch s + 1 — batches are independent, all work of every step
-        is finished before this returns.  --no-pipeline runs the steps strictly one after the other."""
+        """`count` steps.  Pipelined (default): registration of batch s + 1 is enqueued as soon as batch
+        s's registration is, and batch s's verification (all-gather, Chamfer pick, ICP, final Chamfer —
+        VALU work and chains of small dependent launches) runs from a worker thread on a high-priority
+        stream beside it; the main thread never runs more than one batch ahead.  Batches are
+        independent and every step's work is finished before this returns.  --no-pipeline runs
+        registration and verification strictly one after the other."""
+        last = None
         if args.no_pipeline or count <= 1:
-            last = None
             for s in range(first, first + count):
-                last = step(s)
+                last = verify(*register(s))
             return last
         from concurrent.futures import ThreadPoolExecutor
-        last, pending = None, None
+        pending = None
         with ThreadPoolExecutor(max_workers=1) as pool:
             for s in range(first, first + count):
-                out, pose = register_and_pick(s)
+                r = register(s)
                 if pending is not None:
                     last = pending.result()
-                if rank == 0:
-                    tail_stream.wait_stream(torch.cuda.current_stream(dev))
-                    pending = pool.submit(icp_and_final, out, pose)
-                else:
-                    last = out
-            if pending is not None:
-                last = pending.result()
+                pending = pool.submit(verify, *r)
+            last = pending.result()
         return last
 
     def barrier():
@@ -301,7 +301,8 @@ def main():
                        "images_per_gpu": n_local, "P": P, "N": N, "D": D, "hypotheses": args.itr,
                        "parallelism": f"image-sharded x{world}",
                        "step_overlap": ("none" if args.no_pipeline else
-                                        "rank 0's ICP + final Chamfer of batch s overlaps the registration of batch s+1")},
+                                        "verification (all-gather, Chamfer pick, ICP, final Chamfer) of batch s "
+                                        "overlaps the registration of batch s+1")},
             "final_chamfer": last.get("final_chamfer"), "last_step": last,
             "roofline": {"kernel": ("corr_bf16_direct_kernel" if args.k1 == "log2" else "corr_bf16_kernel")
                                    + " (K1 getCors: MFMA GEMM + online LSE + argmax)",
