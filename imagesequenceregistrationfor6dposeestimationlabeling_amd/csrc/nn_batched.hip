@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
 #pragma unroll
             for (int v = 0; v < kGroup; ++v) {
               const int j = tidx[g0 + v];
-              const bool up = d[v] < best || (d[v] == best && j < bidx);
+              const bool up = (d[v] < best) | ((d[v] == best) & (j < bidx));   // bitwise: no branches
               best = up ? d[v] : best;
               bidx = up ? j : bidx;
             }

@@ -117,8 +117,14 @@ __device__ __forceinline__ bool inlier_f32(const float* __restrict__ Pm, float X
 }
 
 constexpr int kScoreThreads = 256;
-constexpr int kCPL = 4;    // correspondences per lane
-constexpr int kHC = 32;    // hypotheses per block: grid.y = ceil(H / kHC) keeps >= 8 waves per SIMD
+#ifndef ISR_SCORE_CPL
+#define ISR_SCORE_CPL 4
+#endif
+#ifndef ISR_SCORE_HC
+#define ISR_SCORE_HC 32
+#endif
+constexpr int kCPL = ISR_SCORE_CPL;   // correspondences per lane
+constexpr int kHC = ISR_SCORE_HC;     // hypotheses per block: grid.y = ceil(H / kHC) keeps >= 8 waves per SIMD
 constexpr int kMaxH = 8192;
 
 __global__ __launch_bounds__(kScoreThreads) void score_kernel(
@@ -152,11 +158,22 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
   const int lane = threadIdx.x & 63;
   for (int h = h0; h < h1; ++h) {
     if (!oks[h - h0]) continue;  // uniform
-    const float* P = Ps[h - h0];
+    // the matrix once per hypothesis (three LDS broadcasts), then straight-line tests: `&`, not `&&` —
+    // short-circuit evaluation turned every test into two exec-masked branches with an LDS wait each
+    const float4 r0 = *reinterpret_cast<const float4*>(&Ps[h - h0][0]);
+    const float4 r1 = *reinterpret_cast<const float4*>(&Ps[h - h0][4]);
+    const float4 r2 = *reinterpret_cast<const float4*>(&Ps[h - h0][8]);
     int c_wave = 0;
 #pragma unroll
     for (int c = 0; c < kCPL; ++c) {
-      const bool in = valid[c] && inlier_f32(P, X[c], Y[c], Z[c], U[c], V[c], reperr);
+      // same operation order as inlier_f32
+      const float x = __builtin_fmaf(r0.z, Z[c], __builtin_fmaf(r0.y, Y[c], __builtin_fmaf(r0.x, X[c], r0.w)));
+      const float y = __builtin_fmaf(r1.z, Z[c], __builtin_fmaf(r1.y, Y[c], __builtin_fmaf(r1.x, X[c], r1.w)));
+      const float z = __builtin_fmaf(r2.z, Z[c], __builtin_fmaf(r2.y, Y[c], __builtin_fmaf(r2.x, X[c], r2.w)));
+      const float ex = __builtin_fmaf(-U[c], z, x), ey = __builtin_fmaf(-V[c], z, y);
+      const float e2 = __builtin_fmaf(ey, ey, ex * ex);
+      const float lim = reperr * z;
+      const bool in = valid[c] & (z > 0.0f) & (e2 <= lim * lim);
       c_wave += __popcll(__ballot(in));
     }
     if (lane == 0 && c_wave) atomicAdd(&cnt[h - h0], c_wave);
