@@ -113,7 +113,7 @@ __device__ __forceinline__ bool inlier_f32(const float* __restrict__ Pm, float X
   const float ex = __builtin_fmaf(-u, z, x), ey = __builtin_fmaf(-v, z, y);
   const float e2 = __builtin_fmaf(ey, ey, ex * ex);
   const float lim = reperr * z;
-  return (z > 0.0f) && (e2 <= lim * lim);
+  return (z > 0.0f) & (e2 <= lim * lim);   // bitwise: straight-line code
 }
 
 constexpr int kScoreThreads = 256;
