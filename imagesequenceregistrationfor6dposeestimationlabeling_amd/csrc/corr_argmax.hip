@@ -248,12 +248,6 @@ __device__ __forceinline__ f32x16 exp_and_next_mfma_l2(const f32x16& cur, L2Stat
   return c;
 }
 
-__device__ __forceinline__ void consume_tile_l2(f32x16& acc, int krow0, L2State& st, f32x16& cinit) {
-  update_max_l2(acc, krow0, st, cinit);
-#pragma unroll
-  for (int i = 0; i < 16; ++i) st.l += __builtin_amdgcn_exp2f(acc[i]);
-}
-
 // Halves share M2, so the winner is decided on mr directly (exact).  Partial of a key range, common
 // to this kernel and corr_bf16_direct_kernel: (max logit in log2 units, reference R, l = sum 2^(s' - R), idx).
 __device__ __forceinline__ void store_partial_l2(const L2State& st, int q, int P, int split, float* pm,
