@@ -51,7 +51,7 @@ PEAK_FP32_VALU = 157.3e12
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--images", type=int, default=64, help="second-sequence images per GPU")
     ap.add_argument("--width", type=int, default=640)
