@@ -168,7 +168,9 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       const int qbn = (w + 1) % QB;
       if (w == NW - 2) {                                  // block-uniform
         if (has_next) lwrite(buf ^ 1);
+#ifndef ISR_ABL_NOBARRIER  // timing-only ablation: what the stage barrier costs (results are wrong without it)
         __syncthreads();
+#endif
       }
       const int kb = k0 + stage * kTK + sub * 32;
       if (FULL || kb < k1) {  // block-uniform
@@ -183,13 +185,23 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
           if (w == NW - 2) { if (has_next) load_a(buf ^ 1, 0); }
           else load_a(buf, sub + 1);
         }
+#ifdef ISR_ABL_DNOMAX   // timing-only ablations (tools/ablate_direct.sh): keep the accumulator live
+        asm volatile("" :: "v"(cur[0]), "v"(cur[15]));
+        st[qb].m = 0.f;      // inside the range check: no fallback launch work
+#else
         const float mn = tile_max_with(cur, st[qb].m);
         st[qb].tb = (mn > st[qb].m) ? kb : st[qb].tb;  // strict: the first tile to reach m keeps it
         st[qb].m = mn;
+#endif
         float l = st[qb].l;
+#ifdef ISR_ABL_DNOEXP
+        asm volatile("" :: "v"(cur[1]), "v"(cur[14]));
+        l = 1.f;
+#else
 #pragma unroll
         for (int i = 0; i < 16; ++i)
           l += __builtin_amdgcn_exp2f(NAT ? __builtin_fmaf(cur[i], kLog2e, nS) : cur[i]);
+#endif
         st[qb].l = l;
         // issue order: the item's 42 VALU instructions (8 max3, 2 record, 16 exp2, 16 add; NAT: 16
         // fma more) spread evenly behind the DK MFMAs of the next item.  The empty asm ties the
