@@ -224,8 +224,8 @@ __global__ __launch_bounds__(kThreads) void nn_grid_search_kernel(
 
 // ---------------------------------------------------------------------- block-cooperative grid search
 // The same exactness argument as nn_grid_search_kernel, with the brute-force kernel's arithmetic
-// intensity: the QUERIES are binned too (coarse cells of ~256 points), a workgroup takes one query
-// cell (<= 256 neighbouring queries, one per lane), bounds it by its axis-aligned box in the target
+// intensity: the QUERIES are binned too (coarse cells of ~170 points), a workgroup takes up to 64
+// neighbouring queries of one cell (one per lane), bounds it by its axis-aligned box in the target
 // grid's frame, and streams the targets of the cells around that box through LDS — ring by ring,
 // every lane against every candidate, winner = lexicographic minimum of (f32 d2, index).  A target
 // outside the box grown by k cells is farther than k h from every query of the workgroup, so the
@@ -240,34 +240,40 @@ struct QBlock {
 };
 
 __global__ __launch_bounds__(kThreads) void qblocks_count_kernel(const GridDesc* __restrict__ g,
-                                                                 const int32_t* __restrict__ start,
+                                                                 const int32_t* __restrict__ start, int tb,
                                                                  int32_t* __restrict__ nblk) {
   const int c = blockIdx.x * kThreads + threadIdx.x;
   if (c >= g->ncell) return;
-  nblk[c] = (start[c + 1] - start[c] + kThreads - 1) / kThreads;
+  nblk[c] = (start[c + 1] - start[c] + tb - 1) / tb;     // tb = queries per search workgroup
 }
 
 __global__ __launch_bounds__(kThreads) void qblocks_fill_kernel(const GridDesc* __restrict__ g,
                                                                 const int32_t* __restrict__ start,
-                                                                const int32_t* __restrict__ bstart,
+                                                                const int32_t* __restrict__ bstart, int tb,
                                                                 QBlock* __restrict__ table) {
   const int c = blockIdx.x * kThreads + threadIdx.x;
   if (c >= g->ncell) return;
   const int s0 = start[c], cnt = start[c + 1] - s0;
   int o = bstart[c];
-  for (int j = 0; j < cnt; j += kThreads) table[o++] = QBlock{s0 + j, min(kThreads, cnt - j)};
+  for (int j = 0; j < cnt; j += tb) table[o++] = QBlock{s0 + j, min(tb, cnt - j)};
 }
 
-__device__ __forceinline__ float block_reduce_max(float v, float* red) {   // red: kThreads / 64 floats
+template <int TB>
+__device__ __forceinline__ float block_reduce_max(float v, float* red) {   // red: TB / 64 floats
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if (TB == 64) return v;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
   __syncthreads();
-  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float m = red[0];
+#pragma unroll
+  for (int w = 1; w < TB / 64; ++w) m = fmaxf(m, red[w]);
+  return m;
 }
 
-__global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
+template <int TB>
+__global__ __launch_bounds__(TB, 8) void nn_tile_search_kernel(
     const float4* __restrict__ qsorted, const QBlock* __restrict__ qtable, const GridDesc* __restrict__ gq,
     const int32_t* __restrict__ qbstart, int Nq, const GridDesc* __restrict__ g, const int32_t* __restrict__ start,
     const float4* __restrict__ sorted, int Nt, const double* __restrict__ Tq, const double* __restrict__ Tt, int nb,
@@ -275,8 +281,8 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
   __shared__ __attribute__((aligned(16))) float tile[3][kTile];
   __shared__ int32_t tidx[kTile];
   __shared__ int32_t run_start[kTileRuns], run_pref[kTileRuns + 1];
-  __shared__ float red[kThreads / 64];
-  __shared__ int32_t scan_w[kThreads / 64];
+  __shared__ float red[TB / 64];
+  __shared__ int32_t scan_w[TB / 64];
   if (skip && *skip) return;
   const int tid = threadIdx.x;
   const int nqb = qbstart[gq->ncell];                 // query blocks (device-side count)
@@ -321,10 +327,10 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
     const float big = 3.0e38f;
     const float fx = (float)floor((mx - g->gmin[0]) * ginv), fy = (float)floor((my - g->gmin[1]) * ginv),
                 fz = (float)floor((mz - g->gmin[2]) * ginv);
-    const float bx1 = block_reduce_max(valid ? fx : -big, red), bx0 = -block_reduce_max(valid ? -fx : -big, red);
-    const float by1 = block_reduce_max(valid ? fy : -big, red), by0 = -block_reduce_max(valid ? -fy : -big, red);
-    const float bz1 = block_reduce_max(valid ? fz : -big, red), bz0 = -block_reduce_max(valid ? -fz : -big, red);
-    const float mag = block_reduce_max(valid ? fabsf(qx) + fabsf(qy) + fabsf(qz) : 0.f, red);
+    const float bx1 = block_reduce_max<TB>(valid ? fx : -big, red), bx0 = -block_reduce_max<TB>(valid ? -fx : -big, red);
+    const float by1 = block_reduce_max<TB>(valid ? fy : -big, red), by0 = -block_reduce_max<TB>(valid ? -fy : -big, red);
+    const float bz1 = block_reduce_max<TB>(valid ? fz : -big, red), bz0 = -block_reduce_max<TB>(valid ? -fz : -big, red);
+    const float mag = block_reduce_max<TB>(valid ? fabsf(qx) + fabsf(qy) + fabsf(qz) : 0.f, red);
     const float slack = 4.0e-6f * mag;
     auto clampi = [](float v, int n) { return v < 0.f ? 0 : (v > (float)(n - 1) ? n - 1 : (int)v); };
 
@@ -332,24 +338,34 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
     int bidx = -1;
     // stream the candidates listed in run_start / run_pref (n_runs runs, C points) against the lanes
     auto scan_runs = [&](int n_runs, int C) {
+      constexpr int CPT = kTile / TB;                        // candidates staged per thread and tile
       for (int t0 = 0; t0 < C; t0 += kTile) {
-        const int p = t0 + tid;
-        float cx = big, cy = big, cz = big;                  // padding: d2 = +inf
-        int ci = 0x7fffffff;
-        if (p < C) {
-          int lo = 0, hi = n_runs;                           // last run with run_pref[r] <= p
-          while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (run_pref[mid] <= p) lo = mid; else hi = mid;
+        float cx[CPT], cy[CPT], cz[CPT];
+        int ci[CPT];
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const int p = t0 + tid + u * TB;
+          cx[u] = big; cy[u] = big; cz[u] = big;             // padding: d2 = +inf
+          ci[u] = 0x7fffffff;
+          if (p < C) {
+            int lo = 0, hi = n_runs;                         // last run with run_pref[r] <= p
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if (run_pref[mid] <= p) lo = mid; else hi = mid;
+            }
+            const float4 c = sorted[run_start[lo] + (p - run_pref[lo])];
+            double tx, ty, tz;
+            xform64(tt, c.x, c.y, c.z, tx, ty, tz);
+            cx[u] = (float)tx; cy[u] = (float)ty; cz[u] = (float)tz;
+            ci[u] = __float_as_int(c.w);
           }
-          const float4 c = sorted[run_start[lo] + (p - run_pref[lo])];
-          double tx, ty, tz;
-          xform64(tt, c.x, c.y, c.z, tx, ty, tz);
-          cx = (float)tx; cy = (float)ty; cz = (float)tz;
-          ci = __float_as_int(c.w);
         }
         __syncthreads();                                     // previous tile fully consumed
-        tile[0][tid] = cx; tile[1][tid] = cy; tile[2][tid] = cz; tidx[tid] = ci;
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const int q = tid + u * TB;
+          tile[0][q] = cx[u]; tile[1][q] = cy[u]; tile[2][q] = cz[u]; tidx[q] = ci[u];
+        }
         __syncthreads();
         const int nvalid = min(kTile, C - t0);
         for (int g0 = 0; g0 < nvalid; g0 += kGroup) {
@@ -403,7 +419,7 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
         if (2 * rows > kTileRuns) break;                         // too wide for the run list: full scan below
         if (grew) {
           // run list: row (z, y) contributes [x0, x1], or its two new end pieces when the row was inside
-          for (int i = tid; i < rows; i += kThreads) {
+          for (int i = tid; i < rows; i += TB) {
             const int zz = z0 + i / (y1 - y0 + 1), yy = y0 + i % (y1 - y0 + 1);
             const int row = (zz * ny + yy) * nx;
             const bool inner = px1 >= px0 && zz >= pz0 && zz <= pz1 && yy >= py0 && yy <= py1;
@@ -417,10 +433,10 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
           __syncthreads();
           // exclusive scan of the run lengths (<= kTileRuns entries, 4 per thread)
           const int n_runs = 2 * rows;
-          int loc[kTileRuns / kThreads], sum = 0;
+          int loc[kTileRuns / TB], sum = 0;
 #pragma unroll
-          for (int j = 0; j < kTileRuns / kThreads; ++j) {
-            const int e = tid * (kTileRuns / kThreads) + j;
+          for (int j = 0; j < kTileRuns / TB; ++j) {
+            const int e = tid * (kTileRuns / TB) + j;
             loc[j] = e < n_runs ? run_pref[e] : 0;
             sum += loc[j];
           }
@@ -434,15 +450,15 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
           __syncthreads();
           int base = 0, total = 0;
 #pragma unroll
-          for (int w = 0; w < kThreads / 64; ++w) {
+          for (int w = 0; w < TB / 64; ++w) {
             if (w < (tid >> 6)) base += scan_w[w];
             total += scan_w[w];
           }
           if (2 * total > Nt) break;                             // block-uniform: cheaper to scan everything once
           int run = base + inc - sum;
 #pragma unroll
-          for (int j = 0; j < kTileRuns / kThreads; ++j) {
-            const int e = tid * (kTileRuns / kThreads) + j;
+          for (int j = 0; j < kTileRuns / TB; ++j) {
+            const int e = tid * (kTileRuns / TB) + j;
             if (e < n_runs) run_pref[e] = run;
             run += loc[j];
           }
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
           scan_runs(n_runs, total);
         }
         px0 = x0; px1 = x1; py0 = y0; py1 = y1; pz0 = z0; pz1 = z1;
-        const float worst = block_reduce_max(valid ? best : 0.f, red);
+        const float worst = block_reduce_max<TB>(valid ? best : 0.f, red);
         const float lim = 0.985f * (float)k * h - slack;
         if (lim > 0.f && worst <= lim * lim) done = true;                        // every lane's winner is final
         else if (k >= kcap) done = true;                                         // nothing outside can count
@@ -478,7 +494,9 @@ __global__ __launch_bounds__(kThreads, 8) void nn_tile_search_kernel(
 }
 
 constexpr double kCellScaleTgt = 6.0;    // cooperative search: ~36 targets per occupied cell
-constexpr double kCellScaleQry = 16.0;   // ~256 queries per occupied cell = one workgroup
+constexpr double kCellScaleQry = 13.0;   // ~170 queries per occupied cell, searched by workgroups of kTileTB
+constexpr int kTileTB = 64;              // one wave per workgroup: tighter boxes, milder worst lane, no block
+                                         // barriers (tools/nn_tile_sweep.py: 25-30 % faster than 256 x 16.0)
 constexpr int kTileGrid = 2048;          // persistent workgroups of nn_tile_search_kernel
 
 // device-side pieces of a grid built in the caller's workspace
@@ -541,22 +559,43 @@ TileWs take_tile(isr::Workspace& w, int Nq, int Nt) {
 }
 
 // both grids and the query-block table; everything stays on the device
+// queries per search workgroup and the two cell scales; ISR_NN_TILE="target scale,query scale,threads"
+// is a tuning hook for experiments (threads in {64, 128, 256})
+struct TileCfg {
+  double st, sq;
+  int tb;
+};
+
+TileCfg tile_cfg() {
+  TileCfg c{kCellScaleTgt, kCellScaleQry, kTileTB};
+  if (const char* e = getenv("ISR_NN_TILE")) (void)sscanf(e, "%lf,%lf,%d", &c.st, &c.sq, &c.tb);
+  if (c.tb != 64 && c.tb != 128 && c.tb != 256) c.tb = kTileTB;
+  return c;
+}
+
 void build_tile(const TileWs& tw, const float* qry, int Nq, const float* tgt, int Nt, hipStream_t stream) {
-  double st = kCellScaleTgt, sq = kCellScaleQry;
-  if (const char* e = getenv("ISR_NN_TILE")) (void)sscanf(e, "%lf,%lf", &st, &sq);   // tuning hook (experiments only)
+  const TileCfg cfg = tile_cfg();
+  const double st = cfg.st, sq = cfg.sq;
+  const int tb = cfg.tb;
   build_grid(tw.t, tgt, Nt, stream, st);
   build_grid(tw.q, qry, Nq, stream, sq);
   const int cb = (kMaxCells + kThreads - 1) / kThreads;      // ncell is a device value: cover the maximum
   (void)hipMemsetAsync(tw.q.count, 0, (size_t)(kMaxCells + 1) * 4, stream);
-  qblocks_count_kernel<<<cb, kThreads, 0, stream>>>(tw.q.desc, tw.q.start, tw.q.count);
+  qblocks_count_kernel<<<cb, kThreads, 0, stream>>>(tw.q.desc, tw.q.start, tb, tw.q.count);
   grid_scan_kernel<<<1, 1024, 0, stream>>>(tw.q.desc, tw.q.count, tw.bstart);
-  qblocks_fill_kernel<<<cb, kThreads, 0, stream>>>(tw.q.desc, tw.q.start, tw.bstart, tw.table);
+  qblocks_fill_kernel<<<cb, kThreads, 0, stream>>>(tw.q.desc, tw.q.start, tw.bstart, tb, tw.table);
 }
 
 void launch_tile_search(const TileWs& tw, int Nq, int Nt, const double* tq, const double* tt, int nb, float stop_radius,
                         float* part_d2, int32_t* part_idx, const int32_t* skip, hipStream_t stream) {
-  nn_tile_search_kernel<<<kTileGrid, kThreads, 0, stream>>>(tw.q.sorted, tw.table, tw.q.desc, tw.bstart, Nq, tw.t.desc,
-                                                            tw.t.start, tw.t.sorted, Nt, tq, tt, nb, stop_radius,
-                                                            part_d2, part_idx, skip);
+  const int tb = tile_cfg().tb;
+#define ISR_TILE_LAUNCH(TBv)                                                                                      \
+  nn_tile_search_kernel<TBv><<<kTileGrid * (kThreads / TBv), TBv, 0, stream>>>(                                   \
+      tw.q.sorted, tw.table, tw.q.desc, tw.bstart, Nq, tw.t.desc, tw.t.start, tw.t.sorted, Nt, tq, tt, nb,        \
+      stop_radius, part_d2, part_idx, skip)
+  if (tb == 64) ISR_TILE_LAUNCH(64);
+  else if (tb == 128) ISR_TILE_LAUNCH(128);
+  else ISR_TILE_LAUNCH(256);
+#undef ISR_TILE_LAUNCH
 }
 

@@ -1,4 +1,5 @@
-"""Cell-size sweep of the block-cooperative grid search (ISR_NN_TILE="target scale,query scale")."""
+"""Cell-size / workgroup-size sweep of the block-cooperative grid search
+(ISR_NN_TILE="target scale,query scale,threads per workgroup")."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -25,7 +26,7 @@ for name, Tb in cases.items():
     e0.record(); [ops.nn_batched(cloud, cloud, Tq, Tt) for _ in range(3)]; e1.record(); torch.cuda.synchronize()
     print(f"N={N} {name:9s} brute {e0.elapsed_time(e1)/3:7.3f} ms", flush=True)
 os.environ["ISR_NN_GRID"] = "2"
-for plan in ("6,16", "4,16", "8,16", "6,11", "6,8", "4,8", "8,11", "10,16", "5,12"):
+for plan in ("6,16,256", "6,11,64", "6,16,64", "8,11,64", "6,13,64", "5,11,64", "6,16,128", "8,16,64", "6,22,64"):
     os.environ["ISR_NN_TILE"] = plan
     out = []
     for name, Tb in cases.items():
@@ -34,4 +35,4 @@ for plan in ("6,16", "4,16", "8,16", "6,11", "6,8", "4,8", "8,11", "10,16", "5,1
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); [ops.nn_batched(cloud, cloud, Tq, Tt) for _ in range(3)]; e1.record(); torch.cuda.synchronize()
         out.append(f"{name} {e0.elapsed_time(e1)/3:7.3f}")
-    print(f"N={N} tile {plan:6s}: " + " | ".join(out), flush=True)
+    print(f"N={N} tile {plan:10s}: " + " | ".join(out), flush=True)
