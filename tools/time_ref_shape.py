@@ -26,3 +26,26 @@ t0 = time.perf_counter()
 for i in range(20): r = sequence.register_image(model, q, pixd, K, itr=500, reperr=2.0, seed=i)
 torch.cuda.synchronize()
 print(f"whole per-image chain (getCors f32 + filter + PnP-RANSAC 500 + refit): {(time.perf_counter()-t0)/20*1e3:.3f} ms/image; status {int(r.status.item())}, rot err {synth.rot_angle(r.pose.cpu().numpy()[:, :3], R[0]):.2e} rad")
+
+# the same chain captured once in a HIP graph (no host launches on replay)
+try:
+    qs, ps = q.clone(), pixd.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            sequence.register_image(model, qs, ps, K, itr=500, reperr=2.0, seed=1)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rg = sequence.register_image(model, qs, ps, K, itr=500, reperr=2.0, seed=1)
+    g.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(20): g.replay()
+    torch.cuda.synchronize()
+    ref = sequence.register_image(model, q, pixd, K, itr=500, reperr=2.0, seed=1)
+    torch.cuda.synchronize()
+    print(f"the chain as one HIP graph replay: {(time.perf_counter()-t0)/20*1e3:.3f} ms/image; pose identical to eager: {torch.equal(rg.pose, ref.pose)}")
+except Exception as e:  # report, do not hide
+    print("HIP graph capture failed:", repr(e))
