@@ -266,6 +266,20 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(0, args.warmup)
+    # K1 with the chip to itself (untimed region, rank 0): the in-step figure below shares the GPU with the
+    # RANSAC chains and the previous batch's verification, this one is the kernel alone
+    k1_alone_ms = None
+    if rank == 0:
+        g_rows = Q_all[:max(args.group, 1)].reshape(-1, D)
+        ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(2):
+            ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries)
+        e1.record()
+        torch.cuda.synchronize()
+        k1_alone_ms = e0.elapsed_time(e1) / 2
     ops.enable_timing(True)
     barrier()
     t0 = time.perf_counter()
@@ -310,6 +324,10 @@ def main():
                          "bound": "mfma", "achieved": k1 * 1e-12, "peak": PEAK_BF16_MFMA * 1e-12,
                          "unit": "TFLOP/s", "frac": k1 / PEAK_BF16_MFMA, "traffic": traffic,
                          "ms_per_launch": k1_ms, "launches": calls,
+                         "alone": {"ms_per_launch": k1_alone_ms,
+                                   "frac": (flop / max(calls, 1) / (k1_alone_ms * 1e-3) / PEAK_BF16_MFMA
+                                            if calls and k1_alone_ms else None),
+                                   "note": "same launch with nothing else on the GPU (incl. finalize), untimed region"},
                          "flop_per_launch": flop / max(calls, 1), "images_per_launch": max(args.group, 1),
                          "exp_per_s": flop / max(calls, 1) / (2.0 * D) / (k1_ms * 1e-3) if calls else 0.0},
             # K3 is no longer one kernel at one rate: single-item calls (ICP steps, final Chamfer) scan every
