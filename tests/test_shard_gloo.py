@@ -98,3 +98,49 @@ def test_world2_vote_row_sums():
         for r in range(size):
             assert ret[r][2] == sums.tolist() and ret[r][0] == int(np.argmax(sums))
         assert ret[0] == ret[1]
+
+
+def _pipelined_worker(rank, size, port, n, steps, ret):
+    """bench.py's step overlap in miniature: the main thread only 'registers' (no collectives), a
+    worker thread per rank issues each step's all-gather + packed all-reduce, one step behind."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(size))
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    try:
+        lo, hi = shard.block_range(n, rank, size)
+
+        def register(s):
+            return torch.full((hi - lo, 12), float(s), dtype=torch.float64) + torch.arange(lo, hi, dtype=torch.float64)[:, None]
+
+        def verify(s, poses):
+            allp = shard.allgather_rows(poses, n)
+            ch = np.abs(np.sin((allp[:-1, 0].numpy() + s) * 1.3)).astype(np.float32)
+            plo, phi = shard.owned_pairs(n, rank, size)
+            loc = (None, 0) if phi <= plo else (float(ch[plo:phi].min()), plo + int(np.argmin(ch[plo:phi])))
+            v, i = shard.allreduce_min_pair(loc[0], loc[1])
+            return (s, float(allp.sum()), v, i)
+
+        out, pending = [], None
+        with ThreadPoolExecutor(max_workers=1) as pool:
+            for s in range(steps):
+                poses = register(s)
+                if pending is not None:
+                    out.append(pending.result())
+                pending = pool.submit(verify, s, poses)
+            out.append(pending.result())
+        dist.barrier()
+        ret[rank] = out
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_pipelined_verification_in_worker_threads():
+    size, port, n, steps = 2, _free_port(), 10, 6
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_pipelined_worker, args=(size, port, n, steps, ret), nprocs=size, join=True)
+        assert ret[0] == ret[1] and [o[0] for o in ret[0]] == list(range(steps))
+        for s, total, v, i in ret[0]:
+            allp0 = np.arange(n, dtype=np.float64) + s
+            ch = np.abs(np.sin((allp0[:-1] + s) * 1.3)).astype(np.float32)
+            assert total == float((allp0 * 12).sum()) and i == int(np.argmin(ch)) and v == float(ch.min())
