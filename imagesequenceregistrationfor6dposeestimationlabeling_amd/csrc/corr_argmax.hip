@@ -10,21 +10,25 @@
 //
 // Orientation: S^T = K Q^T, so the C/D layout puts the QUERY on the lane (col = lane & 31) and 16
 // KEYS in the lane's registers (row = (r&3) + 8(r>>2) + 4(lane>>5)): the reduction over keys is
-// lane-local — no cross-lane traffic until one 2-lane merge at the end.
+// lane-local — no cross-lane traffic until one 2-lane merge per chunk.
 //
-// Per-lane online state for its query:  m  (max logit, exact, for the arg-max; lowest key on ties)
-//   M2 = ceil(m * log2 e)  (an integer, so exp2(fma(s, log2e, -M2)) has one rounding and every
-//                           rescale  l *= 2^(M2old - M2new)  is exact)
-//   l  = sum_n 2^(s_n log2e - M2)
-// Cost per 32x32 tile at D = 64: 4 MFMA (128 matrix-pipe cycles) against ~310 cycles of VALU issue
-// (16 v_exp_f32 at 8.3, 16 adds at 2.8, 8 v_max3 at 4.6, the MFMAs' own ~18 each): the loop is bound
+// A query's result is a function of (query, keys) ONLY — not of the launch it travels in:
+//   * the log-sum-exp is accumulated over CANONICAL CHUNKS of kChunk keys (a constant): per chunk a
+//     partial (reference R_c, l_c = sum 2^(s log2e - R_c)) whose arithmetic order is fixed, written
+//     to the workspace; corr_finalize_kernel adds the chunks in ascending order in f64.  Which
+//     workgroup computed a chunk (the plan splits the key range by occupancy) never matters.
+//   * bf16 fast path (corr_direct.hpp): R_c = 0 for everyone; queries outside its range are redone
+//     per query by corr_bf16_kernel with R_c = ceil(chunk maximum).
+//   * arg-max: raw MFMA logits (C = 0) compare equal wherever they are computed; a query whose top-2
+//     margin is inside the f32 accumulation error bound is decided in exact arithmetic
+//     (corr_recheck_kernel: exact bf16 products summed in f64 in the order of
+//     oracle/isr_oracle.c:orc_corr_argmax_bf16), so bf16 indices equal the oracle's, ties to the
+//     lowest key.
+// dtype f32: v_mfma_f32_32x32x2_f32, bit for bit a k-ordered fmaf chain — the oracle's
+// orc_corr_argmax_f32 reproduces its logits exactly (no recheck needed).
+// Cost per 32x32 tile at D = 64: 4 MFMA (128 matrix-pipe cycles) against ~320 cycles of VALU issue
+// (16 v_exp_f32 at 8.3, 16 adds at 2.8, 8 max at 4.6, ..., the MFMAs' own ~18 each): the loop is bound
 // by VALU issue, almost half of it the transcendental unit — DESIGN.md section 4 has the measurements.
-//
-// dtype bf16: v_mfma_f32_32x32x16_bf16.  dtype f32: v_mfma_f32_32x32x2_f32, which is bit for bit
-// a k-ordered fmaf chain — oracle/isr_oracle.c:orc_corr_argmax_f32 reproduces its logits exactly.
-// dtype bf16-log2 (queries prescaled by log2 e): corr_bf16_direct_kernel, the VALU-minimal loop
-// (wave-uniform reference in the MFMA C operand, record-only arg-max, post-loop row recovery),
-// with corr_bf16_kernel<.., LOG2> as its flagged per-workgroup fallback.
 #include "isr_common.hpp"
 
 #include <type_traits>
@@ -36,16 +40,33 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kQB = 2;                       // 32-query blocks per wave (f32 kernel)
-#ifndef ISR_BF16_QB
-#define ISR_BF16_QB 2
-#endif
-constexpr int kQBbf16 = ISR_BF16_QB;         // 32-query blocks per wave, bf16 kernel (D <= 64)
+constexpr int kQB = 2;                       // 32-query blocks per wave
 constexpr int kTK = 128;                     // keys per LDS stage
+constexpr int kChunkStages = 16;             // stages per canonical chunk
+constexpr int kChunk = kTK * kChunkStages;   // keys per canonical chunk of the log-sum-exp (a CONSTANT)
 constexpr float kLog2e = 1.4426950408889634f;
 // M2 of a lane that has seen no valid key yet: finite, so a fully masked tile gives
 // exp2(fma(-inf, log2e, 1e30)) = 0 instead of NaN, and the first real key rescales l by 2^-huge = 0.
 constexpr float kNoM2 = -1.0e30f;
+constexpr int kKnBlocks = 64;                // blocks of the key-norm pass
+constexpr int kRSplitMax = 16;               // key ranges of the recheck pass (latency, not arithmetic)
+
+// Workspace of one isr_corr_argmax call.
+struct CorrWs {
+  float* pm;        // (nsplit, P) maximum logit of the key range (raw units of the kernel)
+  float* pm2;       // (nsplit, P) runner-up inside the range (bf16 paths)
+  int32_t* pbi;     // (nsplit, P) key of the maximum
+  int32_t* pbad;    // (nsplit, P) 1: outside the direct kernel's range, the fallback owns this (range, query)
+  float* plc;       // (nchunks, P) chunk sums l_c
+  float* pmc;       // (nchunks, P) chunk maxima (fallback / f32: the chunk reference is ceil of it)
+  float* qn2;       // (P) |q|^2, then (finalize) the recheck threshold
+  int32_t* flags;   // (nsplit, qblocks) workgroup holds a bad query
+  float* kn2;       // (kKnBlocks) per-block max |k|^2
+  int32_t* rcount;  // recheck list length
+  int32_t* rlist;   // (P) queries to decide exactly
+  double* rval;     // (rsplit, P) exact best value per recheck key range and list entry
+  int32_t* ridx;    // (rsplit, P)
+};
 
 struct LaneState {
   float m;    // running max logit
@@ -56,22 +77,17 @@ struct LaneState {
 
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
+__device__ __forceinline__ f32x16 splat16(float v) {
+  return f32x16{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
+}
+
 // Part A of consuming a tile (rows kb + 4h + (r&3) + 8(r>>2), r = 0..15, of this lane's query):
 // the running maximum / arg-max and the integer log2 reference M2.
 __device__ __forceinline__ void update_max(const f32x16& acc, int krow0, LaneState& st) {
-#ifdef ISR_ABL_NOMAX  // timing-only ablation (tools/ablate_corr.hip): keep acc live, skip part A
-  asm volatile("" :: "v"(acc[0]), "v"(acc[15]));
-  (void)krow0; (void)st;
-  return;
-#endif
   const float x0 = max3(acc[0], acc[1], acc[2]), x1 = max3(acc[3], acc[4], acc[5]),
               x2 = max3(acc[6], acc[7], acc[8]), x3 = max3(acc[9], acc[10], acc[11]),
               x4 = max3(acc[12], acc[13], acc[14]);
   const float t = fmaxf(max3(x0, x1, x2), max3(x3, x4, acc[15]));
-#ifdef ISR_ABL_NOUPD  // timing-only ablation: maximum without the arg-max/rescale branch
-  st.m = fmaxf(st.m, t);
-  return;
-#endif
   if (__any(t > st.m)) {  // wave-uniform; taken for ~64(1 + ln(tiles/64)) of a key range's tiles
     if (t > st.m) {
       int r = 15;
@@ -98,39 +114,6 @@ __device__ __forceinline__ void consume_tile(const f32x16& acc, int krow0, LaneS
   accumulate_exp(acc, st);
 }
 
-// Part B of tile `cur` interleaved with the DK MFMAs of the next tile, so one wave keeps both the
-// matrix pipe and the VALU/transcendental pipe fed (co-resident waves run this same program in
-// lockstep, so overlap cannot be left to chance between waves — measured: 14 % co-execution).
-template <int DK>
-__device__ __forceinline__ f32x16 exp_and_next_mfma(const f32x16& cur, LaneState& st,
-                                                    const bf16x8 (&a)[DK], const bf16x8 (&b)[DK]) {
-  constexpr int E = 16 / DK > 0 ? 16 / DK : 1;  // exp elements per MFMA
-  const float nM2 = -st.M2;
-  float l = st.l;
-  f32x16 c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int s = 0; s < DK; ++s) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], c, 0, 0, 0);
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int i = s * E + e;
-#ifdef ISR_ABL_NOEXP  // timing-only ablation: keep the accumulator live, no fma/exp/add
-      if (i < 16) asm volatile("" :: "v"(cur[i]));
-#else
-      if (i < 16) l += __builtin_amdgcn_exp2f(__builtin_fmaf(cur[i], kLog2e, nM2));
-#endif
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // 1 MFMA
-    __builtin_amdgcn_sched_group_barrier(0x002, 3 * E, 0);  // then this step's fma/exp/add
-  }
-  if (DK * E < 16) {
-#pragma unroll
-    for (int i = DK * E; i < 16; ++i) l += __builtin_amdgcn_exp2f(__builtin_fmaf(cur[i], kLog2e, nM2));
-  }
-  st.l = l;
-  return c;
-}
-
 __device__ __forceinline__ void mask_tail(f32x16& acc, int krow0, int N) {
 #pragma unroll
   for (int i = 0; i < 16; ++i)
@@ -141,6 +124,7 @@ __device__ __forceinline__ bool better(float ma, int ia, float mb, int ib) {
   return (ma > mb) || (ma == mb && ia < ib);
 }
 
+// the two lanes (h = 0, 1) of a query -> one (m, M2, l, bi); M2 = ceil(m log2e) stays true
 __device__ __forceinline__ void merge_state(LaneState& a, const LaneState& b) {
   const float M2 = fmaxf(a.M2, b.M2);
   const float la = (a.M2 == M2) ? a.l : a.l * __builtin_amdgcn_exp2f(a.M2 - M2);
@@ -150,47 +134,73 @@ __device__ __forceinline__ void merge_state(LaneState& a, const LaneState& b) {
   a.l = la + lb;
 }
 
-__device__ __forceinline__ void store_partial(const LaneState& st_, int q, int P, int split,
-                                              float* pm, float* pM2, float* pl, int32_t* pbi) {
-  LaneState st = st_;
+__device__ __forceinline__ LaneState merged_with_other_half(LaneState st) {
   LaneState o;
   o.m = __shfl_xor(st.m, 32, 64);
   o.M2 = __shfl_xor(st.M2, 32, 64);
   o.l = __shfl_xor(st.l, 32, 64);
   o.bi = __shfl_xor(st.bi, 32, 64);
   merge_state(st, o);
-  if ((threadIdx.x & 63) < 32 && q < P) {
-    const size_t off = (size_t)split * P + q;
-    pm[off] = st.m; pM2[off] = st.M2; pl[off] = st.l; pbi[off] = st.bi;
-  }
+  return st;
 }
 
+// ------------------------------------------------------------------------- key staging (LDS)
+// 128-key stages through an XOR-swizzled LDS image: coalesced 16-byte global loads,
+// conflict-free ds_read_b128 in MFMA A-operand layout.  Shared by the fallback and recheck kernels
+// (the direct kernel stages through a raw buffer descriptor, corr_direct.hpp).
+template <int DK>
+struct KeyStage {
+  static constexpr int NCH = 2 * DK;                         // 16-byte chunks per key row
+  static constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;     // key rows per 256-byte LDS bank row
+  static constexpr int CHUNKS = kTK * NCH;                   // chunks per stage
+  static constexpr int NLD = (CHUNKS + kThreads - 1) / kThreads;
+  uint4 stg[NLD];
+  __device__ __forceinline__ void gload(const uint16_t* __restrict__ K, int ldk, int key0, int k1) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int ci = threadIdx.x + i * kThreads;
+      const int row = ci / NCH, c = ci % NCH;
+      const int key = key0 + row;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ci < CHUNKS && key < k1) v = *reinterpret_cast<const uint4*>(K + (size_t)key * ldk + 8 * c);
+      stg[i] = v;
+    }
+  }
+  __device__ __forceinline__ void lwrite(uint4* lds) const {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int ci = threadIdx.x + i * kThreads;
+      const int row = ci / NCH, c = ci % NCH;
+      if (ci < CHUNKS) lds[row * NCH + (c ^ ((row / RPB) & (NCH - 1)))] = stg[i];
+    }
+  }
+  static __device__ __forceinline__ void load_a(const uint4* lds, int sub, int r, int h, bf16x8 (&a)[DK]) {
+    const int row = sub * 32 + r;
+    const int sw = (row / RPB) & (NCH - 1);
+#pragma unroll
+    for (int s = 0; s < DK; ++s) {
+      const uint4 v = lds[row * NCH + ((2 * s + h) ^ sw)];
+      a[s] = *reinterpret_cast<const bf16x8*>(&v);
+    }
+  }
+};
 
-// ---------------------------------------------------------------------- bf16, log2-domain variant
-// dtype ISR_DTYPE_BF16_LOG2: the caller multiplied the queries by log2(e) BEFORE rounding them to
-// bf16, so the MFMA produces logits in log2 units and exp2 needs no multiply.  The subtraction of
-// the integer reference M2 rides in the MFMA's C operand: each query block keeps a 16-register
-// tile holding -M2 (rewritten only when M2 moves), the first MFMA of every chain takes it as C and
-// writes a different destination, so the accumulator already holds s' - M2 and the epilogue is
-// exp2 + add per element: 16 VALU instructions per tile fewer than the natural-log path, no extra
-// MFMA.  (Carrying -M2 as an extra k-step instead was measured: the fifth MFMA cost what the 16
-// fmas saved.)  MFMA numerics with the large C term: profiles/r01_mfma_numerics.txt (max abs error
-// 1.9e-5 over |s' - M2| <= 190, no bias).
+// ---------------------------------------------------------------------- bf16, log2-domain fallback
+// dtype ISR_DTYPE_BF16_LOG2, per-query reference: the subtraction of the integer reference M2 rides in
+// the MFMA's C operand: each query block keeps a 16-register tile holding -M2 (rewritten only when
+// M2 moves), the first MFMA of every chain takes it as C, so the accumulator already holds s' - M2
+// and the epilogue is exp2 + add per element.  MFMA numerics with the large C term:
+// profiles/r01_mfma_numerics.txt (max abs error 1.9e-5 over |s' - M2| <= 190, no bias).
 struct L2State {
   float mr;   // max(s') - M2 of this lane's rows (-inf before the first key)
   float M2;   // integer reference, SHARED by the two lanes (h = 0, 1) of a query
   float l;    // sum 2^(s' - M2)
-  int bi;
 };
-
-__device__ __forceinline__ f32x16 splat16(float v) {
-  return f32x16{v, v, v, v, v, v, v, v, v, v, v, v, v, v, v, v};
-}
 
 // Part A, log2 domain.  acc holds s' - M2; a new maximum above the reference bumps M2 by an integer d
 // (both lanes of the query, exchanged with one cross-half shuffle), rescales l by 2^-d exactly,
 // shifts this tile's accumulators and rewrites the query block's -M2 tile.
-__device__ __forceinline__ void update_max_l2(f32x16& acc, int krow0, L2State& st, f32x16& cinit) {
+__device__ __forceinline__ void update_max_l2(f32x16& acc, L2State& st, f32x16& cinit) {
   const float x0 = max3(acc[0], acc[1], acc[2]), x1 = max3(acc[3], acc[4], acc[5]),
               x2 = max3(acc[6], acc[7], acc[8]), x3 = max3(acc[9], acc[10], acc[11]),
               x4 = max3(acc[12], acc[13], acc[14]);
@@ -202,13 +212,7 @@ __device__ __forceinline__ void update_max_l2(f32x16& acc, int krow0, L2State& s
     float d = up ? (first ? ceilf(t) : fmaxf(0.f, ceilf(t))) : (first ? ninf : 0.f);
     d = fmaxf(d, __shfl_xor(d, 32, 64));
     d = (d > ninf) ? d : 0.f;
-    if (up) {
-      int r = 15;
-#pragma unroll
-      for (int i = 14; i >= 0; --i) r = (acc[i] == t) ? i : r;
-      st.bi = krow0 + (r & 3) + 8 * (r >> 2);
-      st.mr = t;
-    }
+    if (up) st.mr = t;
     if (__any(d != 0.f)) {
       if (d != 0.f) {
 #pragma unroll
@@ -222,233 +226,116 @@ __device__ __forceinline__ void update_max_l2(f32x16& acc, int krow0, L2State& s
   }
 }
 
-// Part B, log2 domain, interleaved with the DK MFMAs of the next tile (first one takes C = -M2).
-// Compile-time recursion over the steps: sched_group_barrier needs literal group sizes.
-template <int DK, int S>
-__device__ __forceinline__ void l2_step(const f32x16& cur, float& l, f32x16& c, const bf16x8 (&a)[DK],
-                                        const bf16x8 (&b)[DK], const f32x16& cinit) {
-  constexpr int E = 16 / DK > 0 ? 16 / DK : 1;
-  if constexpr (S == 0) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], cinit, 0, 0, 0);
-  else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[S], b[S], c, 0, 0, 0);
-#pragma unroll
-  for (int e = 0; e < E; ++e) l += __builtin_amdgcn_exp2f(cur[S * E + e]);
-  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-  __builtin_amdgcn_sched_group_barrier(0x002, 2 * E, 0);
-  if constexpr (S + 1 < DK) l2_step<DK, S + 1>(cur, l, c, a, b, cinit);
-}
-
-template <int DK>
-__device__ __forceinline__ f32x16 exp_and_next_mfma_l2(const f32x16& cur, L2State& st, const bf16x8 (&a)[DK],
-                                                       const bf16x8 (&b)[DK], const f32x16& cinit) {
-  static_assert(DK <= 16, "one exp group per MFMA");
-  float l = st.l;
-  f32x16 c;
-  l2_step<DK, 0>(cur, l, c, a, b, cinit);
-  st.l = l;
-  return c;
-}
-
-// Halves share M2, so the winner is decided on mr directly (exact).  Partial of a key range, common
-// to this kernel and corr_bf16_direct_kernel: (max logit in log2 units, reference R, l = sum 2^(s' - R), idx).
-__device__ __forceinline__ void store_partial_l2(const L2State& st, int q, int P, int split, float* pm,
-                                                 float* pM2, float* pl, int32_t* pbi) {
-  const float omr = __shfl_xor(st.mr, 32, 64);
-  const float ol = __shfl_xor(st.l, 32, 64);
-  const int obi = __shfl_xor(st.bi, 32, 64);
-  const bool other = better(omr, obi, st.mr, st.bi);
-  if ((threadIdx.x & 63) < 32 && q < P) {
-    const size_t off = (size_t)split * P + q;
-    pm[off] = st.M2 + (other ? omr : st.mr);
-    pM2[off] = st.M2;
-    pl[off] = st.l + ol;
-    pbi[off] = other ? obi : st.bi;
-  }
-}
-
-// Merge key ranges in f64: winner by the maximum (ascending ranges, strict >: ties keep the lower
-// key), l rescaled to the largest reference;
-//   logp = -(ln l + (Rf - mw) ln2),  lse = mw ln2 - logp   (natural-log units).
-__global__ void corr_finalize_l2_kernel(int P, int nsplit, const float* __restrict__ pm,
-                                        const float* __restrict__ pM2, const float* __restrict__ pl,
-                                        const int32_t* __restrict__ pbi, int32_t* __restrict__ idx,
-                                        float* __restrict__ logp, float* __restrict__ lse) {
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= P) return;
-  double mw = pm[q], Rf = pM2[q], l = pl[q];
-  int bi = pbi[q];
-  for (int s = 1; s < nsplit; ++s) {
-    const size_t o = (size_t)s * P + q;
-    const double m = pm[o], R = pM2[o], ls = pl[o];
-    if (m > mw) { mw = m; bi = pbi[o]; }
-    if (R > Rf) { l = l * exp2(Rf - R) + ls; Rf = R; }
-    else l += ls * exp2(R - Rf);
-  }
-  const double ln2 = 0.6931471805599453094;
-  // <= 0 like log_softmax (the sum contains the maximum's own term); rounding of the shifted
-  // logits can leave it a few 1e-6 above
-  const double lp = fmin(0.0, -(log(l) + (Rf - mw) * ln2));
-  idx[q] = bi;
-  if (logp) logp[q] = (float)lp;
-  if (lse) lse[q] = (float)(mw * ln2 - lp);
-}
-
-// ------------------------------------------------------------------------------------ bf16
-// Keys are staged through LDS once per workgroup (coalesced 16-byte global loads, XOR-swizzled
-// image, ds_read_b128 in MFMA operand layout) and shared by the workgroup's four waves.
-// (Tried and rejected, measured on MI355X: every wave streaming its own A fragments straight from
-// global memory — no LDS, no barrier — is bound by the CU's vector L1: 245 ns per tile against
-// 202 ns here, with the epilogue entirely hidden behind the loads.)
-#ifndef ISR_BF16_WAVES
-#define ISR_BF16_WAVES 1
-#endif
-template <int DK, int QB, bool LOG2 = false>  // D = 16 * DK, DK in {1, 2, 4, 8}; QB 32-query blocks per wave
-__global__ __launch_bounds__(kThreads, (DK <= 4 && !LOG2) ? ISR_BF16_WAVES : 1) void corr_bf16_kernel(
+// The per-query-reference kernel: ONE canonical chunk per workgroup (grid.y = chunk), so every
+// chunk starts from a clean state (C = 0 for the first tile) whatever else the launch holds.  It
+// runs behind corr_bf16_direct_kernel and only for the queries that kernel marked bad; it leaves
+// (chunk maximum, l_c relative to R_c = ceil(chunk maximum [* log2 e])) — the index of a bad query is
+// always decided by the exact recheck, so no arg-max is kept here.
+template <int DK, bool LOG2>
+__global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
-    int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
-    int32_t* __restrict__ pbi, const int32_t* __restrict__ flags) {
-  // flags != nullptr: this kernel runs as the fallback of corr_bf16_direct_kernel — only the
-  // workgroups that kernel flagged do any work.
-  if (flags && flags[blockIdx.y * gridDim.x + blockIdx.x] == 0) return;
-  constexpr int NCH = 2 * DK;                         // 16-byte chunks per key row
-  constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;     // key rows per 256-byte LDS bank row
-  constexpr int CHUNKS = kTK * NCH;                   // chunks per stage
-  constexpr int NLD = (CHUNKS + kThreads - 1) / kThreads;
-  __shared__ uint4 lds[2][CHUNKS];
+    int range_chunks, CorrWs ws) {
+  const int chunk = blockIdx.y;
+  const int range = chunk / range_chunks;
+  if (ws.flags[range * gridDim.x + blockIdx.x] == 0) return;
+  using KS = KeyStage<DK>;
+  __shared__ uint4 lds[2][KS::CHUNKS];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int split = blockIdx.y;
-  const int q0 = (blockIdx.x * kWaves + wave) * (QB * 32);
+  const int q0 = (blockIdx.x * kWaves + wave) * (kQB * 32);
 
-  bf16x8 bq[QB][DK];
+  bf16x8 bq[kQB][DK];
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
+  for (int qb = 0; qb < kQB; ++qb) {
     int row = q0 + qb * 32 + r;
     row = row < P ? row : P - 1;
     const uint16_t* src = Q + (size_t)row * ldq + 8 * h;
 #pragma unroll
     for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
   }
-
-  LaneState st[QB];
-  L2State s2[QB];
-  f32x16 cinit[QB];                     // LOG2: -M2 of the lane's query, the C operand of each chain
+  LaneState st[kQB];
+  L2State s2[kQB];
+  f32x16 cinit[kQB];                    // LOG2: -M2 of the lane's query, the C operand of each chain
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
+  for (int qb = 0; qb < kQB; ++qb) {
     st[qb].m = -__builtin_inff(); st[qb].M2 = kNoM2; st[qb].l = 0.f; st[qb].bi = 0;
-    s2[qb].mr = -__builtin_inff(); s2[qb].M2 = 0.f; s2[qb].l = 0.f; s2[qb].bi = 0;
+    s2[qb].mr = -__builtin_inff(); s2[qb].M2 = 0.f; s2[qb].l = 0.f;
     cinit[qb] = splat16(0.f);
   }
-
-  const int k0 = split * split_len;
-  const int k1 = min(N, k0 + split_len);
+  const int k0 = chunk * kChunk;
+  const int k1 = min(N, k0 + kChunk);
   const int nstage = (k1 - k0 + kTK - 1) / kTK;
-
-  uint4 stg[NLD];
-  auto gload = [&](int stage) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int ci = tid + i * kThreads;
-      const int row = ci / NCH, c = ci % NCH;
-      const int key = k0 + stage * kTK + row;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ci < CHUNKS && key < k1)
-        v = *reinterpret_cast<const uint4*>(K + (size_t)key * ldk + 8 * c);
-      stg[i] = v;
-    }
-  };
-  auto lwrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int ci = tid + i * kThreads;
-      const int row = ci / NCH, c = ci % NCH;
-      if (ci < CHUNKS) lds[buf][row * NCH + (c ^ ((row / RPB) & (NCH - 1)))] = stg[i];
-    }
-  };
-  // A fragments of key sub-tile `sub` of LDS buffer `buf`
-  bf16x8 a[DK];
-  auto load_a = [&](int buf, int sub) {
-    const int row = sub * 32 + r;
-    const int sw = (row / RPB) & (NCH - 1);
-#pragma unroll
-    for (int s = 0; s < DK; ++s) {
-      const uint4 v = lds[buf][row * NCH + ((2 * s + h) ^ sw)];
-      a[s] = *reinterpret_cast<const bf16x8*>(&v);
-    }
-  };
-
-  // Software pipeline over the stage's work items w = (sub, qb): while item w's logits go through
-  // the softmax epilogue, the MFMAs of item w + 1 run.  The stage barrier sits before the LAST
-  // item's epilogue (all LDS reads of the stage are done by then), so the first MFMAs of the next
-  // stage overlap that epilogue too.  Two named accumulators alternate by the (static) item
-  // parity: no register copies between items.
-  constexpr int NSUB = kTK / 32, NW = NSUB * QB;
-  static_assert(NW % 2 == 0, "items per stage must be even for the accumulator ping-pong");
-  gload(0);
-  lwrite(0);
+  KS ks;
+  ks.gload(K, ldk, k0, k1);
+  ks.lwrite(lds[0]);
   __syncthreads();
-  load_a(0, 0);
-  f32x16 acc[2];
-  acc[0] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int s = 0; s < DK; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[0][s], acc[0], 0, 0, 0);
-
-  // FULL stages (every key of the stage exists) run without any per-item condition, so the two
-  // accumulators never meet in a phi and the compiler keeps them in place (a v_mov between the
-  // MFMA chain and the epilogue would stall the in-order wave until the chain retires).
-  // The last, partial stage takes the guarded body.
-  auto stage_body = [&](int stage, auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
+  for (int stage = 0; stage < nstage; ++stage) {
     const int buf = stage & 1;
-    const bool has_next = stage + 1 < nstage;
-    if (has_next) gload(stage + 1);
+    if (stage + 1 < nstage) ks.gload(K, ldk, k0 + (stage + 1) * kTK, k1);
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      const int sub = w / QB, qb = w % QB;
-      const int qbn = (w + 1) % QB;
-      if (w + 1 == NW) {
-        if (has_next) lwrite(buf ^ 1);
-        __syncthreads();
-        if (has_next) load_a(buf ^ 1, 0);
-      } else if (qbn == 0) {
-        load_a(buf, sub + 1);
-      }
+    for (int sub = 0; sub < kTK / 32; ++sub) {
       const int kb = k0 + stage * kTK + sub * 32;
-      const int krow0 = kb + 4 * h;
-      if (FULL || kb < k1) {  // block-uniform
-        if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], krow0, k1);
-        if (LOG2) {
-          update_max_l2(acc[w & 1], krow0, s2[qb], cinit[qb]);
-          acc[(w + 1) & 1] = exp_and_next_mfma_l2<DK>(acc[w & 1], s2[qb], a, bq[qbn], cinit[qbn]);
-        } else {
-          update_max(acc[w & 1], krow0, st[qb]);
-          acc[(w + 1) & 1] = exp_and_next_mfma<DK>(acc[w & 1], st[qb], a, bq[qbn]);
+      if (kb < k1) {  // block-uniform
+        bf16x8 a[DK];
+        KS::load_a(lds[buf], sub, r, h, a);
+#pragma unroll
+        for (int qb = 0; qb < kQB; ++qb) {
+          f32x16 acc = LOG2 ? cinit[qb] : splat16(0.f);
+#pragma unroll
+          for (int s = 0; s < DK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qb][s], acc, 0, 0, 0);
+          if (kb + 32 > k1) mask_tail(acc, kb + 4 * h, k1);
+          if (LOG2) {
+            update_max_l2(acc, s2[qb], cinit[qb]);
+            float l = s2[qb].l;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) l += __builtin_amdgcn_exp2f(acc[i]);
+            s2[qb].l = l;
+          } else {
+            consume_tile(acc, kb + 4 * h, st[qb]);
+          }
         }
       }
     }
-  };
-  const int nfull = (k1 - k0) / kTK;  // stages whose kTK keys all exist
-  for (int stage = 0; stage < nfull; ++stage) stage_body(stage, std::true_type{});
-  if (nfull < nstage) stage_body(nfull, std::false_type{});
-
+    if (stage + 1 < nstage) ks.lwrite(lds[buf ^ 1]);
+    __syncthreads();
+  }
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    if (LOG2) store_partial_l2(s2[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
-    else store_partial(st[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
+  for (int qb = 0; qb < kQB; ++qb) {
+    const int q = q0 + qb * 32 + r;
+    float mc, lc;
+    if (LOG2) {
+      // the halves share M2: chunk maximum mc = M2 + max(mr); stored reference Rs = ceil(mc) (equal to
+      // M2 except when the f32 sum M2 + mr rounds down to M2 - 1: l is then rescaled by an exact 2)
+      const float mr = fmaxf(s2[qb].mr, __shfl_xor(s2[qb].mr, 32, 64));
+      const float l = s2[qb].l + __shfl_xor(s2[qb].l, 32, 64);
+      mc = s2[qb].M2 + mr;
+      lc = l * __builtin_amdgcn_exp2f(s2[qb].M2 - ceilf(mc));
+    } else {
+      const LaneState mgd = merged_with_other_half(st[qb]);      // M2 = ceil(m * log2 e)
+      mc = mgd.m;
+      lc = mgd.l;
+    }
+    if (h == 0 && q < P && ws.pbad[(size_t)range * P + q]) {
+      ws.pmc[(size_t)chunk * P + q] = mc;
+      ws.plc[(size_t)chunk * P + q] = lc;
+    }
   }
 }
 
 #include "corr_direct.hpp"   // corr_bf16_direct_kernel: the VALU-minimal bf16 loop (log2 and natural units)
 
 // ------------------------------------------------------------------------------------- f32
+// Exact path: v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain.  Per canonical chunk the
+// lane state restarts; the range keeps the exact (maximum, lowest key).
 template <int DP>  // padded D (multiple of 2): k-steps = DP / 2
 __global__ __launch_bounds__(kThreads) void corr_f32_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, int P, int N, int D, int ldq, int ldk,
-    int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
-    int32_t* __restrict__ pbi) {
+    int range_chunks, CorrWs ws) {
   constexpr int KS = DP / 2;
   constexpr int LD = DP + 1;  // odd dword stride: conflict-free ds_read_b32 down a column
-  __shared__ float lds[2][kTK * LD];
+  constexpr int TKF = (DP <= 64) ? kTK : 32;     // keys per LDS stage (D = 128: 2 x 32 x 129 x 4 B = 33 KB)
+  __shared__ float lds[2][TKF * LD];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
@@ -467,117 +354,364 @@ __global__ __launch_bounds__(kThreads) void corr_f32_kernel(
     }
   }
   LaneState st[kQB];
+  float gm[kQB];
+  int gbi[kQB];
+#pragma unroll
+  for (int qb = 0; qb < kQB; ++qb) { gm[qb] = -__builtin_inff(); gbi[qb] = 0; }
+
+  const int c0 = split * range_chunks;
+  const int cend = min((N + kChunk - 1) / kChunk, c0 + range_chunks);
+  constexpr int NEL = (TKF * DP + kThreads - 1) / kThreads;
+  float stg[NEL];
+  for (int c = c0; c < cend; ++c) {
+    const int k0 = c * kChunk;
+    const int k1 = min(N, k0 + kChunk);
+    const int nstage = (k1 - k0 + TKF - 1) / TKF;
+#pragma unroll
+    for (int qb = 0; qb < kQB; ++qb) { st[qb].m = -__builtin_inff(); st[qb].M2 = kNoM2; st[qb].l = 0.f; st[qb].bi = 0; }
+    auto gload = [&](int stage) {
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) {
+        const int e = tid + i * kThreads;
+        const int row = e / DP, col = e % DP;
+        const int key = k0 + stage * TKF + row;
+        stg[i] = (e < TKF * DP && key < k1 && col < D) ? K[(size_t)key * ldk + col] : 0.f;
+      }
+    };
+    auto lwrite = [&](int buf) {
+#pragma unroll
+      for (int i = 0; i < NEL; ++i) {
+        const int e = tid + i * kThreads;
+        if (e < TKF * DP) lds[buf][(e / DP) * LD + (e % DP)] = stg[i];
+      }
+    };
+    __syncthreads();                    // the previous chunk's last reads are done
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    for (int stage = 0; stage < nstage; ++stage) {
+      const int buf = stage & 1;
+      if (stage + 1 < nstage) gload(stage + 1);
+#pragma unroll
+      for (int sub = 0; sub < TKF / 32; ++sub) {
+        const int kb = k0 + stage * TKF + sub * 32;
+        if (kb < k1) {
+          const float* arow = &lds[buf][(sub * 32 + r) * LD + h];
+          f32x16 acc[kQB];
+#pragma unroll
+          for (int qb = 0; qb < kQB; ++qb) acc[qb] = splat16(0.f);
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const float a = arow[2 * s];
+#pragma unroll
+            for (int qb = 0; qb < kQB; ++qb)
+              acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[qb][s], acc[qb], 0, 0, 0);
+          }
+          const int krow0 = kb + 4 * h;
+          if (kb + 32 > k1) {
+#pragma unroll
+            for (int qb = 0; qb < kQB; ++qb) mask_tail(acc[qb], krow0, k1);
+          }
+#pragma unroll
+          for (int qb = 0; qb < kQB; ++qb) consume_tile(acc[qb], krow0, st[qb]);
+        }
+      }
+      if (stage + 1 < nstage) lwrite(buf ^ 1);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < kQB; ++qb) {
+      const LaneState mgd = merged_with_other_half(st[qb]);
+      const int q = q0 + qb * 32 + r;
+      if (h == 0 && q < P) {
+        ws.pmc[(size_t)c * P + q] = mgd.m;
+        ws.plc[(size_t)c * P + q] = mgd.l;
+      }
+      if (mgd.m > gm[qb]) { gm[qb] = mgd.m; gbi[qb] = mgd.bi; }   // ascending chunks: ties keep the lower key
+    }
+  }
 #pragma unroll
   for (int qb = 0; qb < kQB; ++qb) {
-    st[qb].m = -__builtin_inff(); st[qb].M2 = kNoM2; st[qb].l = 0.f; st[qb].bi = 0;
+    const int q = q0 + qb * 32 + r;
+    if (h == 0 && q < P) {
+      const size_t off = (size_t)split * P + q;
+      ws.pm[off] = gm[qb];
+      ws.pbi[off] = gbi[qb];
+    }
   }
+}
 
-  const int k0 = split * split_len;
-  const int k1 = min(N, k0 + split_len);
-  const int nstage = (k1 - k0 + kTK - 1) / kTK;
-  constexpr int NEL = (kTK * DP + kThreads - 1) / kThreads;
-  float stg[NEL];
-  auto gload = [&](int stage) {
+// ------------------------------------------------------------------------------ key norms
+// max_n |k_n|^2 for the error bound of the margin test, one partial per block; block 0 also zeroes
+// the recheck counter of this call.
+__global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __restrict__ K, int N, int D,
+                                                           int ldk, CorrWs ws) {
+  __shared__ float red[4];
+  float mx = 0.f;
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += kKnBlocks * 256) {
+    const uint16_t* row = K + (size_t)n * ldk;
+    float s = 0.f;
+    for (int d = 0; d < D; d += 8) {
+      const uint4 v = *reinterpret_cast<const uint4*>(row + d);
+      const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int i = 0; i < NEL; ++i) {
-      const int e = tid + i * kThreads;
-      const int row = e / DP, col = e % DP;
-      const int key = k0 + stage * kTK + row;
-      stg[i] = (e < kTK * DP && key < k1 && col < D) ? K[(size_t)key * ldk + col] : 0.f;
-    }
-  };
-  auto lwrite = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NEL; ++i) {
-      const int e = tid + i * kThreads;
-      if (e < kTK * DP) lds[buf][(e / DP) * LD + (e % DP)] = stg[i];
-    }
-  };
-
-  if (nstage > 0) { gload(0); lwrite(0); }
-  __syncthreads();
-  for (int stage = 0; stage < nstage; ++stage) {
-    const int buf = stage & 1;
-    if (stage + 1 < nstage) gload(stage + 1);
-#pragma unroll
-    for (int sub = 0; sub < kTK / 32; ++sub) {
-      const int kb = k0 + stage * kTK + sub * 32;
-      if (kb < k1) {
-        const float* arow = &lds[buf][(sub * 32 + r) * LD + h];
-        f32x16 acc[kQB];
-#pragma unroll
-        for (int qb = 0; qb < kQB; ++qb)
-          acc[qb] = f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          const float a = arow[2 * s];
-#pragma unroll
-          for (int qb = 0; qb < kQB; ++qb)
-            acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq[qb][s], acc[qb], 0, 0, 0);
-        }
-        const int krow0 = kb + 4 * h;
-        if (kb + 32 > k1) {
-#pragma unroll
-          for (int qb = 0; qb < kQB; ++qb) mask_tail(acc[qb], krow0, k1);
-        }
-#pragma unroll
-        for (int qb = 0; qb < kQB; ++qb) consume_tile(acc[qb], krow0, st[qb]);
+      for (int j = 0; j < 4; ++j) {
+        const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xFFFF0000u);
+        s = __builtin_fmaf(lo, lo, s);
+        s = __builtin_fmaf(hi, hi, s);
       }
     }
-    if (stage + 1 < nstage) lwrite(buf ^ 1);
-    __syncthreads();
+    mx = fmaxf(mx, s);
   }
 #pragma unroll
-  for (int qb = 0; qb < kQB; ++qb) store_partial(st[qb], q0 + qb * 32 + r, P, split, pm, pM2, pl, pbi);
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ws.kn2[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (blockIdx.x == 0) *ws.rcount = 0;
+  }
 }
 
-// Merge the key-range splits (ascending, so equal maxima keep the lowest key) and write outputs.
-// logp = -ln sum_n e^(s_n - m) is formed without the m - lse cancellation, in f64:
-//   sum_n e^(s_n - m) = l * 2^M2 / e^m   ->   logp = -(ln l + M2 ln2 - m)
-__global__ void corr_finalize_kernel(int P, int nsplit, const float* __restrict__ pm,
-                                     const float* __restrict__ pM2, const float* __restrict__ pl,
-                                     const int32_t* __restrict__ pbi, int32_t* __restrict__ idx,
-                                     float* __restrict__ logp, float* __restrict__ lse) {
+// ------------------------------------------------------------------------------- finalize
+// Per query: the winner over the key ranges (ascending, strict >: ties keep the lower key), the
+// canonical f64 sum over the chunks
+//     L = sum_c l_c 2^(R_c - Rf),   Rf = max_c R_c
+// and   logp = -(ln L + Rf ln2 - m)   [natural logits; log2-domain logits: -(ln L + (Rf - m') ln2)],
+// formed without the m - lse cancellation.  MODE 0: f32 path (every chunk carries its maximum).
+// MODE 1: bf16 log2 domain, MODE 2: bf16 natural units — chunks of good queries have R_c = 0, chunks of
+// bad (range, query) pairs R_c = ceil(chunk maximum [* log2 e]); then the margin test:
+//     |MFMA logit - exact logit| <= eps = (D + 2) 2^-23 |q| max|k|
+// holds for ANY order of at-least-faithfully-rounded f32 additions of the D exact products (Higham's
+// gamma_n bound with u = 2^-23; Cauchy-Schwarz on sum |q_d k_d|), so a winner more than 2 eps above the
+// runner-up is the exact arg-max; everything else goes on the recheck list with the threshold below
+// which no key can be the exact winner.
+template <int MODE>
+__global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, int nsplit, int range_chunks,
+                                                            int nchunks, CorrWs ws, int32_t* __restrict__ idx,
+                                                            float* __restrict__ logp, float* __restrict__ lse) {
+  __shared__ float s_kn2;
+  if (MODE != 0) {
+    if (threadIdx.x < 64) {
+      float v = ws.kn2[threadIdx.x];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+      if (threadIdx.x == 0) s_kn2 = v;
+    }
+    __syncthreads();
+  }
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= P) return;
-  LaneState a{pm[q], pM2[q], pl[q], pbi[q]};
-  for (int s = 1; s < nsplit; ++s) {
-    const size_t o = (size_t)s * P + q;
-    const LaneState b{pm[o], pM2[o], pl[o], pbi[o]};
-    merge_state(a, b);
+  float G1 = -__builtin_inff(), G2 = -__builtin_inff();
+  int bi = 0;
+  bool anybad = false;
+  for (int r = 0; r < nsplit; ++r) {
+    const size_t o = (size_t)r * P + q;
+    if (MODE != 0 && ws.pbad[o]) { anybad = true; continue; }
+    const float m = ws.pm[o];
+    if (m > G1) { G2 = fmaxf(G2, G1); G1 = m; bi = ws.pbi[o]; }
+    else G2 = fmaxf(G2, m);
+    if (MODE != 0) G2 = fmaxf(G2, ws.pm2[o]);
+  }
+  double L = 0.0, Rf = -__builtin_inf();
+  for (int c = 0; c < nchunks; ++c) {
+    const size_t o = (size_t)c * P + q;
+    float R = 0.f;
+    if (MODE == 0 || ws.pbad[(size_t)(c / range_chunks) * P + q]) {
+      const float mc = ws.pmc[o];
+      R = (MODE == 1) ? ceilf(mc) : ceilf(mc * kLog2e);
+      if (MODE != 0) {                                    // approximate maximum of a bad range
+        if (mc > G1) { G2 = fmaxf(G2, G1); G1 = mc; } else G2 = fmaxf(G2, mc);
+      }
+    }
+    const double l = ws.plc[o];
+    if ((double)R > Rf) { L = L * exp2(Rf - (double)R) + l; Rf = R; }
+    else L += l * exp2((double)R - Rf);
   }
   const double ln2 = 0.6931471805599453094;
-  const double lp = fmin(0.0, -(log((double)a.l) + ((double)a.M2 * ln2 - (double)a.m)));   // <= 0 like log_softmax
-  idx[q] = a.bi;
+  // <= 0 like log_softmax (the sum contains the maximum's own term); rounding can leave it a few 1e-6 above
+  double lp, ls;
+  if (MODE == 1) {
+    lp = fmin(0.0, -(log(L) + (Rf - (double)G1) * ln2));
+    ls = (double)G1 * ln2 - lp;
+  } else {
+    lp = fmin(0.0, -(log(L) + (Rf * ln2 - (double)G1)));
+    ls = (double)G1 - lp;
+  }
+  idx[q] = bi;
   if (logp) logp[q] = (float)lp;
-  if (lse) lse[q] = (float)((double)a.m - lp);
+  if (lse) lse[q] = (float)ls;
+  if (MODE != 0) {
+    const double eps = (double)(D + 2) * 1.1920928955078125e-7 * sqrt((double)ws.qn2[q] * (double)s_kn2) * 1.0001;
+    const double margin = (double)G1 - (double)G2;
+    if (anybad || !(margin > 2.0 * eps)) {
+      // exact winner x* >= exact(winner) >= G1 - eps, so its MFMA logit is >= G1 - 2 eps; bad ranges carry
+      // logits shifted by their reference (error up to ~3 eps) and the f32 rounding of M2 + mr
+      const double thr = anybad ? (double)G1 - 8.0 * eps - 1e-5 * fabs((double)G1) : (double)G1 - 2.0 * eps;
+      ws.qn2[q] = (float)(thr - 1e-6 * fabs(thr) - 1e-30);      // rounded down
+      ws.rlist[atomicAdd(ws.rcount, 1)] = q;
+    }
+  }
 }
 
-// upper bound on nsplit (also sizes the workspace, which must not depend on the device)
-constexpr int kMaxSplit = 64;
+// ------------------------------------------------------------------------------ exact recheck
+// exact <q, k> of two bf16 rows: products of bf16 values are exact in f64 and are added in ascending d
+// exactly as oracle/isr_oracle.c:orc_corr_argmax_bf16 does, then scaled like the oracle's logit.
+__device__ __attribute__((noinline)) double exact_logit(const uint16_t* __restrict__ qrow, const uint16_t* __restrict__ krow,
+                                              int D, double scale) {
+  double acc = 0.0;
+  for (int d = 0; d < D; d += 8) {
+    const uint4 qa = *reinterpret_cast<const uint4*>(qrow + d);
+    const uint4 ka = *reinterpret_cast<const uint4*>(krow + d);
+    const uint32_t qw[4] = {qa.x, qa.y, qa.z, qa.w}, kw[4] = {ka.x, ka.y, ka.z, ka.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc += (double)__uint_as_float(qw[j] << 16) * (double)__uint_as_float(kw[j] << 16);
+      acc += (double)__uint_as_float(qw[j] & 0xFFFF0000u) * (double)__uint_as_float(kw[j] & 0xFFFF0000u);
+    }
+  }
+  return acc * scale;
+}
+
+// The listed queries (gathered through rlist) against one key range per blockIdx.y, on the same MFMA
+// chain as the main kernels (C = 0: the same f32 logits); every element at or above the query's
+// threshold is evaluated exactly; per (range, list entry) the best exact value and its lowest key.
+template <int DK>
+__global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
+    const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
+    int rsplit, double scale, CorrWs ws) {
+  using KS = KeyStage<DK>;
+  __shared__ uint4 lds[2][KS::CHUNKS];
+  const int cnt = *ws.rcount;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int range = blockIdx.y;
+  const int nstage_all = (N + kTK - 1) / kTK;
+  const int per = (nstage_all + rsplit - 1) / rsplit;
+  const int k0 = range * per * kTK;
+  const int k1 = min(N, k0 + per * kTK);
+  for (int g = blockIdx.x; g * (kWaves * kQB * 32) < cnt; g += gridDim.x) {   // block-uniform
+    const int e0 = (g * kWaves + wave) * (kQB * 32);
+    bf16x8 bq[kQB][DK];
+    float thr[kQB];
+    int qrow[kQB];
+    double best[kQB];
+    int bidx[kQB];
+#pragma unroll
+    for (int qb = 0; qb < kQB; ++qb) {
+      const int e = e0 + qb * 32 + r;
+      qrow[qb] = ws.rlist[e < cnt ? e : cnt - 1];
+      thr[qb] = e < cnt ? ws.qn2[qrow[qb]] : __builtin_inff();
+      const uint16_t* src = Q + (size_t)qrow[qb] * ldq + 8 * h;
+#pragma unroll
+      for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+      best[qb] = -__builtin_inf();
+      bidx[qb] = -1;
+    }
+    const int nstage = k1 > k0 ? (k1 - k0 + kTK - 1) / kTK : 0;
+    KS ks;
+    __syncthreads();                    // the previous group's last LDS reads are done
+    if (nstage > 0) {
+      ks.gload(K, ldk, k0, k1);
+      ks.lwrite(lds[0]);
+    }
+    __syncthreads();
+    for (int stage = 0; stage < nstage; ++stage) {
+      const int buf = stage & 1;
+      if (stage + 1 < nstage) ks.gload(K, ldk, k0 + (stage + 1) * kTK, k1);
+#pragma unroll
+      for (int sub = 0; sub < kTK / 32; ++sub) {
+        const int kb = k0 + stage * kTK + sub * 32;
+        if (kb < k1) {  // block-uniform
+          bf16x8 a[DK];
+          KS::load_a(lds[buf], sub, r, h, a);
+#pragma unroll
+          for (int qb = 0; qb < kQB; ++qb) {
+            f32x16 acc = splat16(0.f);
+#pragma unroll
+            for (int s = 0; s < DK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qb][s], acc, 0, 0, 0);
+            if (kb + 32 > k1) mask_tail(acc, kb + 4 * h, k1);
+            const float t = tile_max(acc);
+            if (__any(t >= thr[qb])) {                    // rare
+              if (t >= thr[qb]) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {            // ascending key inside the lane: strict > keeps the lowest
+                  if (acc[i] >= thr[qb]) {
+                    const int n = kb + 4 * h + (i & 3) + 8 * (i >> 2);
+                    const double v = exact_logit(Q + (size_t)qrow[qb] * ldq, K + (size_t)n * ldk, 16 * DK, scale);
+                    if (v > best[qb] || (v == best[qb] && n < bidx[qb])) { best[qb] = v; bidx[qb] = n; }
+                  }
+                }
+              }
+            }
+          }
+        }
+      }
+      if (stage + 1 < nstage) ks.lwrite(lds[buf ^ 1]);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int qb = 0; qb < kQB; ++qb) {
+      const double ov = __shfl_xor(best[qb], 32, 64);
+      const int oi = __shfl_xor(bidx[qb], 32, 64);
+      if (oi >= 0 && (bidx[qb] < 0 || ov > best[qb] || (ov == best[qb] && oi < bidx[qb]))) { best[qb] = ov; bidx[qb] = oi; }
+      const int e = e0 + qb * 32 + r;
+      if (h == 0 && e < cnt) {
+        ws.rval[(size_t)range * P + e] = best[qb];
+        ws.ridx[(size_t)range * P + e] = bidx[qb];
+      }
+    }
+  }
+}
+
+// list entry e: best over the recheck key ranges (ascending: ties keep the lower key) -> idx[rlist[e]]
+__global__ __launch_bounds__(256) void corr_recheck_merge_kernel(int P, int rsplit, CorrWs ws,
+                                                                 int32_t* __restrict__ idx) {
+  const int cnt = *ws.rcount;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += gridDim.x * blockDim.x) {
+    double best = -__builtin_inf();
+    int bi = -1;
+    for (int r = 0; r < rsplit; ++r) {
+      const int i = ws.ridx[(size_t)r * P + e];
+      const double v = ws.rval[(size_t)r * P + e];
+      if (i >= 0 && (bi < 0 || v > best)) { best = v; bi = i; }
+    }
+    if (bi >= 0) idx[ws.rlist[e]] = bi;
+  }
+}
+
+// ------------------------------------------------------------------------------------ plan
+constexpr int kMaxSplit = 64;     // upper bound on key ranges per launch
+constexpr int kSlotCap = 2048;    // device-independent cap on the resident-workgroup estimate
 
 struct CorrPlan {
-  int qblocks, nsplit, split_len;
+  int qblocks, nchunks, nsplit, range_chunks, rsplit;
 };
 
-// Work units = (query block, key range).  Splitting the key range costs VALU work: every split
-// restarts its running maximum, and the arg-max update path (taken whenever ANY of a wave's 64
-// lanes improves, i.e. for ~64(1 + ln(tiles/64)) of a split's tiles) is the expensive part of the
-// epilogue — measured: 23 splits raised VALU instructions per tile from ~75 to 113.  So the range
-// is split only when the query blocks alone cannot fill the machine (small P, e.g. the
-// reference's 75x75 crops), and then just enough to give every resident slot one unit.
-// Launch tails of large-P calls are hidden by the caller pipelining images over streams.
+inline int max_split_for(int qblocks, int nchunks) {
+  int ns = (kSlotCap + qblocks - 1) / qblocks;
+  if (ns > nchunks) ns = nchunks;
+  if (ns > kMaxSplit) ns = kMaxSplit;
+  return ns < 1 ? 1 : ns;
+}
+
+// Work units = (query block, key range of whole chunks).  The range is split only when the query
+// blocks alone cannot fill the machine (small P, e.g. the reference's 75x75 crops), and then just
+// enough to give every resident slot one unit: every range pays its own row recovery and partials.
+// The split changes which workgroup computes a chunk, never a chunk's arithmetic.
 CorrPlan make_plan(int P, int N, int slots, int q_per_block) {
   CorrPlan p;
   p.qblocks = (P + q_per_block - 1) / q_per_block;
-  const int max_split = (N + kTK - 1) / kTK;
+  p.nchunks = (N + kChunk - 1) / kChunk;
+  if (slots > kSlotCap) slots = kSlotCap;
   int ns = 1;
   if (p.qblocks < slots) ns = (slots + p.qblocks - 1) / p.qblocks;
-  if (ns > max_split) ns = max_split;
-  if (ns > kMaxSplit) ns = kMaxSplit;
-  const int stages = (max_split + ns - 1) / ns;
-  p.split_len = stages * kTK;
-  p.nsplit = (N + p.split_len - 1) / p.split_len;
+  const int cap = max_split_for(p.qblocks, p.nchunks);
+  if (ns > cap) ns = cap;
+  p.range_chunks = (p.nchunks + ns - 1) / ns;
+  p.nsplit = (p.nchunks + p.range_chunks - 1) / p.range_chunks;
+  const int nstage = (N + kTK - 1) / kTK;
+  p.rsplit = nstage < kRSplitMax ? nstage : kRSplitMax;
   return p;
 }
 
@@ -599,112 +733,155 @@ int resident_slots(Kern kern) {
 
 int slots_for(int dtype, int D) {
   // cached per (kernel family, padded D): the occupancy query costs tens of microseconds
-  static int cache[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  static int cache[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   int v = 0;
   if (dtype != ISR_DTYPE_F32) v = (D <= 16) ? 0 : (D <= 32) ? 1 : (D <= 64) ? 2 : 3;
-  else v = (D <= 8) ? 0 : (D <= 16) ? 1 : (D <= 32) ? 2 : 3;
+  else v = (D <= 8) ? 0 : (D <= 16) ? 1 : (D <= 32) ? 2 : (D <= 64) ? 3 : 4;
   int& c = cache[dtype == ISR_DTYPE_F32 ? 1 : dtype == ISR_DTYPE_BF16_LOG2 ? 2 : 0][v];
   if (c == 0) {
     if (dtype == ISR_DTYPE_BF16_LOG2) {
-      c = v == 0 ? resident_slots(corr_bf16_direct_kernel<1, kQBbf16, false>)
-        : v == 1 ? resident_slots(corr_bf16_direct_kernel<2, kQBbf16, false>)
-        : v == 2 ? resident_slots(corr_bf16_direct_kernel<4, kQBbf16, false>)
-                 : resident_slots(corr_bf16_direct_kernel<8, 2, false>);
+      c = v == 0 ? resident_slots(corr_bf16_direct_kernel<1, kQB, false>)
+        : v == 1 ? resident_slots(corr_bf16_direct_kernel<2, kQB, false>)
+        : v == 2 ? resident_slots(corr_bf16_direct_kernel<4, kQB, false>)
+                 : resident_slots(corr_bf16_direct_kernel<8, kQB, false>);
     } else if (dtype != ISR_DTYPE_F32) {
-      c = v == 0 ? resident_slots(corr_bf16_direct_kernel<1, kQBbf16, true>)
-        : v == 1 ? resident_slots(corr_bf16_direct_kernel<2, kQBbf16, true>)
-        : v == 2 ? resident_slots(corr_bf16_direct_kernel<4, kQBbf16, true>)
-                 : resident_slots(corr_bf16_direct_kernel<8, 2, true>);
+      c = v == 0 ? resident_slots(corr_bf16_direct_kernel<1, kQB, true>)
+        : v == 1 ? resident_slots(corr_bf16_direct_kernel<2, kQB, true>)
+        : v == 2 ? resident_slots(corr_bf16_direct_kernel<4, kQB, true>)
+                 : resident_slots(corr_bf16_direct_kernel<8, kQB, true>);
     } else {
       c = v == 0 ? resident_slots(corr_f32_kernel<8>) : v == 1 ? resident_slots(corr_f32_kernel<16>)
-        : v == 2 ? resident_slots(corr_f32_kernel<32>) : resident_slots(corr_f32_kernel<64>);
+        : v == 2 ? resident_slots(corr_f32_kernel<32>) : v == 3 ? resident_slots(corr_f32_kernel<64>)
+                 : resident_slots(corr_f32_kernel<128>);
     }
   }
   return c;
 }
 
-// upper bound on nsplit for the workspace query (which must not depend on the device)
+// carve the workspace for the worst plan the call can take (the split bound does not depend on the device)
+size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
+  const int qblocks = (P + kWaves * kQB * 32 - 1) / (kWaves * kQB * 32);
+  const int nchunks = (N + kChunk - 1) / kChunk;
+  const int ns = max_split_for(qblocks, nchunks);
+  const int nstage = (N + kTK - 1) / kTK;
+  const int rs = nstage < kRSplitMax ? nstage : kRSplitMax;
+  const bool bf16 = dtype != ISR_DTYPE_F32;
+  o->pm = w.take<float>((size_t)ns * P);
+  o->pbi = w.take<int32_t>((size_t)ns * P);
+  o->plc = w.take<float>((size_t)nchunks * P);
+  o->pmc = w.take<float>((size_t)nchunks * P);
+  o->pm2 = bf16 ? w.take<float>((size_t)ns * P) : nullptr;
+  o->pbad = bf16 ? w.take<int32_t>((size_t)ns * P) : nullptr;
+  o->qn2 = bf16 ? w.take<float>(P) : nullptr;
+  o->flags = bf16 ? w.take<int32_t>((size_t)ns * qblocks) : nullptr;
+  o->kn2 = bf16 ? w.take<float>(kKnBlocks) : nullptr;
+  o->rcount = bf16 ? w.take<int32_t>(4) : nullptr;
+  o->rlist = bf16 ? w.take<int32_t>(P) : nullptr;
+  o->rval = bf16 ? w.take<double>((size_t)rs * P) : nullptr;
+  o->ridx = bf16 ? w.take<int32_t>((size_t)rs * P) : nullptr;
+  return w.off;
+}
+
 }  // namespace
 
 extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype) {
-  (void)D; (void)dtype;
+  (void)D;
   if (P <= 0 || N <= 0) return 0;
-  const int max_split = (N + kTK - 1) / kTK;
-  const int ns = max_split < kMaxSplit ? max_split : kMaxSplit;
-  const size_t nflags = (size_t)ns * ((size_t)P / (kWaves * 32) + 2);   // one per (query block, key range)
-  return 4 * isr::align_up((size_t)ns * P * 4, 256) + isr::align_up(nflags * 4, 256) + 256;
+  isr::Workspace w(nullptr, 0);
+  CorrWs o;
+  return carve(w, P, N, dtype, &o) + 256;
+}
+
+// Diagnostics: how many queries of the LAST call that used this workspace (same P, N, dtype) went to
+// the exact recheck.  Synchronises the stream.  *count_host = -1 for the f32 path (no recheck).
+extern "C" int isr_corr_argmax_recheck_count(const void* ws_, size_t ws_bytes, int P, int N, int dtype,
+                                             int32_t* count_host, isr_stream_t stream_) {
+  ISR_REQUIRE(ws_ && count_host && P > 0 && N > 0, "isr_corr_argmax_recheck_count: bad argument");
+  ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, 0, dtype), "isr_corr_argmax_recheck_count: workspace too small");
+  *count_host = -1;
+  if (dtype == ISR_DTYPE_F32) return ISR_OK;
+  isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
+  CorrWs ws;
+  carve(w, P, N, dtype, &ws);
+  hipStream_t stream = isr::as_stream(stream_);
+  ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.rcount, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  ISR_CHECK_HIP(hipStreamSynchronize(stream));
+  return ISR_OK;
 }
 
 extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
-                               int dtype, int32_t* idx, float* logp, float* lse, void* ws,
+                               int dtype, int32_t* idx, float* logp, float* lse, void* ws_,
                                size_t ws_bytes, isr_stream_t stream_) {
   ISR_REQUIRE(Q && K && idx, "isr_corr_argmax: null pointer");
   ISR_REQUIRE(P > 0 && N > 0 && D > 0, "isr_corr_argmax: P=%d N=%d D=%d must be positive", P, N, D);
   ISR_REQUIRE(ldq >= D && ldk >= D, "isr_corr_argmax: ldq=%d ldk=%d < D=%d", ldq, ldk, D);
-  if (!ws || ws_bytes < isr_corr_argmax_workspace_bytes(P, N, D, dtype)) {
+  ISR_REQUIRE(dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2 || dtype == ISR_DTYPE_F32,
+              "isr_corr_argmax: dtype %d", dtype);
+  if (!ws_ || ws_bytes < isr_corr_argmax_workspace_bytes(P, N, D, dtype)) {
     isr::set_error("isr_corr_argmax: workspace %zu < %zu", ws_bytes,
                    isr_corr_argmax_workspace_bytes(P, N, D, dtype));
     return ISR_ERR_WORKSPACE;
   }
   hipStream_t stream = isr::as_stream(stream_);
-  const int qb_wave = (dtype != ISR_DTYPE_F32 && D <= 64) ? kQBbf16 : 2;
-  const CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * qb_wave * 32);
-  isr::Workspace w(ws, ws_bytes);
-  float* pm = w.take<float>((size_t)p.nsplit * P);
-  float* pM2 = w.take<float>((size_t)p.nsplit * P);
-  float* pl = w.take<float>((size_t)p.nsplit * P);
-  int32_t* pbi = w.take<int32_t>((size_t)p.nsplit * P);
-  int32_t* flags = w.take<int32_t>((size_t)p.nsplit * p.qblocks);
+  const CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * kQB * 32);
+  isr::Workspace w(ws_, ws_bytes);
+  CorrWs ws;
+  carve(w, P, N, dtype, &ws);
   const dim3 grid(p.qblocks, p.nsplit);
+  const int fin_blocks = (P + 255) / 256;
 
   if (dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2) {
     ISR_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128,
                 "isr_corr_argmax(bf16): D=%d must be 16, 32, 64 or 128 (zero-pad the columns)", D);
     ISR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0),
                 "isr_corr_argmax(bf16): rows must be 16-byte aligned (ldq=%d ldk=%d)", ldq, ldk);
-    ISR_REQUIRE((long long)p.split_len * ldk * 2 < (1ll << 31),
+    ISR_REQUIRE((long long)p.range_chunks * kChunk * ldk * 2 < (1ll << 31),
                 "isr_corr_argmax(bf16): a key range of %d rows x ldk=%d exceeds the 2 GiB buffer window",
-                p.split_len, ldk);
+                p.range_chunks * kChunk, ldk);
     const uint16_t* q = static_cast<const uint16_t*>(Q);
     const uint16_t* k = static_cast<const uint16_t*>(K);
-#define ISR_LAUNCH_BF16(DKv, QBv)                                                                         \
-  do {                                                                                                    \
-    if (dtype == ISR_DTYPE_BF16_LOG2) {                                                                   \
-      corr_bf16_direct_kernel<DKv, QBv, false><<<grid, kThreads, 0, stream>>>(                            \
-          q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi, flags);                                    \
-      corr_bf16_kernel<DKv, QBv, true><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, \
-                                                                      pm, pM2, pl, pbi, flags);            \
-    } else {                                                                                              \
-      corr_bf16_direct_kernel<DKv, QBv, true><<<grid, kThreads, 0, stream>>>(                             \
-          q, k, P, N, ldq, ldk, p.split_len, pm, pM2, pl, pbi, flags);                                    \
-      corr_bf16_kernel<DKv, QBv, false><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.split_len, \
-                                                                       pm, pM2, pl, pbi, flags);           \
-    }                                                                                                     \
+    const bool log2 = dtype == ISR_DTYPE_BF16_LOG2;
+    const dim3 cgrid(p.qblocks, p.nchunks);       // fallback: one canonical chunk per workgroup
+    const dim3 rgrid(256, p.rsplit);
+    const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
+    corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, ws);
+#define ISR_LAUNCH_BF16(DKv)                                                                                  \
+  do {                                                                                                        \
+    if (log2) {                                                                                               \
+      corr_bf16_direct_kernel<DKv, kQB, false><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,          \
+                                                                              p.range_chunks, ws);           \
+      corr_bf16_kernel<DKv, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws);  \
+      corr_finalize_kernel<1><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
+                                                              idx, logp, lse);                               \
+    } else {                                                                                                  \
+      corr_bf16_direct_kernel<DKv, kQB, true><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,           \
+                                                                             p.range_chunks, ws);            \
+      corr_bf16_kernel<DKv, false><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws); \
+      corr_finalize_kernel<2><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
+                                                              idx, logp, lse);                               \
+    }                                                                                                         \
+    corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, ws);      \
   } while (0)
     switch (D) {
-      case 16: ISR_LAUNCH_BF16(1, kQBbf16); break;
-      case 32: ISR_LAUNCH_BF16(2, kQBbf16); break;
-      case 64: ISR_LAUNCH_BF16(4, kQBbf16); break;
-      default: ISR_LAUNCH_BF16(8, 2); break;
+      case 16: ISR_LAUNCH_BF16(1); break;
+      case 32: ISR_LAUNCH_BF16(2); break;
+      case 64: ISR_LAUNCH_BF16(4); break;
+      default: ISR_LAUNCH_BF16(8); break;
     }
 #undef ISR_LAUNCH_BF16
-  } else if (dtype == ISR_DTYPE_F32) {
-    ISR_REQUIRE(D <= 64, "isr_corr_argmax(f32): D=%d > 64", D);
+    corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, p.rsplit, ws, idx);
+    ISR_CHECK_LAUNCH("corr bf16 kernels");
+  } else {
+    ISR_REQUIRE(D <= 128, "isr_corr_argmax(f32): D=%d > 128", D);
     const float* q = static_cast<const float*>(Q);
     const float* k = static_cast<const float*>(K);
-    if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.split_len, pm, pM2, pl, pbi);
-    else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.split_len, pm, pM2, pl, pbi);
-    else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.split_len, pm, pM2, pl, pbi);
-    else corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.split_len, pm, pM2, pl, pbi);
-  } else {
-    isr::set_error("isr_corr_argmax: dtype %d", dtype);
-    return ISR_ERR_ARG;
+    if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 64) corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else corr_f32_kernel<128><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    corr_finalize_kernel<0><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
+    ISR_CHECK_LAUNCH("corr f32 kernels");
   }
-  ISR_CHECK_LAUNCH("corr kernel");
-  if (dtype == ISR_DTYPE_BF16_LOG2)
-    corr_finalize_l2_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, p.nsplit, pm, pM2, pl, pbi, idx, logp, lse);
-  else
-    corr_finalize_kernel<<<(P + 255) / 256, 256, 0, stream>>>(P, p.nsplit, pm, pM2, pl, pbi, idx, logp, lse);
-  ISR_CHECK_LAUNCH("corr_finalize_kernel");
   return ISR_OK;
 }

@@ -1,64 +1,56 @@
 // corr_direct.hpp — corr_bf16_direct_kernel, the fast path of K1 for bf16 descriptors.  Included by
 // corr_argmax.hip inside its anonymous namespace after the shared pieces (vector types, kThreads /
-// kWaves / kTK / kLog2e, max3, splat16, mask_tail, better); corr_bf16_kernel in that file is its
-// flagged per-workgroup fallback and both write the same partials.
+// kWaves / kTK / kChunk / kLog2e, CorrWs, max3, splat16, mask_tail, better); corr_bf16_kernel in that
+// file is its per-query fallback.
 #pragma once
 
-// -------------------------------------------------------------- bf16, log2 domain, direct sums
-// The fast path of ISR_DTYPE_BF16_LOG2.  The loop above is bound by VALU issue (81 % busy, PMC), so
-// this one carries the fewest per-element instructions the math allows: with logits already in log2
-// units, l = sum 2^(s' - S) needs exp2 + add per element once the reference S is WAVE-uniform: it
-// rides in the C operand of the first MFMA of every chain (one 16-register tile shared by the wave's
-// two query blocks), so the accumulator already holds s' - S.  S is set from the wave's first tile
-// so that the largest logit sits at +kAnchor, and is bumped
-// (checked once per 128-key stage, taken a handful of times per launch at most) when a lane's
-// running maximum passes +kBump: l is rescaled by an exact power of two.  Every term that matters
-// relative to 2^m is a normal f32 as long as the lane's maximum ends above kLow (relative to the
-// wave's reference), and an overflow (a jump of ~100 log2 units within one stage) leaves l = inf.
-// A workgroup with such a lane — maxima of neighbouring pixels more than ~120 log2 units apart, or
-// that jump — raises its flag, and the per-query-reference kernel above (launched right behind,
-// returning at once for unflagged workgroups) redoes it: results never depend on the range
-// assumption.
-// Arg-max: the loop records only (m, first tile that reached m) — two instructions, no branch; the
-// row inside the winning tile is found after the loop by running that one tile through the MFMA
-// chain again with C = 0: the decision inside the tile and the reported maximum are unshifted
-// logits, so equal keys compare equal whatever wave or key range saw them (lowest key on ties as
-// everywhere; only the choice BETWEEN tiles is made on shifted values).
-constexpr float kAnchor = 24.f;    // log2 units: where the wave's largest logit is put
-constexpr float kBump = 64.f;      // a running maximum above this moves the reference
-constexpr float kLow = -100.f;     // below: terms of the sum may have been flushed -> fallback
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
+// -------------------------------------------------------------- bf16, direct sums, fixed reference
+// The loop is bound by VALU issue (PMC: ~80 % busy), so it carries the fewest per-element
+// instructions the math allows: with logits in log2 units, l = sum 2^s' is exp2 + add per element —
+// no reference subtraction at all.  The reference of the log-sum-exp is the CONSTANT 0, so what a
+// query's sums are made of depends on the query and the keys only, never on its wave-mates or on
+// the launch (round 1 anchored the reference on the wave's first tile: results then moved by ~1e-5
+// with the launch shape, enough to flip the strict `>` of the top-80 % cut, inference.py:282-290).
+// Canonical order of the sum: keys are cut into CHUNKS of kChunk = 2048 (a constant); inside a
+// chunk each of the query's two lanes adds its 16 rows per 32-key tile in register order, tile
+// after tile, in f32; the two lane sums are added; the chunk sums go to memory and
+// corr_finalize_kernel adds them in ascending order in f64.  A workgroup may own any number of
+// whole chunks (the plan splits the key range only when the query blocks alone cannot fill the
+// chip): the grouping of chunks into workgroups never enters the arithmetic.
+// Range: 2^s' is a normal f32 for -126 <= s' < 128.  A query whose maximum lies below kLow (terms
+// that matter relative to the maximum could flush) or whose chunk sum overflows is marked bad and
+// redone by the per-query-reference kernel (corr_bf16_kernel, same canonical chunks) — per QUERY,
+// so a good query's result does not depend on its neighbours being good.
+// Arg-max: the loop records, per lane, the two largest tile maxima (v_med3 keeps the runner-up) and
+// the first tile that reached the maximum; the row inside the winning tile is found after the loop
+// by running that one tile through the MFMA chain again.  All comparisons are on raw MFMA outputs
+// (C = 0): a given (query, key) pair yields the same f32 logit wherever it is computed.
+// The runner-up bounds the top-2 margin; corr_finalize_kernel sends queries whose margin is inside
+// the f32 accumulation error bound to corr_recheck_kernel, which decides them in exact arithmetic.
+constexpr float kLow = -100.f;     // log2 units: a maximum below this sends the query to the fallback
 
 struct DirectState {
-  float m;   // running max of s' - S (log2 units)
-  float l;   // sum 2^(s' - S)
+  float m;   // largest tile maximum so far (raw logit)
+  float m2;  // second largest tile maximum (with multiplicity)
+  float l;   // sum 2^(s') over the current chunk
   int tb;    // first key of the first 32-key tile whose maximum reached m
 };
 
-// max(m, the 16 logits of the tile) in eight v_max3_f32
-__device__ __forceinline__ float tile_max_with(const f32x16& acc, float m) {
+// max of the 16 logits of a tile: seven v_max3_f32 + one v_max_f32
+__device__ __forceinline__ float tile_max(const f32x16& acc) {
   const float x0 = max3(acc[0], acc[1], acc[2]), x1 = max3(acc[3], acc[4], acc[5]),
               x2 = max3(acc[6], acc[7], acc[8]), x3 = max3(acc[9], acc[10], acc[11]),
               x4 = max3(acc[12], acc[13], acc[14]);
-  return max3(max3(x0, x1, x2), max3(x3, x4, acc[15]), m);
+  return fmaxf(max3(x0, x1, x2), max3(x3, x4, acc[15]));
 }
 
-// NAT = false: log2-unit logits (ISR_DTYPE_BF16_LOG2), reference in the MFMA C operand.
-// NAT = true:  natural-unit logits (ISR_DTYPE_BF16): the accumulator stays raw (C = 0) and the
-//   wave-uniform integer reference S (log2 units) enters through the one-rounding
-//   exp2(fma(s, log2 e, -S)) — one more VALU instruction per element than the log2 path, still
-//   without the per-query reference, its rescale branch and the in-loop arg-max update of
-//   corr_bf16_kernel.  The running maximum is then the raw logit itself.
+// NAT = false: log2-unit logits (ISR_DTYPE_BF16_LOG2): l += exp2(s').
+// NAT = true:  natural-unit logits (ISR_DTYPE_BF16):   l += exp2(s * log2 e) — one multiply more per
+//   element.  Maxima are raw logits in either case.
 template <int DK, int QB, bool NAT>
 __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
-    int split_len, float* __restrict__ pm, float* __restrict__ pM2, float* __restrict__ pl,
-    int32_t* __restrict__ pbi, int32_t* __restrict__ flags) {
+    int range_chunks, CorrWs ws) {
   constexpr int NCH = 2 * DK;
   constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;
   constexpr int CHUNKS = kTK * NCH;
@@ -80,12 +72,32 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
 #pragma unroll
     for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
   }
+  // |q|^2 for the error bound of the margin test (f32, upper bound to rounding; finalize inflates it)
+  if (split == 0) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      float n2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < DK; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float v = __uint_as_float((uint32_t)(uint16_t)bq[qb][s][e] << 16);
+          n2 = __builtin_fmaf(v, v, n2);
+        }
+      n2 += __shfl_xor(n2, 32, 64);
+      const int q = q0 + qb * 32 + r;
+      if (h == 0 && q < P) ws.qn2[q] = n2;
+    }
+  }
   DirectState st[QB];
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) { st[qb].m = -__builtin_inff(); st[qb].l = 0.f; st[qb].tb = 0; }
+  for (int qb = 0; qb < QB; ++qb) {
+    st[qb].m = -__builtin_inff(); st[qb].m2 = -__builtin_inff(); st[qb].l = 0.f; st[qb].tb = 0;
+  }
 
-  const int k0 = split * split_len;
-  const int k1 = min(N, k0 + split_len);
+  const int c0 = split * range_chunks;                 // first canonical chunk of this key range
+  const int k0 = c0 * kChunk;
+  const int k1 = min(N, k0 + range_chunks * kChunk);
   const int nstage = (k1 - k0 + kTK - 1) / kTK;
   const int nfull = (k1 - k0) / kTK;                  // stages whose kTK keys all exist
 
@@ -130,9 +142,9 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     }
   };
 
-  // Same software pipeline as corr_bf16_kernel: item w's epilogue runs under item w + 1's MFMAs.
-  // The stage barrier sits two items before the stage's end (every LDS read of the stage has been
-  // issued by then), so the next stage's first fragments are a full item ahead too.
+  // Software pipeline: item w's epilogue runs under item w + 1's MFMAs.  The stage barrier sits two
+  // items before the stage's end (every LDS read of the stage has been issued by then), so the next
+  // stage's first fragments are a full item ahead too.
   constexpr int NSUB = kTK / 32, NW = NSUB * QB;
   static_assert(QB == 2 && NSUB % 2 == 0, "item schedule below is written for two query blocks per wave");
   gload(0);
@@ -143,19 +155,6 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   acc[0] = splat16(0.f);
 #pragma unroll
   for (int s = 0; s < DK; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[0][s], acc[0], 0, 0, 0);
-
-  // reference from the first tile (rows >= k1 of a short range are zero rows: logit 0, harmless here)
-  constexpr float kUnit = NAT ? kLog2e : 1.0f;         // log2 units per logit unit
-  float S = ceilf(wave_max(tile_max_with(acc[0], -__builtin_inff())) * kUnit) - kAnchor;
-  S = fminf(fmaxf(S, -3.0e38f), 3.0e38f);
-  f32x16 cS = splat16(NAT ? 0.f : -S);
-  if (!NAT) {
-    asm volatile("" : "+v"(cS));        // one resident tile, not sixteen moves per chain
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[0][i] -= S;
-  }
-  float nS = -S;                        // NAT: the addend of the exp2 argument
-  float bump_at = NAT ? (S + kBump) * 0.6931471805599453f : kBump;   // running maximum that moves S
 
   auto stage_body = [&](int stage, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
@@ -177,8 +176,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], kb + 4 * h, k1);
         const f32x16& cur = acc[w & 1];
         f32x16& nxt = acc[(w + 1) & 1];
-        if (NAT) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[qbn][0], splat16(0.f), 0, 0, 0);
-        else nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[qbn][0], cS, 0, 0, 0);
+        nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[qbn][0], splat16(0.f), 0, 0, 0);
 #pragma unroll
         for (int s = 1; s < DK; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qbn][s], nxt, 0, 0, 0);
         if (qb == 0) {                                    // the chain above was the fragments' last reader
@@ -187,11 +185,12 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         }
 #ifdef ISR_ABL_DNOMAX   // timing-only ablations (tools/ablate_direct.sh): keep the accumulator live
         asm volatile("" :: "v"(cur[0]), "v"(cur[15]));
-        st[qb].m = 0.f;      // inside the range check: no fallback launch work
+        st[qb].m = 0.f;
 #else
-        const float mn = tile_max_with(cur, st[qb].m);
-        st[qb].tb = (mn > st[qb].m) ? kb : st[qb].tb;  // strict: the first tile to reach m keeps it
-        st[qb].m = mn;
+        const float t = tile_max(cur);
+        st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);   // second largest of {m, m2, t} (m2 <= m)
+        st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;                     // strict: the first tile to reach m keeps it
+        st[qb].m = fmaxf(st[qb].m, t);
 #endif
         float l = st[qb].l;
 #ifdef ISR_ABL_DNOEXP
@@ -200,60 +199,49 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
 #else
 #pragma unroll
         for (int i = 0; i < 16; ++i)
-          l += __builtin_amdgcn_exp2f(NAT ? __builtin_fmaf(cur[i], kLog2e, nS) : cur[i]);
+          l += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
 #endif
         st[qb].l = l;
-        // issue order: the item's 42 VALU instructions (8 max3, 2 record, 16 exp2, 16 add; NAT: 16
-        // fma more) spread evenly behind the DK MFMAs of the next item.  The empty asm ties the
-        // item's results to a fixed point of the instruction stream: a stage is one basic block, and
-        // without it instruction selection sinks all eight epilogues below all eight MFMA chains
-        // (eight tiles live, 243 VGPRs, nothing overlapped).
-        constexpr int G = ((NAT ? 58 : 42) + DK - 1) / DK;
+        // issue order: the item's 44 VALU instructions (7 max3 + max, med3, cmp, cndmask, max, 16 exp2,
+        // 16 add; NAT: 16 mul more) spread evenly behind the DK MFMAs of the next item.  The empty asm
+        // ties the item's results to a fixed point of the instruction stream: a stage is one basic
+        // block, and without it instruction selection sinks all eight epilogues below all eight MFMA
+        // chains (eight tiles live, 243 VGPRs, nothing overlapped).
+        constexpr int G = ((NAT ? 60 : 44) + DK - 1) / DK;
 #pragma unroll
         for (int s = 0; s < DK; ++s) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           if (qb == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // this fragment's next ds_read
           __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
         }
-        asm volatile("" : "+v"(nxt), "+v"(st[qb].l), "+v"(st[qb].m), "+v"(st[qb].tb));
+        asm volatile("" : "+v"(nxt), "+v"(st[qb].l), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // reference upkeep, once per stage (wave-uniform, rare): acc[0] is the tile in flight
-    const float mm = fmaxf(st[0].m, st[1].m);
-    if (__any(mm > bump_at)) {
-      const float top = ceilf(wave_max(mm) * kUnit);      // log2 units; NAT: absolute, else relative to S
-      const float d = fminf(NAT ? top - kAnchor - S : top - kAnchor, 3.0e38f);
-      S += d;
-      const float sc = __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb) st[qb].l *= sc;     // an overflowed l stays inf
-      if (NAT) {
-        nS = -S;
-        bump_at = (S + kBump) * 0.6931471805599453f;
-      } else {
-        cS = splat16(-S);
-        asm volatile("" : "+v"(cS));
-#pragma unroll
-        for (int qb = 0; qb < QB; ++qb) st[qb].m -= d;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[0][i] -= d;
-      }
-    }
   };
-  for (int stage = 0; stage < nfull; ++stage) stage_body(stage, std::true_type{});
-  if (nfull < nstage) stage_body(nfull, std::false_type{});
 
-  // ---- range check: any lane outside the direct-sum range sends the workgroup to the fallback
-  bool bad = false;
+  // canonical chunks: kChunkStages stages each; the sums of a chunk leave the registers at its end
+  bool over[QB];
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb)
-    bad |= !((NAT ? __builtin_fmaf(st[qb].m, kLog2e, -S) : st[qb].m) >= kLow && st[qb].l <= 3.0e38f);
-  const int any_bad = __syncthreads_or(bad ? 1 : 0);
-  if (tid == 0) flags[blockIdx.y * gridDim.x + blockIdx.x] = any_bad;
-  if (any_bad) return;   // block-uniform; the fallback kernel writes this workgroup's partials
+  for (int qb = 0; qb < QB; ++qb) over[qb] = false;
+  int stage = 0;
+  for (int c = c0; stage < nstage; ++c) {
+    const int send = min(nstage, stage + kChunkStages);
+    const int sfull = min(nfull, send);
+    for (; stage < sfull; ++stage) stage_body(stage, std::true_type{});
+    if (stage < send) { stage_body(stage, std::false_type{}); ++stage; }   // only a range's last stage is partial
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const float lc = st[qb].l + __shfl_xor(st[qb].l, 32, 64);
+      over[qb] |= !(lc <= 3.0e38f);     // the same on both lanes of the query
+      const int q = q0 + qb * 32 + r;
+      if (h == 0 && q < P) ws.plc[(size_t)c * P + q] = lc;
+      st[qb].l = 0.f;
+    }
+  }
 
   // ---- row recovery: one MFMA chain per distinct winning tile of the wave's queries
+  bool any_bad_lane = false;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     // the two lanes (h = 0, 1) of a query agree on (M, T): the maximum and the lowest tile reaching it
@@ -262,7 +250,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     const float M = fmaxf(st[qb].m, mo);
     const int T = (st[qb].m == M) ? ((mo == M) ? min(st[qb].tb, tbo) : st[qb].tb) : tbo;
     int cand = T;
-    float cmax = -__builtin_inff();
+    float cmax = -__builtin_inff(), c2 = -__builtin_inff();
     unsigned long long todo = __ballot(true);
     auto fetch = [&](int kb, bf16x8 (&dst)[DK]) {
       int row = kb + r;
@@ -287,7 +275,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       for (int s = 0; s < DK; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s], bq[qb][s], c, 0, 0, 0);
       if (kb_cur + 32 > k1) mask_tail(c, kb_cur + 4 * h, k1);
       if (T == kb_cur) {
-        cmax = tile_max_with(c, -__builtin_inff());
+        // the two largest of this lane's 16 rows (with multiplicity) and the lowest row of the largest
+        float a1v = -__builtin_inff(), a2v = -__builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          a2v = __builtin_amdgcn_fmed3f(a1v, a2v, c[i]);
+          a1v = fmaxf(a1v, c[i]);
+        }
+        cmax = a1v; c2 = a2v;
         int rr = 15;
 #pragma unroll
         for (int i = 14; i >= 0; --i) rr = (c[i] == cmax) ? i : rr;   // lowest register = lowest key
@@ -298,18 +293,26 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       for (int s = 0; s < DK; ++s) a0[s] = a1[s];
       kb_cur = kb_nxt;
     }
+    // runner-up of the query inside this key range.  The lane that owns the winner contributes its
+    // second tile maximum and the second row of the winning tile, the other lane its best.
     const int co = __shfl_xor(cand, 32, 64);
     const float cmo = __shfl_xor(cmax, 32, 64);
-    if (better(cmo, co, cmax, cand)) { cand = co; cmax = cmo; }
-    const float lo = __shfl_xor(st[qb].l, 32, 64);
+    const bool other_wins = better(cmo, co, cmax, cand);
+    const float mine = other_wins ? st[qb].m : fmaxf(st[qb].m2, c2);
+    const float run = fmaxf(mine, __shfl_xor(mine, 32, 64));
+    if (other_wins) { cand = co; cmax = cmo; }
+    const float mlog2 = NAT ? cmax * kLog2e : cmax;
+    const bool bad_q = over[qb] || !(mlog2 >= kLow);      // the same on both lanes of the query
     const int q = q0 + qb * 32 + r;
     if (h == 0 && q < P) {
       const size_t off = (size_t)split * P + q;
-      pm[off] = cmax;             // the unshifted logit: equal keys compare equal across waves and ranges
-      pM2[off] = S;
-      pl[off] = st[qb].l + lo;
-      pbi[off] = cand;
+      ws.pm[off] = cmax;
+      ws.pm2[off] = run;
+      ws.pbi[off] = cand;
+      ws.pbad[off] = bad_q ? 1 : 0;
     }
+    any_bad_lane |= bad_q && q < P;
   }
+  const int any_bad = __syncthreads_or(any_bad_lane ? 1 : 0);
+  if (tid == 0) ws.flags[blockIdx.y * gridDim.x + blockIdx.x] = any_bad;
 }
-

@@ -173,8 +173,8 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
         dtype = _capi.DTYPE_F32
         queries, keys = queries.to(torch.float32), keys.to(torch.float32)
         Dp = D
-        if D > 64:
-            raise ValueError(f"f32 path supports D <= 64, got {D}")
+        if D > 128:
+            raise ValueError(f"f32 path supports D <= 128, got {D}")
     q, k = _pad_cols(queries, Dp), _pad_cols(keys, Dp)
     idx = torch.empty(P, dtype=torch.int32, device=dev)
     logp = torch.empty(P, dtype=torch.float32, device=dev)
@@ -186,7 +186,27 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
         rc = L.isr_corr_argmax(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, ptr(idx), ptr(logp), ptr(lse),
                                ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_corr_argmax")
+    global _last_corr
+    _last_corr = (ws, P, N, dtype, dev)
     return (idx, logp, lse) if want_lse else (idx, logp)
+
+
+_last_corr = None
+
+
+def corr_recheck_count() -> int:
+    """Diagnostics: how many queries of the last corr_argmax call were decided by the exact recheck
+    (-1 on the f32 path).  Synchronises the current stream."""
+    import ctypes
+    if _last_corr is None:
+        return -1
+    ws, P, N, dtype, dev = _last_corr
+    out = ctypes.c_int32(-1)
+    with torch.cuda.device(dev):
+        rc = lib().isr_corr_argmax_recheck_count(ptr(ws), ws.numel(), P, N, dtype, ctypes.addressof(out),
+                                                 current_stream(dev))
+    check(rc, "isr_corr_argmax_recheck_count")
+    return int(out.value)
 
 
 def select_top(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500, n_dev: torch.Tensor | None = None):

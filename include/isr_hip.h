@@ -38,9 +38,8 @@ extern "C" {
 #define ISR_DTYPE_BF16 0 /* bf16 inputs, v_mfma_f32_32x32x16_bf16, f32 accumulate */
 #define ISR_DTYPE_F32 1  /* f32 inputs, v_mfma_f32_32x32x2_f32: k-ordered fmaf chain, bit-exact */
 #define ISR_DTYPE_BF16_LOG2 2 /* bf16 inputs whose QUERIES were multiplied by log2(e) before their one
-                                rounding to bf16: logits are in log2 units inside the kernel (no multiply
-                                before exp2, the wave's log-sum-exp reference rides in the MFMA C
-                                operand) — the fastest path; outputs stay natural-log */
+                                rounding to bf16: logits are in log2 units inside the kernel (exp2 + add
+                                per element, nothing else) — the fastest path; outputs stay natural-log */
 
 typedef void* isr_stream_t; /* hipStream_t */
 
@@ -55,9 +54,12 @@ int isr_device_count(void);
  *           inference.py:142-149 (= finalposes.py:38-45 = choosePose.py:35-42),
  *           and the logsumexp-only use at pose_refine.py:56 (ask for `lse`).
  * Q (P, ldq) and K (N, ldk) row-major, element type by `dtype`; the first D columns are used.
- * D must be a multiple of 16 (bf16) / 2 (f32) and <= 256; ldq, ldk >= D and rows 16-byte aligned.
- * Outputs, per query row p:
- *   idx[p]  = argmax_n <Q[p],K[n]>   (lowest n on ties)
+ * D: 16, 32, 64 or 128 (bf16: zero-pad the columns) / any D <= 128 (f32); ldq, ldk >= D and (bf16) rows
+ * 16-byte aligned.
+ * Outputs, per query row p — functions of (Q[p], K) only, bit-identical whatever else is in the launch:
+ *   idx[p]  = argmax_n <Q[p],K[n]>   (lowest n on ties).  f32: of the k-ordered fmaf-chain logits; bf16:
+ *             of the EXACT logits (products of bf16 values summed without error: queries whose top-2
+ *             margin is inside the f32 accumulation error bound are re-decided in exact arithmetic)
  *   logp[p] = max_n logit - logsumexp_n logit   (= the top-1 value of log_softmax)
  *   lse[p]  = logsumexp_n logit      (nullable)
  * The (P x N) matrix is never materialised.
@@ -66,6 +68,11 @@ size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype);
 int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk, int dtype,
                     int32_t* idx, float* logp, float* lse, void* ws, size_t ws_bytes,
                     isr_stream_t stream);
+
+/* Diagnostics: number of queries the last isr_corr_argmax call on this workspace (same P, N, dtype)
+ * decided by the exact recheck; -1 for ISR_DTYPE_F32.  count_host is a HOST pointer; synchronises. */
+int isr_corr_argmax_recheck_count(const void* ws, size_t ws_bytes, int P, int N, int dtype,
+                                  int32_t* count_host, isr_stream_t stream);
 
 /* K1 materialising variant for small P: out (P, N) f32 = log_softmax(Q K^T) row-wise.
  * replaces poseEstSurf.py:70 (corr_matrix_log) and getCors with leaves > 1 (caller runs topk). */

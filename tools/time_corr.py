@@ -27,4 +27,5 @@ for name, q, l2 in cases:
         ops.corr_argmax(q, Kb, log2_prescaled=l2)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    print(f"{name}: P={P} N={N} D={D}  {ms:.3f} ms  {2.0*P*N*D/ms*1e-9:.1f} TFLOP/s  {P*N/ms*1e-9:.2f} Texp/s")
+    print(f"{name}: P={P} N={N} D={D}  {ms:.3f} ms  {2.0*P*N*D/ms*1e-9:.1f} TFLOP/s  {P*N/ms*1e-9:.2f} Texp/s"
+          f"  rechecked {ops.corr_recheck_count()} of {P}")
