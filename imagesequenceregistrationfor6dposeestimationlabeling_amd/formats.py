@@ -136,15 +136,31 @@ def read_scene_camera(path: Path | str):
     return [int(k) for k in keys], np.array([np.asarray(d[k]["cam_K"], np.float64).reshape(3, 3) for k in keys])
 
 
-def crop_camera(K, bbox_xywh, out_size: int = 224, pad: float = 1.2, down_sample: int = 3):
-    """a4 — the camera-matrix arithmetic of inference.py:212-222 and :260-263 (host, f64):
-    size = out/max(w,h)/pad; M = size*[I | -centre]; M[:,2] += out/2; cam = [M;0 0 1] @ K;
-    then the pixel-centre-preserving division by the ::down_sample subsampling."""
+def crop_affine(bbox_xywh, out_size: int = 224, pad: float = 1.2, even_size: bool = True) -> np.ndarray:
+    """The 2x3 crop affine M of inference.py:203-219 (host, f64): the bounding box of the visible
+    mask (cv2.boundingRect) is shrunk to even width / height (:203-206), then
+    size = out/max(w,h)/pad;  M = size * [I | -centre];  M[:,2] += out/2.
+    even_size=False skips the decrement for callers that already applied it."""
     x, y, w, h = bbox_xywh
+    if even_size:
+        if w % 2 != 0:
+            w = w - 1
+        if h % 2 != 0:
+            h = h - 1
     size = out_size / max(w, h) / pad
     c = np.array([x + w / 2.0, y + h / 2.0])
     M = np.concatenate([np.eye(2), -c[:, None]], axis=1) * size
     M[:, 2] += out_size / 2.0
+    return M
+
+
+def crop_camera(K, bbox_xywh, out_size: int = 224, pad: float = 1.2, down_sample: int = 3,
+                even_size: bool = True):
+    """a4 — the camera-matrix arithmetic of inference.py:203-222 and :260-263 (host, f64):
+    cam = [M; 0 0 1] @ K with M = crop_affine(bbox) (odd box sizes are decremented first, exactly as
+    the reference does with cv2.boundingRect's output), then the pixel-centre-preserving division
+    by the ::down_sample subsampling (camMat[:2,2] += .5; camMat[:2] /= ds; camMat[:2,2] -= .5)."""
+    M = crop_affine(bbox_xywh, out_size, pad, even_size)
     cam = np.vstack([M, [0, 0, 1]]) @ np.asarray(K, np.float64)
     cam[:2, 2] += 0.5
     cam[:2] /= down_sample

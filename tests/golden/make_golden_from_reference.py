@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/ref_*.npz by EXECUTING THE REFERENCE'S OWN CODE for the hot-path pieces
+that need nothing but torch / numpy / scikit-learn.
+
+Runs in the build container only (it reads /root/reference, which does not travel to the GPU box).
+The reference's hot-path scripts cannot be imported — every one parses argv, needs cuda:0 and
+imports cv2 / open3d / trimesh at import — so nothing is imported: each file is read as text,
+parsed with `ast`, and only the named function definitions / the statements of the cited line
+ranges are compiled and executed, in a namespace that provides the libraries the reference itself
+uses (torch, numpy, torch.nn.functional as F, sklearn.neighbors.KDTree) and the inputs.  What is
+written to disk is DATA ONLY — inputs and the outputs the reference code produced for them; no
+reference text is stored.
+
+  ref_getcors.npz        getCors               inference.py:142-149 (= finalposes.py:38-45 = choosePose.py:35-42)
+  ref_filter.npz         top-80 % cut          inference.py:282-288 (statements)
+  ref_add_adds.npz       ADD, ADDS             inference.py:116-120
+  ref_relpose.npz        compute_rel_poses     choosePose.py:43-51;  calculate_relative_pose  verfication.py:9-19
+  ref_cammat.npz         crop / down-sample    inference.py:203-206, 212-222, 260-263 (statements)
+  ref_normalize.npz      normalize             inference.py:135-141
+  ref_estimate_front.npz estimate_pose front   poseEstSurf.py:37-107 (statements; both avg_queries branches)
+  ref_refine_objective.npz  refine_pose `sample` + objective body   pose_refine.py:60-68, 78-87 (statements)
+
+Not reproducible this way (cv2 / open3d / torch_scatter are absent and must not be stood in for):
+pnp (inference.py:123-134), estimate_pose's P3P loop and batch_score (poseEstSurf.py:133-237),
+Chamfer / ICP (verfication.py:97-101, icp.py:96-117) — those stay "parity unpinned" (DESIGN.md §2).
+
+Run from the repo root:  python tests/golden/make_golden_from_reference.py
+"""
+import ast
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from sklearn.neighbors import KDTree
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent
+
+
+def _tree(fname: str) -> ast.Module:
+    return ast.parse((REF / fname).read_text(), filename=fname)
+
+
+def ref_function(fname: str, name: str, ns: dict):
+    """Compile ONE top-level `def name` of a reference script into namespace `ns` and return it."""
+    for node in _tree(fname).body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            mod = ast.Module(body=[node], type_ignores=[])
+            exec(compile(mod, f"{fname}:{name}", "exec"), ns)
+            return ns[name]
+    raise KeyError(f"{fname}: def {name} not found")
+
+
+def _stmts_in(body, lo, hi, out):
+    for st in body:
+        if st.lineno >= lo and st.end_lineno <= hi:
+            out.append(st)
+            continue
+        if st.end_lineno < lo or st.lineno > hi:
+            continue
+        for field in ("body", "orelse", "finalbody"):
+            sub = getattr(st, field, None)
+            if isinstance(sub, list) and sub and isinstance(sub[0], ast.stmt):
+                _stmts_in(sub, lo, hi, out)
+
+
+def ref_statements(fname: str, lo: int, hi: int, must_contain: tuple[str, ...]):
+    """The outermost statements of a reference script that lie entirely inside lines [lo, hi], as a
+    compiled code object.  `must_contain` guards against a shifted line range."""
+    out: list[ast.stmt] = []
+    _stmts_in(_tree(fname).body, lo, hi, out)
+    text = "\n".join(ast.unparse(s) for s in out)
+    for needle in must_contain:
+        assert needle in text, f"{fname}:{lo}-{hi}: expected `{needle}` in the extracted statements"
+    return compile(ast.Module(body=out, type_ignores=[]), f"{fname}:{lo}-{hi}", "exec")
+
+
+def unit_rows(rng, n, d, scale):
+    k = rng.normal(size=(n, d))
+    return (scale * k / np.linalg.norm(k, axis=1, keepdims=True)).astype(np.float32)
+
+
+def random_rotation(rng):
+    q, r = np.linalg.qr(rng.normal(size=(3, 3)))
+    q = q * np.sign(np.diag(r))
+    if np.linalg.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q
+
+
+def main():
+    torch.manual_seed(1)                       # inference.py:37
+    rng = np.random.default_rng(20261004)
+    base = {"torch": torch, "np": np, "F": F, "KDTree": KDTree}
+
+    # ---------------------------------------------------------------- getCors (three identical copies)
+    fns = [ref_function(f, "getCors", dict(base)) for f in ("inference.py", "finalposes.py", "choosePose.py")]
+    out = {}
+    for c, (P, N, D, tau, leaves) in enumerate([(400, 2000, 12, 5.0, 1), (257, 999, 12, 3.0, 1), (64, 500, 12, 5.0, 3)]):
+        K = unit_rows(rng, N, D, tau)
+        gt = rng.integers(N, size=P)
+        Q = (K[gt] + 0.35 * rng.normal(size=(P, D))).astype(np.float32)
+        res = [fn(torch.from_numpy(Q), torch.from_numpy(K), leaves) for fn in fns]
+        for r in res[1:]:
+            assert torch.equal(r[0], res[0][0]) and torch.equal(r[1], res[0][1])
+        idx, vals = res[0]
+        assert not idx.is_cuda
+        out.update({f"Q{c}": Q, f"K{c}": K, f"leaves{c}": leaves, f"idx{c}": idx.numpy(), f"vals{c}": vals.numpy()})
+    np.savez_compressed(OUT / "ref_getcors.npz", n_cases=3, **out)
+
+    # ---------------------------------------------------------------- top-80 % cut (statements)
+    code = ref_statements("inference.py", 282, 288, ("torch.sort", "threshval", "nidx"))
+    out, c = {}, 0
+    for n in (1500, 501, 500, 37, 2):
+        for ties in (False, True):
+            v = -np.abs(rng.normal(size=(n, 1))).astype(np.float32) * 1e-2
+            if ties:
+                v[rng.integers(n, size=n // 3), 0] = v[rng.integers(n), 0]    # a third of the values collide
+            ns = dict(base, in1=torch.from_numpy(v))
+            exec(code, ns)
+            out.update({f"in{c}": v, f"nidx{c}": np.asarray(ns["nidx"]), f"thr{c}": np.float32(ns["threshval"].item())})
+            c += 1
+    np.savez_compressed(OUT / "ref_filter.npz", n_cases=c, **out)
+
+    # ---------------------------------------------------------------- ADD / ADDS
+    ns = dict(base)
+    ADD = ref_function("inference.py", "ADD", ns)
+    ADDS = ref_function("inference.py", "ADDS", ns)
+    ns2 = dict(base)
+    ADD2, ADDS2 = ref_function("choosePose.py", "ADD", ns2), ref_function("choosePose.py", "ADDS", ns2)
+    verts = rng.normal(size=(300, 3)) * [40, 25, 15]
+    surf = (rng.normal(size=(800, 3)) * [40, 25, 15]).astype(np.float32).astype(np.float64)
+    ns["surfacePointsScaled"] = surf            # the module global ADDS reads (inference.py:88, choosePose.py:160)
+    ns2["surfacePointsScaled"] = surf
+    Rg, tg, Rp, tp, add, adds = [], [], [], [], [], []
+    for i in range(5):
+        R1, R2 = random_rotation(rng), random_rotation(rng)
+        if i < 3:                                # near pose: a perturbation of the GT
+            w = rng.normal(size=3) * 0.03
+            Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            R2 = (np.eye(3) + Wx) @ R1
+            R2, _ = np.linalg.qr(R2)
+            R2 *= np.sign(np.diag(R2.T @ R1))[None, :]
+        t1 = np.array([0, 0, 700.0]) + rng.normal(size=3) * 20
+        t2 = t1 + rng.normal(size=3) * (2.0 if i < 3 else 30.0)
+        Rg.append(R1); tg.append(t1); Rp.append(R2); tp.append(t2)
+        add.append(ADD(verts, R1, t1, R2, t2))
+        adds.append(ADDS(verts, R1, t1, R2, t2))
+        assert add[-1] == ADD2(verts, R1, t1, R2, t2) and adds[-1] == ADDS2(verts, R1, t1, R2, t2)
+    np.savez_compressed(OUT / "ref_add_adds.npz", verts=verts, surface=surf, Rg=np.array(Rg), tg=np.array(tg),
+                        Rp=np.array(Rp), tp=np.array(tp), add=np.array(add), adds=np.array(adds))
+
+    # ---------------------------------------------------------------- relative poses
+    crp = ref_function("choosePose.py", "compute_rel_poses", dict(base))
+    calc = ref_function("verfication.py", "calculate_relative_pose", dict(base))
+    n = 6
+    R = np.array([random_rotation(rng) for _ in range(n)])
+    t = rng.normal(size=(n, 3)) * 50 + [0, 0, 700]
+    rel_c = np.zeros((n, n, 3, 4))
+    rel_v = np.zeros((n, n, 3, 4))
+    for i in range(n):
+        for j in range(n):
+            a, b = crp(R[i], t[i], R[j], t[j])
+            rel_c[i, j, :, :3], rel_c[i, j, :, 3] = a, b
+            a, b = calc(R[i], t[i], R[j], t[j])
+            rel_v[i, j, :, :3], rel_v[i, j, :, 3] = a, b
+    np.savez_compressed(OUT / "ref_relpose.npz", R=R, t=t, choose=rel_c, verif=rel_v)
+
+    # ---------------------------------------------------------------- camera matrix of the crop (statements)
+    even = ref_statements("inference.py", 203, 206, ("w % 2", "h % 2"))
+    crop = ref_statements("inference.py", 212, 222, ("centerX", "camMat", "camparams"))
+    down = ref_statements("inference.py", 260, 263, ("camMat[:2, 2] += 0.5", "down_sample"))
+    boxes, Ks, cams, Ms = [], [], [], []
+    for (x, y, w, h) in [(100, 80, 200, 150), (311, 7, 97, 133), (0, 0, 640, 480), (250, 200, 51, 50), (17, 300, 224, 1)]:
+        camparams = np.array([[1075.65 + rng.normal(), 0, 320 + rng.normal()], [0, 1073.9 + rng.normal(), 240 + rng.normal()], [0, 0, 1]])
+        ns = dict(base, x=x, y=y, w=w, h=h, camparams=camparams, camMatScaling=True, down_sample=3)
+        exec(even, ns)
+        exec(crop, ns)
+        Ms.append(np.array(ns["M"]))
+        exec(down, ns)
+        boxes.append((x, y, w, h)); Ks.append(camparams); cams.append(np.array(ns["camMat"]))
+    np.savez_compressed(OUT / "ref_cammat.npz", boxes=np.array(boxes), K=np.array(Ks), camMat=np.array(cams), M=np.array(Ms))
+
+    # ---------------------------------------------------------------- normalize
+    normalize = ref_function("inference.py", "normalize", dict(base))
+    img = rng.integers(0, 256, size=(9, 11, 3), dtype=np.uint8)
+    np.savez_compressed(OUT / "ref_normalize.npz", img=img, out=normalize(img))
+
+    # ---------------------------------------------------------------- estimate_pose, front part (statements)
+    front = ref_statements("poseEstSurf.py", 37, 107, ("F.logsigmoid", "corr_matrix_log", "F.avg_pool2d", "mask_prob"))
+    out = {}
+    for tag, avg in (("avg", True), ("patch", False)):
+        r, e, m, scale = 30, 12, 160, 3
+        mask_lgts = torch.from_numpy(rng.normal(size=(r, r)).astype(np.float32) * 3)
+        query_img = torch.from_numpy(rng.normal(size=(r, r, e)).astype(np.float32) * 0.7)
+        obj_keys = torch.from_numpy(unit_rows(rng, m, e, 3.0))
+        Kc = np.array([[600.0, 0, r / 2 - 0.3], [0, 590.0, r / 2 + 0.2], [0, 0, 1]])
+        ns = dict(base, mask_lgts=mask_lgts.clone(), query_img=query_img.clone(), obj_keys=obj_keys, K=Kc.copy(),
+                  down_sample_scale=scale, max_pool=True, avg_queries=avg)
+        exec(front, ns)
+        out.update({f"{tag}_mask_lgts": mask_lgts.numpy(), f"{tag}_query_img": query_img.numpy(),
+                    f"{tag}_obj_keys": obj_keys.numpy(), f"{tag}_K_in": Kc, f"{tag}_K": ns["K"],
+                    f"{tag}_mask_log_prob": ns["mask_log_prob"].numpy(), f"{tag}_neg_mask_log_prob": ns["neg_mask_log_prob"].numpy(),
+                    f"{tag}_mask_prob": ns["mask_prob"].numpy(), f"{tag}_img_pts": ns["img_pts"].numpy(),
+                    f"{tag}_corr_matrix": ns["corr_matrix"].numpy(), f"{tag}_corr_matrix_log": ns["corr_matrix_log"].numpy()})
+    np.savez_compressed(OUT / "ref_estimate_front.npz", down_sample_scale=3, **out)
+
+    # ---------------------------------------------------------------- refine_pose: sample + objective body
+    sample_def = ref_statements("pose_refine.py", 60, 68, ("F.grid_sample", "padding_mode"))
+    body = ref_statements("pose_refine.py", 78, 87, ("p_img_norm", "log_nominator", "score"))
+    res, e, Npt = 32, 12, 150
+    query_img = torch.from_numpy(rng.normal(size=(res, res, e)).astype(np.float32))
+    denom_img = torch.from_numpy(rng.normal(size=(res, res, 1)).astype(np.float32) + 5)
+    keys_masked = torch.from_numpy(rng.normal(size=(Npt, e)).astype(np.float32))
+    X = rng.normal(size=(Npt, 3)).astype(np.float32) * 20
+    coord_masked = torch.from_numpy(np.concatenate([X, np.ones((Npt, 1), np.float32)], 1))
+    K_crop = torch.tensor([[45.0, 0, 15.5], [0, 45.0, 15.5], [0, 0, 1]])
+    Rm = torch.from_numpy(random_rotation(rng).astype(np.float32))
+    scores, grads, ts = [], [], []
+    for tz in (120.0, 60.0, 35.0):               # the last one pushes projections across the border (clamped samples)
+        tvec = torch.tensor([1.5, -2.0, tz], requires_grad=True)
+        ns = dict(base, interpolation="bilinear", query_img=query_img, denom_img=denom_img, keys_masked=keys_masked,
+                  coord_masked=coord_masked, K_crop=K_crop, res_crop=res, Rt=torch.cat((Rm, tvec[:, None]), dim=1))
+        exec(sample_def, ns)
+        exec(body, ns)
+        ns["score"].backward()
+        scores.append(ns["score"].item()); grads.append(tvec.grad.numpy().copy()); ts.append(tvec.detach().numpy().copy())
+    np.savez_compressed(OUT / "ref_refine_objective.npz", query_img=query_img.numpy(), denom_img=denom_img.numpy()[..., 0],
+                        keys=keys_masked.numpy(), X=X, K_crop=K_crop.numpy().astype(np.float64), R=Rm.numpy().astype(np.float64),
+                        t=np.array(ts, np.float64), score=np.array(scores), grad_t=np.array(grads))
+    print("wrote", sorted(p.name for p in OUT.glob("ref_*.npz")))
+
+
+if __name__ == "__main__":
+    sys.exit(main())

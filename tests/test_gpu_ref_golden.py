@@ -1,0 +1,93 @@
+"""GPU: the HIP path (through the C ABI) against vectors produced by EXECUTING THE REFERENCE'S OWN
+CODE (tests/golden/ref_*.npz, generator tests/golden/make_golden_from_reference.py).  The reference
+itself does not exist on the GPU box: only the committed data does."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = Path(__file__).resolve().parent / "golden"
+
+
+def test_getcors_vs_reference_output(cuda0):
+    """registration.getCors (exact-f32 MFMA kernel) vs the reference's getCors (inference.py:142-149) run
+    on torch-CPU: the same winning indices, log-probabilities to f32 rounding; leaves=3 as the reference."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration
+    g = np.load(G / "ref_getcors.npz")
+    for c in range(int(g["n_cases"])):
+        Q, K, leaves = torch.from_numpy(g[f"Q{c}"]).to(cuda0), torch.from_numpy(g[f"K{c}"]).to(cuda0), int(g[f"leaves{c}"])
+        idx, vals = registration.getCors(Q, K, leaves)
+        assert not idx.is_cuda and idx.dtype == torch.int64 and vals.is_cuda
+        assert idx.shape == g[f"idx{c}"].shape and vals.shape == g[f"vals{c}"].shape
+        assert np.array_equal(idx.numpy(), g[f"idx{c}"])
+        np.testing.assert_allclose(vals.cpu().numpy(), g[f"vals{c}"], atol=2e-5)
+
+
+def test_filter_vs_reference_output(cuda0):
+    """isr_select_top vs the reference's statements inference.py:282-288: integer-exact kept set and
+    the same threshold value, both branches (n > 500, n <= 500), tied values included."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, registration
+    g = np.load(G / "ref_filter.npz")
+    for c in range(int(g["n_cases"])):
+        v = torch.from_numpy(g[f"in{c}"]).to(cuda0)
+        keep, M, thr = ops.select_top(v[:, 0])
+        m = int(M.item())
+        assert np.array_equal(keep[:m].cpu().numpy(), g[f"nidx{c}"]), c
+        assert np.float32(thr.item()) == g[f"thr{c}"], c
+        assert np.array_equal(registration.filter_top(v), g[f"nidx{c}"])
+
+
+def test_add_adds_vs_reference_output(cuda0):
+    """isr_add_metric / isr_nn_batched vs the reference's ADD / ADDS (inference.py:116-120, sklearn
+    KDTree(leaf_size=2)).  Clouds are uploaded as f32: 1e-4 mm covers it."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration
+    g = np.load(G / "ref_add_adds.npz")
+    registration.set_surface_points(g["surface"])
+    for i in range(len(g["add"])):
+        a = registration.ADD(g["verts"], g["Rg"][i], g["tg"][i], g["Rp"][i], g["tp"][i])
+        s = registration.ADDS(g["verts"], g["Rg"][i], g["tg"][i], g["Rp"][i], g["tp"][i])
+        assert abs(a - g["add"][i]) < 1e-4 and abs(s - g["adds"][i]) < 1e-4
+
+
+def test_rel_pose_tables_vs_reference_output(cuda0):
+    """isr_rel_pose_table (both modes) vs compute_rel_poses (choosePose.py:43-51) and
+    calculate_relative_pose (verfication.py:9-19) executed from the reference."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration
+    g = np.load(G / "ref_relpose.npz")
+    tab = registration.relative_pose_table(g["R"], g["t"], "choose")
+    np.testing.assert_allclose(tab[:, :, :3, :], g["choose"], rtol=0, atol=1e-12)
+    tab = registration.relative_pose_table(g["R"], g["t"], "verif")
+    np.testing.assert_allclose(tab[:, :, :3, :], g["verif"], rtol=0, atol=1e-9)    # np.linalg.inv vs R^T
+    assert np.all(tab[:, :, 3, :] == [0, 0, 0, 1])
+
+
+def test_estimate_pose_front_vs_reference_statements(cuda0):
+    """isr_ep_prepare, isr_corr_logsoftmax, isr_ep_pool_corr vs poseEstSurf.py:37-107 executed from the
+    reference (avg_queries=True)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, pose_est_surf as pes
+    g = np.load(G / "ref_estimate_front.npz")
+    ml, q, keys = (torch.from_numpy(g[f"avg_{k}"]).to(cuda0) for k in ("mask_lgts", "query_img", "obj_keys"))
+    mlp, nmlp, mp, queries, res = pes.prepare(ml, q, int(g["down_sample_scale"]), True)
+    np.testing.assert_allclose(mlp.cpu().numpy(), g["avg_mask_log_prob"], atol=1e-6)
+    np.testing.assert_allclose(nmlp.cpu().numpy(), g["avg_neg_mask_log_prob"], atol=1e-6)
+    np.testing.assert_allclose(mp.cpu().numpy(), g["avg_mask_prob"], atol=1e-6)
+    raw = ops.corr_logsoftmax(queries, keys)
+    np.testing.assert_allclose(pes.pool_corr(raw, res).cpu().numpy(), g["avg_corr_matrix_log"], atol=1e-5)
+    np.testing.assert_allclose((raw.exp() * mp[:, None]).cpu().numpy(), g["avg_corr_matrix"], atol=1e-6)
+    assert np.array_equal(pes._k_scaled(g["avg_K_in"], 3), g["avg_K"])
+
+
+def test_refine_objective_vs_reference_statements(cuda0):
+    """isr_refine_objective (value + analytic d/dt) vs pose_refine.py:60-68, 78-87 executed from the
+    reference with torch autograd, including border-clamped samples."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import pose_refine
+    g = np.load(G / "ref_refine_objective.npz")
+    q, den = torch.from_numpy(g["query_img"]).to(cuda0), torch.from_numpy(g["denom_img"]).to(cuda0)
+    obj = pose_refine.RefineObjective(torch.from_numpy(g["X"]).to(cuda0), torch.from_numpy(g["keys"]).to(cuda0), q, den,
+                                      g["K_crop"], g["R"])
+    for t, s, gr in zip(g["t"], g["score"], g["grad_t"]):
+        pose = np.concatenate([np.zeros(3), t])
+        assert abs(obj(pose) - s) <= 2e-5 * max(1.0, abs(s))
+        np.testing.assert_allclose(obj(pose, return_grad=True)[3:], gr, rtol=2e-3, atol=1e-6)
