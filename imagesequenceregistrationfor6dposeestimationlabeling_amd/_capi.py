@@ -46,6 +46,11 @@ SIGNATURES = {
     "isr_select_top_workspace_bytes": (_sz, [_i]),
     "isr_select_top": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_select_top_dev": (_i, [_vp, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_select_top_batch_workspace_bytes": (_sz, [_i, _i]),
+    "isr_select_top_batch": (_i, [_vp, _i, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_gather_corr_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "isr_pnp_ransac_batch_workspace_bytes": (_sz, [_i, _i, _i]),
+    "isr_pnp_ransac_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_prep_queries_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_prep_queries": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),

@@ -24,6 +24,10 @@
 //   5. compaction   inlier mask -> ascending int32 indices.
 // Every step reads M and the status from device memory: the whole chain is enqueued without a
 // host round trip.
+// Every kernel carries an IMAGE dimension (blockIdx.z) with the cameras and seeds of up to kMaxBatch
+// images in the kernel arguments: the per-image chain of inference.py:293 over a group of images is
+// one chain of launches for the whole group (isr_pnp_ransac_batch).  The single-image entry points
+// are the B = 1 case of the same kernels: bit-identical by construction.
 #include "isr_common.hpp"
 #include "p3p_device.hpp"
 
@@ -31,15 +35,26 @@ namespace {
 
 using namespace isr_p3p;
 
+constexpr int kMaxBatch = 16;   // images per launch chain (kernel-argument space: 16 x (144 + 8) B)
 
+struct ImgBatch {
+  Cam cam[kMaxBatch];
+  uint32_t seed_lo[kMaxBatch], seed_hi[kMaxBatch];
+};
 
 __global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
-                           const int32_t* __restrict__ M_dev, Cam cam, int H, uint32_t seed_lo,
-                           uint32_t seed_hi, double* __restrict__ Rt_out, uint8_t* __restrict__ ok_out,
+                           const int32_t* __restrict__ M_dev, int M_cap, ImgBatch ib, int H,
+                           double* __restrict__ Rt_out, uint8_t* __restrict__ ok_out,
                            int32_t* __restrict__ sample_out) {
+  const int b = blockIdx.z;
+  const Cam& cam = ib.cam[b];
+  const uint32_t seed_lo = ib.seed_lo[b], seed_hi = ib.seed_hi[b];
+  p3d += (size_t)b * M_cap * 3; p2d += (size_t)b * M_cap * 2;
+  Rt_out += (size_t)b * H * 12; ok_out += (size_t)b * H;
+  if (sample_out) sample_out += (size_t)b * H * 4;
   const int h = blockIdx.x * blockDim.x + threadIdx.x;
   if (h >= H) return;
-  const int M = *M_dev;
+  const int M = M_dev[b];
   double* Rt = Rt_out + 12 * (size_t)h;
   uint8_t ok = 0;
   int s[4] = {0, 0, 0, 0};
@@ -97,8 +112,14 @@ __global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restric
 
 // ------------------------------------------------------------------------------- scoring
 // Pm (H,12) f32 = float(K [R|t]) with the f64 fma order of oracle/isr_oracle.c:proj_matrix_f32.
-__global__ void proj_matrix_kernel(const double* __restrict__ Rt, Cam cam, int H, float* __restrict__ Pm) {
+// Also zeroes the image's inlier counters (no memset launch).
+__global__ void proj_matrix_kernel(const double* __restrict__ Rt, ImgBatch ib, int H, float* __restrict__ Pm,
+                                   int32_t* __restrict__ n_inl) {
+  const int b = blockIdx.z;
+  const Cam& cam = ib.cam[b];
+  Rt += (size_t)b * H * 12; Pm += (size_t)b * H * 12; n_inl += (size_t)b * H;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < H) n_inl[e] = 0;
   if (e >= H * 12) return;
   const int h = e / 12, r = (e % 12) / 4, c = e % 4;
   const double* T = Rt + 12 * (size_t)h;
@@ -128,13 +149,16 @@ constexpr int kHC = ISR_SCORE_HC;     // hypotheses per block: grid.y = ceil(H /
 constexpr int kMaxH = 8192;
 
 __global__ __launch_bounds__(kScoreThreads) void score_kernel(
-    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev,
+    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev, int M_cap,
     const float* __restrict__ Pm, const uint8_t* __restrict__ ok, int H, float reperr,
     int32_t* __restrict__ n_inl) {
   __shared__ int32_t cnt[kHC];
   __shared__ __attribute__((aligned(16))) float Ps[kHC][12];   // the block's projection matrices: one
   __shared__ uint8_t oks[kHC];                                  // coalesced load, then LDS broadcasts
-  const int M = *M_dev;
+  const int b = blockIdx.z;
+  p3d += (size_t)b * M_cap * 3; p2d += (size_t)b * M_cap * 2;
+  Pm += (size_t)b * H * 12; ok += (size_t)b * H; n_inl += (size_t)b * H;
+  const int M = M_dev[b];
   const int base = blockIdx.x * (kScoreThreads * kCPL);
   if (base >= M) return;  // block-uniform
   const int h0 = blockIdx.y * kHC;
@@ -182,11 +206,19 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
   if (threadIdx.x < h1 - h0 && cnt[threadIdx.x]) atomicAdd(&n_inl[h0 + threadIdx.x], cnt[threadIdx.x]);
 }
 
-// One block: best = arg-max n_inl over ok hypotheses (lowest h on ties); status = count >= 4.
+// One block per image: best = arg-max n_inl over ok hypotheses (lowest h on ties); status = count >= 4.
+// Also clears the image's Gauss-Newton convergence flag (no memset launch).
 __global__ void best_kernel(const int32_t* __restrict__ n_inl, const uint8_t* __restrict__ ok, int H,
                             int32_t* __restrict__ best_dev, int32_t* __restrict__ status_dev,
-                            const double* __restrict__ Rt, double* __restrict__ pose_dev) {
+                            const double* __restrict__ Rt, double* __restrict__ pose_dev,
+                            int32_t* __restrict__ gn_state) {
   __shared__ int32_t sc[256], sh[256];
+  const int b = blockIdx.z;
+  n_inl += (size_t)b * H; ok += (size_t)b * H; Rt += (size_t)b * H * 12;
+  best_dev += b;
+  if (status_dev) status_dev += b;
+  if (pose_dev) pose_dev += (size_t)b * 12;
+  if (gn_state && threadIdx.x == 0) gn_state[4 * b] = 0;
   int bc = -1, bh = -1;
   for (int h = threadIdx.x; h < H; h += 256) {
     if (ok[h] && n_inl[h] > bc) { bc = n_inl[h]; bh = h; }  // ascending h per thread: lowest kept
@@ -213,12 +245,15 @@ __global__ void best_kernel(const int32_t* __restrict__ n_inl, const uint8_t* __
 }
 
 __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
-                                 const int32_t* __restrict__ M_dev, int M_cap,
+                                 const int32_t* __restrict__ M_dev, int M_cap, int H,
                                  const float* __restrict__ Pm, const int32_t* __restrict__ best_dev,
-                                 float reperr, uint32_t* __restrict__ mask) {
+                                 float reperr, uint32_t* __restrict__ mask, int mask_words) {
+  const int img = blockIdx.z;
+  p3d += (size_t)img * M_cap * 3; p2d += (size_t)img * M_cap * 2; Pm += (size_t)img * H * 12;
+  mask += (size_t)img * mask_words;
   const int m = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim multiple of 64
-  const int M = *M_dev;
-  const int b = *best_dev;
+  const int M = M_dev[img];
+  const int b = best_dev[img];
   bool in = false;
   if (m < M && b >= 0)
     in = inlier_f32(Pm + 12 * (size_t)b, p3d[3 * (size_t)m], p3d[3 * (size_t)m + 1], p3d[3 * (size_t)m + 2],
@@ -236,17 +271,22 @@ constexpr int kRefBlocks = 64;
 constexpr int kNAcc = 28;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2)
 
 __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
-    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev,
-    const uint32_t* __restrict__ mask, Cam cam, const double* __restrict__ Rt,
+    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev, int M_cap,
+    const uint32_t* __restrict__ mask, int mask_words, ImgBatch ib, const double* __restrict__ Rt,
     const int32_t* __restrict__ status_dev, const int32_t* __restrict__ state,
     double* __restrict__ partial) {
   __shared__ double red[kRefThreads / 64][kNAcc];
+  const int img = blockIdx.z;
+  const Cam& cam = ib.cam[img];
+  p3d += (size_t)img * M_cap * 3; p2d += (size_t)img * M_cap * 2;
+  if (mask) mask += (size_t)img * mask_words;
+  Rt += (size_t)img * 12; state += 4 * img; partial += (size_t)img * kRefBlocks * kNAcc;
   if (state[0]) return;  // converged (block-uniform)
   double acc[kNAcc];
 #pragma unroll
   for (int i = 0; i < kNAcc; ++i) acc[i] = 0.0;
-  const int M = *M_dev;
-  const bool live = (status_dev == nullptr) || (*status_dev != 0);
+  const int M = M_dev[img];
+  const bool live = (status_dev == nullptr) || (status_dev[img] != 0);
   if (live) {
     double T[12];
 #pragma unroll
@@ -300,7 +340,9 @@ __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
 __global__ void gn_solve_kernel(const double* __restrict__ partial, double* __restrict__ Rt,
                                 const int32_t* __restrict__ status_dev, int32_t* __restrict__ state) {
   __shared__ double s[kNAcc];
-  if (status_dev && *status_dev == 0) return;
+  const int img = blockIdx.z;
+  partial += (size_t)img * kRefBlocks * kNAcc; Rt += (size_t)img * 12; state += 4 * img;
+  if (status_dev && status_dev[img] == 0) return;
   if (state[0]) return;
   if (threadIdx.x < kNAcc) {
     double a = 0.0;
@@ -390,11 +432,13 @@ __device__ __forceinline__ int block_scan_excl(int v, int* total) {
   return base + inc - v;
 }
 
-__global__ __launch_bounds__(kCompBlock) void mask_count_kernel(const uint32_t* __restrict__ mask,
+__global__ __launch_bounds__(kCompBlock) void mask_count_kernel(const uint32_t* __restrict__ mask, int mask_words,
                                                                 const int32_t* __restrict__ M_dev,
                                                                 const int32_t* __restrict__ status_dev,
                                                                 int32_t* __restrict__ block_counts) {
-  const int W = (status_dev && *status_dev == 0) ? 0 : (*M_dev + 31) / 32;
+  const int img = blockIdx.z;
+  mask += (size_t)img * mask_words; block_counts += (size_t)img * gridDim.x;
+  const int W = (status_dev && status_dev[img] == 0) ? 0 : (M_dev[img] + 31) / 32;
   const int w = blockIdx.x * kCompBlock + threadIdx.x;
   int total;
   (void)block_scan_excl(w < W ? __popc(mask[w]) : 0, &total);
@@ -403,6 +447,7 @@ __global__ __launch_bounds__(kCompBlock) void mask_count_kernel(const uint32_t* 
 
 __global__ void mask_scan_kernel(int32_t* __restrict__ block_counts, int nblocks, int32_t* __restrict__ n_out) {
   __shared__ int32_t tsum[1024];
+  block_counts += (size_t)blockIdx.z * nblocks; n_out += blockIdx.z;
   const int t = threadIdx.x;
   const int per = (nblocks + 1023) / 1024;
   int32_t s = 0;
@@ -430,12 +475,14 @@ __global__ void mask_scan_kernel(int32_t* __restrict__ block_counts, int nblocks
   if (t == 1023) *n_out = tsum[1023];
 }
 
-__global__ __launch_bounds__(kCompBlock) void mask_scatter_kernel(const uint32_t* __restrict__ mask,
+__global__ __launch_bounds__(kCompBlock) void mask_scatter_kernel(const uint32_t* __restrict__ mask, int mask_words,
                                                                   const int32_t* __restrict__ M_dev,
                                                                   const int32_t* __restrict__ status_dev,
                                                                   const int32_t* __restrict__ block_off,
-                                                                  int32_t* __restrict__ out) {
-  const int W = (status_dev && *status_dev == 0) ? 0 : (*M_dev + 31) / 32;
+                                                                  int32_t* __restrict__ out, int M_cap) {
+  const int img = blockIdx.z;
+  mask += (size_t)img * mask_words; block_off += (size_t)img * gridDim.x; out += (size_t)img * M_cap;
+  const int W = (status_dev && status_dev[img] == 0) ? 0 : (M_dev[img] + 31) / 32;
   const int w = blockIdx.x * kCompBlock + threadIdx.x;
   uint32_t bits = w < W ? mask[w] : 0u;
   int total;
@@ -446,29 +493,43 @@ __global__ __launch_bounds__(kCompBlock) void mask_scatter_kernel(const uint32_t
   }
 }
 
+inline int mask_words_of(int M_cap) { return (M_cap + 31) / 32 + 2; }
+inline int comp_blocks_of(int M_cap) { return ((M_cap + 31) / 32 + kCompBlock - 1) / kCompBlock; }
+
 struct RansacWs {
-  double* Rt;        // H x 12
-  float* Pm;         // H x 12
-  uint8_t* ok;       // H
-  int32_t* n_inl;    // H
-  int32_t* best;     // 1
-  uint32_t* mask;    // ceil(M_cap/32)
-  double* partial;   // kRefBlocks x kNAcc
-  int32_t* state;    // GN convergence flag
-  int32_t* cblocks;  // compaction block counts
+  double* Rt;        // B x H x 12
+  float* Pm;         // B x H x 12
+  uint8_t* ok;       // B x H
+  int32_t* n_inl;    // B x H
+  int32_t* best;     // B
+  uint32_t* mask;    // B x mask_words
+  double* partial;   // B x kRefBlocks x kNAcc
+  int32_t* state;    // B x 4: GN convergence flag
+  int32_t* cblocks;  // B x comp_blocks: compaction block counts
 };
 
-size_t carve(isr::Workspace& w, int M_cap, int H, RansacWs* o) {
-  o->Rt = w.take<double>((size_t)H * 12);
-  o->Pm = w.take<float>((size_t)H * 12);
-  o->ok = w.take<uint8_t>(H);
-  o->n_inl = w.take<int32_t>(H);
-  o->best = w.take<int32_t>(4);
-  o->mask = w.take<uint32_t>((M_cap + 31) / 32 + 2);
-  o->partial = w.take<double>((size_t)kRefBlocks * kNAcc);
-  o->state = w.take<int32_t>(4);
-  o->cblocks = w.take<int32_t>(((M_cap + 31) / 32 + kCompBlock - 1) / kCompBlock + 1);
+size_t carve(isr::Workspace& w, int M_cap, int H, int B, RansacWs* o) {
+  o->Rt = w.take<double>((size_t)B * H * 12);
+  o->Pm = w.take<float>((size_t)B * H * 12);
+  o->ok = w.take<uint8_t>((size_t)B * H);
+  o->n_inl = w.take<int32_t>((size_t)B * H);
+  o->best = w.take<int32_t>(B + 4);
+  o->mask = w.take<uint32_t>((size_t)B * mask_words_of(M_cap));
+  o->partial = w.take<double>((size_t)B * kRefBlocks * kNAcc);
+  o->state = w.take<int32_t>((size_t)B * 4);
+  o->cblocks = w.take<int32_t>((size_t)B * (comp_blocks_of(M_cap) + 1));
   return w.off;
+}
+
+bool make_batch(const double* Kcams, const uint64_t* seeds, int B, ImgBatch* ib) {
+  for (int b = 0; b < B; ++b) {
+    if (!make_cam(Kcams + 9 * (size_t)b, &ib->cam[b])) return false;
+    const uint64_t s = seeds ? seeds[b] : 0;
+    ib->seed_lo[b] = (uint32_t)s;
+    ib->seed_hi[b] = (uint32_t)(s >> 32);
+  }
+  for (int b = B; b < kMaxBatch; ++b) { ib->cam[b] = ib->cam[0]; ib->seed_lo[b] = ib->seed_hi[b] = 0; }
+  return true;
 }
 
 }  // namespace
@@ -477,7 +538,14 @@ extern "C" size_t isr_pnp_ransac_workspace_bytes(int M_cap, int H) {
   if (M_cap <= 0 || H <= 0) return 0;
   isr::Workspace w(nullptr, 0);
   RansacWs o;
-  return carve(w, M_cap, H, &o) + 512;
+  return carve(w, M_cap, H, 1, &o) + 512;
+}
+
+extern "C" size_t isr_pnp_ransac_batch_workspace_bytes(int M_cap, int H, int B) {
+  if (M_cap <= 0 || H <= 0 || B <= 0) return 0;
+  isr::Workspace w(nullptr, 0);
+  RansacWs o;
+  return carve(w, M_cap, H, B < kMaxBatch ? B : kMaxBatch, &o) + 512;
 }
 
 extern "C" int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
@@ -485,25 +553,24 @@ extern "C" int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int3
                                   int32_t* sample, isr_stream_t stream) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt && ok, "isr_p3p_hypotheses: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0, "isr_p3p_hypotheses: M_cap=%d H=%d", M_cap, H);
-  Cam cam;
-  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_p3p_hypotheses: singular camera matrix");
-  p3p_kernel<<<(H + 63) / 64, 64, 0, isr::as_stream(stream)>>>(p3d, p2d, M_dev, cam, H, (uint32_t)seed,
-                                                               (uint32_t)(seed >> 32), Rt, ok, sample);
+  ImgBatch ib;
+  ISR_REQUIRE(make_batch(Kcam, &seed, 1, &ib), "isr_p3p_hypotheses: singular camera matrix");
+  p3p_kernel<<<dim3((H + 63) / 64, 1, 1), 64, 0, isr::as_stream(stream)>>>(p3d, p2d, M_dev, M_cap, ib, H, Rt, ok, sample);
   ISR_CHECK_LAUNCH("p3p_kernel");
   return ISR_OK;
 }
 
-static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, const Cam& cam,
+static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgBatch& ib,
                       const double* Rt, const uint8_t* ok, int H, float reperr, float* Pm, int32_t* n_inl,
                       int32_t* best_dev, uint32_t* best_mask, int32_t* status_dev, double* pose_dev,
-                      hipStream_t stream) {
-  proj_matrix_kernel<<<(H * 12 + 255) / 256, 256, 0, stream>>>(Rt, cam, H, Pm);
-  ISR_CHECK_HIP(hipMemsetAsync(n_inl, 0, sizeof(int32_t) * (size_t)H, stream));
+                      int32_t* gn_state, hipStream_t stream) {
+  proj_matrix_kernel<<<dim3((H * 12 + 255) / 256, 1, B), 256, 0, stream>>>(Rt, ib, H, Pm, n_inl);
   const int nblk = (M_cap + kScoreThreads * kCPL - 1) / (kScoreThreads * kCPL);
-  score_kernel<<<dim3(nblk, (H + kHC - 1) / kHC), kScoreThreads, 0, stream>>>(p3d, p2d, M_dev, Pm, ok, H, reperr, n_inl);
-  best_kernel<<<1, 256, 0, stream>>>(n_inl, ok, H, best_dev, status_dev, Rt, pose_dev);
+  score_kernel<<<dim3(nblk, (H + kHC - 1) / kHC, B), kScoreThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, Pm, ok, H, reperr, n_inl);
+  best_kernel<<<dim3(1, 1, B), 256, 0, stream>>>(n_inl, ok, H, best_dev, status_dev, Rt, pose_dev, gn_state);
   if (best_mask)
-    best_mask_kernel<<<(M_cap + 255) / 256, 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, Pm, best_dev, reperr, best_mask);
+    best_mask_kernel<<<dim3((M_cap + 255) / 256, 1, B), 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, H, Pm, best_dev, reperr,
+                                                                          best_mask, mask_words_of(M_cap));
   ISR_CHECK_LAUNCH("ransac score kernels");
   return ISR_OK;
 }
@@ -514,25 +581,25 @@ extern "C" int isr_ransac_score(const float* p3d, const float* p2d, const int32_
                                 void* ws, size_t ws_bytes, isr_stream_t stream_) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt && ok && n_inl && best_dev, "isr_ransac_score: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH, "isr_ransac_score: M_cap=%d H=%d (H <= %d)", M_cap, H, kMaxH);
-  Cam cam;
-  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_ransac_score: singular camera matrix");
+  ImgBatch ib;
+  ISR_REQUIRE(make_batch(Kcam, nullptr, 1, &ib), "isr_ransac_score: singular camera matrix");
   if (!ws || ws_bytes < isr_pnp_ransac_workspace_bytes(M_cap, H)) {
     isr::set_error("isr_ransac_score: workspace %zu < %zu", ws_bytes, isr_pnp_ransac_workspace_bytes(M_cap, H));
     return ISR_ERR_WORKSPACE;
   }
   isr::Workspace w(ws, ws_bytes);
   float* Pm = w.take<float>((size_t)H * 12);
-  return score_impl(p3d, p2d, M_dev, M_cap, cam, Rt, ok, H, reperr, Pm, n_inl, best_dev, best_mask,
-                    nullptr, nullptr, isr::as_stream(stream_));
+  return score_impl(p3d, p2d, M_dev, M_cap, 1, ib, Rt, ok, H, reperr, Pm, n_inl, best_dev, best_mask,
+                    nullptr, nullptr, nullptr, isr::as_stream(stream_));
 }
 
-static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev, const uint32_t* mask,
-                       const Cam& cam, int iters, double* Rt_io, const int32_t* status_dev, double* partial,
+static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const uint32_t* mask,
+                       const ImgBatch& ib, int iters, double* Rt_io, const int32_t* status_dev, double* partial,
                        int32_t* state, hipStream_t stream) {
-  ISR_CHECK_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int32_t), stream));
   for (int it = 0; it < iters; ++it) {
-    gn_accumulate_kernel<<<kRefBlocks, kRefThreads, 0, stream>>>(p3d, p2d, M_dev, mask, cam, Rt_io, status_dev, state, partial);
-    gn_solve_kernel<<<1, 64, 0, stream>>>(partial, Rt_io, status_dev, state);
+    gn_accumulate_kernel<<<dim3(kRefBlocks, 1, B), kRefThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, mask, mask_words_of(M_cap),
+                                                                             ib, Rt_io, status_dev, state, partial);
+    gn_solve_kernel<<<dim3(1, 1, B), 64, 0, stream>>>(partial, Rt_io, status_dev, state);
   }
   ISR_CHECK_LAUNCH("pnp refine kernels");
   return ISR_OK;
@@ -543,8 +610,8 @@ extern "C" int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t*
                               size_t ws_bytes, isr_stream_t stream) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt_io, "isr_pnp_refine: null pointer");
   ISR_REQUIRE(M_cap > 0 && iters >= 0, "isr_pnp_refine: M_cap=%d iters=%d", M_cap, iters);
-  Cam cam;
-  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_pnp_refine: singular camera matrix");
+  ImgBatch ib;
+  ISR_REQUIRE(make_batch(Kcam, nullptr, 1, &ib), "isr_pnp_refine: singular camera matrix");
   const size_t need = sizeof(double) * kRefBlocks * kNAcc + 1024;
   if (!ws || ws_bytes < need) {
     isr::set_error("isr_pnp_refine: workspace %zu < %zu", ws_bytes, need);
@@ -553,7 +620,27 @@ extern "C" int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t*
   isr::Workspace w(ws, ws_bytes);
   double* partial = w.take<double>((size_t)kRefBlocks * kNAcc);
   int32_t* state = w.take<int32_t>(4);
-  return refine_impl(p3d, p2d, M_dev, mask, cam, iters, Rt_io, nullptr, partial, state, isr::as_stream(stream));
+  ISR_CHECK_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int32_t), isr::as_stream(stream)));
+  return refine_impl(p3d, p2d, M_dev, M_cap, 1, mask, ib, iters, Rt_io, nullptr, partial, state, isr::as_stream(stream));
+}
+
+// the chain for B <= kMaxBatch images: hypotheses, scoring, best + mask, refit, compaction
+static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgBatch& ib,
+                        int H, float reperr, int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
+                        int32_t* status_dev, const RansacWs& b, hipStream_t stream) {
+  p3p_kernel<<<dim3((H + 63) / 64, 1, B), 64, 0, stream>>>(p3d, p2d, M_dev, M_cap, ib, H, b.Rt, b.ok, nullptr);
+  ISR_CHECK_LAUNCH("p3p_kernel");
+  int rc = score_impl(p3d, p2d, M_dev, M_cap, B, ib, b.Rt, b.ok, H, reperr, b.Pm, b.n_inl, b.best, b.mask,
+                      status_dev, pose_dev, b.state, stream);
+  if (rc != ISR_OK) return rc;
+  rc = refine_impl(p3d, p2d, M_dev, M_cap, B, b.mask, ib, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
+  if (rc != ISR_OK) return rc;
+  const int cb = comp_blocks_of(M_cap), mw = mask_words_of(M_cap);
+  mask_count_kernel<<<dim3(cb, 1, B), kCompBlock, 0, stream>>>(b.mask, mw, M_dev, status_dev, b.cblocks);
+  mask_scan_kernel<<<dim3(1, 1, B), 1024, 0, stream>>>(b.cblocks, cb, n_inl_dev);
+  mask_scatter_kernel<<<dim3(cb, 1, B), kCompBlock, 0, stream>>>(b.mask, mw, M_dev, status_dev, b.cblocks, inl_idx, M_cap);
+  ISR_CHECK_LAUNCH("mask compaction kernels");
+  return ISR_OK;
 }
 
 extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
@@ -563,28 +650,42 @@ extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t*
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && pose_dev && inl_idx && n_inl_dev && status_dev,
               "isr_pnp_ransac: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH, "isr_pnp_ransac: M_cap=%d H=%d (H <= %d)", M_cap, H, kMaxH);
-  Cam cam;
-  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_pnp_ransac: singular camera matrix");
+  ImgBatch ib;
+  ISR_REQUIRE(make_batch(Kcam, &seed, 1, &ib), "isr_pnp_ransac: singular camera matrix");
   if (!ws || ws_bytes < isr_pnp_ransac_workspace_bytes(M_cap, H)) {
     isr::set_error("isr_pnp_ransac: workspace %zu < %zu", ws_bytes, isr_pnp_ransac_workspace_bytes(M_cap, H));
     return ISR_ERR_WORKSPACE;
   }
-  hipStream_t stream = isr::as_stream(stream_);
   isr::Workspace w(ws, ws_bytes);
   RansacWs b;
-  carve(w, M_cap, H, &b);
-  p3p_kernel<<<(H + 63) / 64, 64, 0, stream>>>(p3d, p2d, M_dev, cam, H, (uint32_t)seed, (uint32_t)(seed >> 32),
-                                               b.Rt, b.ok, nullptr);
-  ISR_CHECK_LAUNCH("p3p_kernel");
-  int rc = score_impl(p3d, p2d, M_dev, M_cap, cam, b.Rt, b.ok, H, reperr, b.Pm, b.n_inl, b.best, b.mask,
-                      status_dev, pose_dev, stream);
-  if (rc != ISR_OK) return rc;
-  rc = refine_impl(p3d, p2d, M_dev, b.mask, cam, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
-  if (rc != ISR_OK) return rc;
-  const int cb = ((M_cap + 31) / 32 + kCompBlock - 1) / kCompBlock;
-  mask_count_kernel<<<cb, kCompBlock, 0, stream>>>(b.mask, M_dev, status_dev, b.cblocks);
-  mask_scan_kernel<<<1, 1024, 0, stream>>>(b.cblocks, cb, n_inl_dev);
-  mask_scatter_kernel<<<cb, kCompBlock, 0, stream>>>(b.mask, M_dev, status_dev, b.cblocks, inl_idx);
-  ISR_CHECK_LAUNCH("mask compaction kernels");
+  carve(w, M_cap, H, 1, &b);
+  return ransac_chain(p3d, p2d, M_dev, M_cap, 1, ib, H, reperr, refine_iters, pose_dev, inl_idx, n_inl_dev, status_dev,
+                      b, isr::as_stream(stream_));
+}
+
+extern "C" int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B,
+                                    const double* Kcams, int H, const uint64_t* seeds, float reperr, int refine_iters,
+                                    double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev, int32_t* status_dev,
+                                    void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(p3d && p2d && M_dev && Kcams && seeds && pose_dev && inl_idx && n_inl_dev && status_dev,
+              "isr_pnp_ransac_batch: null pointer");
+  ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH && B > 0, "isr_pnp_ransac_batch: M_cap=%d H=%d (H <= %d) B=%d", M_cap, H, kMaxH, B);
+  if (!ws || ws_bytes < isr_pnp_ransac_batch_workspace_bytes(M_cap, H, B)) {
+    isr::set_error("isr_pnp_ransac_batch: workspace %zu < %zu", ws_bytes, isr_pnp_ransac_batch_workspace_bytes(M_cap, H, B));
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  for (int b0 = 0; b0 < B; b0 += kMaxBatch) {        // kernel-argument space holds kMaxBatch cameras
+    const int nb = (B - b0 < kMaxBatch) ? B - b0 : kMaxBatch;
+    ImgBatch ib;
+    ISR_REQUIRE(make_batch(Kcams + 9 * (size_t)b0, seeds + b0, nb, &ib), "isr_pnp_ransac_batch: singular camera matrix");
+    isr::Workspace w(ws, ws_bytes);               // chunks run one after the other on the stream: same scratch
+    RansacWs wsb;
+    carve(w, M_cap, H, nb, &wsb);
+    const int rc = ransac_chain(p3d + (size_t)b0 * M_cap * 3, p2d + (size_t)b0 * M_cap * 2, M_dev + b0, M_cap, nb, ib, H,
+                                reperr, refine_iters, pose_dev + (size_t)b0 * 12, inl_idx + (size_t)b0 * M_cap,
+                                n_inl_dev + b0, status_dev + b0, wsb, stream);
+    if (rc != ISR_OK) return rc;
+  }
   return ISR_OK;
 }

@@ -11,6 +11,9 @@
 // HBM-bound integer work: 4 coalesced reads of logp (3 histogram passes + 1 flag pass) plus one
 // more in the scatter; histograms use LDS atomics then one integer global atomic per bin per
 // block, so results are deterministic.  The kept count stays on the device (M_dev).
+// Every kernel carries an IMAGE dimension (blockIdx.z): the per-image loop of inference.py:163 over a
+// group of images becomes ten launches for the whole group (isr_select_top_batch); the single-image
+// entry points are the B = 1 case of the same kernels, so results are bit-identical by construction.
 #include "isr_common.hpp"
 
 namespace {
@@ -36,13 +39,17 @@ __device__ __forceinline__ float unordered(uint32_t u) {
   return __uint_as_float(b);
 }
 
+constexpr int kHistInts = 3 * 2048;   // the three histograms of one image
+
 template <int SHIFT, int BITS>
-__global__ __launch_bounds__(kThreads) void hist_kernel(const float* __restrict__ x, int P,
+__global__ __launch_bounds__(kThreads) void hist_kernel(const float* __restrict__ x, int64_t ld,
                                                         const SelState* __restrict__ st,
                                                         int32_t* __restrict__ hist) {
   constexpr int NB = 1 << BITS;
   __shared__ int32_t h[NB];
-  P = st->n;   // the element count: the host's P, or the device-side count (isr_select_top_dev)
+  x += blockIdx.z * ld; st += blockIdx.z; hist += (size_t)blockIdx.z * kHistInts;
+  const int P = st->n;   // the element count: the host's P, or the device-side count (isr_select_top_dev)
+  if (blockIdx.x * kChunk >= P) return;   // block-uniform: nothing of this image falls in this block
   for (int i = threadIdx.x; i < NB; i += kThreads) h[i] = 0;
   __syncthreads();
   const uint32_t prefix = st->prefix, mask = st->mask;
@@ -66,6 +73,8 @@ template <int SHIFT, int BITS, bool LAST>
 __global__ void pick_kernel(const int32_t* __restrict__ hist, SelState* __restrict__ st,
                             float* __restrict__ thr_out) {
   constexpr int NB = 1 << BITS;
+  hist += (size_t)blockIdx.z * kHistInts; st += blockIdx.z;
+  if (thr_out) thr_out += blockIdx.z;
   __shared__ int32_t cum[NB];
   // inclusive scan, 1024 threads x (NB/1024) bins
   const int t = threadIdx.x;
@@ -138,11 +147,12 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
 }
 
 // Thread t of a block owns the kPerThread CONSECUTIVE elements base + t*kPerThread .. (ordered).
-__global__ __launch_bounds__(kThreads) void count_kernel(const float* __restrict__ x, int P,
+__global__ __launch_bounds__(kThreads) void count_kernel(const float* __restrict__ x, int64_t ld,
                                                          const SelState* __restrict__ st,
                                                          int32_t* __restrict__ block_counts) {
+  x += blockIdx.z * ld; st += blockIdx.z; block_counts += (size_t)blockIdx.z * gridDim.x;
   const float thr = __uint_as_float(st->thr_bits);
-  P = st->n;
+  const int P = st->n;
   const int i0 = blockIdx.x * kChunk + threadIdx.x * kPerThread;
   int c = 0;
 #pragma unroll
@@ -155,8 +165,9 @@ __global__ __launch_bounds__(kThreads) void count_kernel(const float* __restrict
 
 __global__ void scan_blocks_kernel(int32_t* __restrict__ block_counts, int nblocks,
                                    int32_t* __restrict__ M_dev) {
-  // single block of 1024 threads; each thread scans a contiguous run
+  // one block of 1024 threads per image; each thread scans a contiguous run
   __shared__ int32_t tsum[1024];
+  block_counts += (size_t)blockIdx.z * nblocks; M_dev += blockIdx.z;
   const int t = threadIdx.x;
   const int per = (nblocks + 1023) / 1024;
   int32_t s = 0;
@@ -184,12 +195,13 @@ __global__ void scan_blocks_kernel(int32_t* __restrict__ block_counts, int nbloc
   if (t == 1023) *M_dev = tsum[1023];
 }
 
-__global__ __launch_bounds__(kThreads) void scatter_kernel(const float* __restrict__ x, int P,
+__global__ __launch_bounds__(kThreads) void scatter_kernel(const float* __restrict__ x, int64_t ld,
                                                            const SelState* __restrict__ st,
                                                            const int32_t* __restrict__ block_off,
-                                                           int32_t* __restrict__ keep) {
+                                                           int32_t* __restrict__ keep, int64_t ldkeep) {
+  x += blockIdx.z * ld; st += blockIdx.z; block_off += (size_t)blockIdx.z * gridDim.x; keep += blockIdx.z * ldkeep;
   const float thr = __uint_as_float(st->thr_bits);
-  P = st->n;
+  const int P = st->n;
   const int i0 = blockIdx.x * kChunk + threadIdx.x * kPerThread;
   bool f[kPerThread];
   int c = 0;
@@ -218,9 +230,14 @@ __host__ __device__ inline long select_rank(long n, double frac, int min_n) {
 
 // n_dev == nullptr: n = P (checked on the host).  Otherwise n = min(P, *n_dev); n = 0, or a rank the
 // reference would raise IndexError for, selects nothing: thr = +inf.
-__global__ void init_state_kernel(SelState* st, int P, const int32_t* __restrict__ n_dev, double frac, int min_n) {
+// One block per image: zeroes the image's three histograms (no memset launch) and sets its state.
+__global__ void init_state_kernel(SelState* st, int32_t* __restrict__ hist, int P, const int32_t* __restrict__ n_dev,
+                                  double frac, int min_n) {
+  st += blockIdx.z; hist += (size_t)blockIdx.z * kHistInts;
+  for (int i = threadIdx.x; i < kHistInts; i += blockDim.x) hist[i] = 0;
+  if (threadIdx.x != 0) return;
   int n = P;
-  if (n_dev) n = min(P, max(0, *n_dev));
+  if (n_dev) n = min(P, max(0, n_dev[blockIdx.z]));
   const long rank = select_rank(n, frac, min_n);
   st->prefix = 0; st->mask = 0; st->thr_bits = 0;
   if (n <= 0 || rank < 0 || rank >= n) {
@@ -235,9 +252,11 @@ __global__ void init_state_kernel(SelState* st, int P, const int32_t* __restrict
 __global__ void gather_kernel(const int32_t* __restrict__ idx, const int32_t* __restrict__ keep,
                               const int32_t* __restrict__ M_dev, const float* __restrict__ pts,
                               const float* __restrict__ pix_xy, float* __restrict__ p3d,
-                              float* __restrict__ p2d) {
+                              float* __restrict__ p2d, int64_t P, int64_t pix_stride) {
+  const int b = blockIdx.z;
+  idx += b * P; keep += b * P; pix_xy += b * pix_stride; p3d += b * P * 3; p2d += b * P * 2;
   const int m = blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= *M_dev) return;
+  if (m >= M_dev[b]) return;
   const int p = keep[m];
   const int k = idx[p];
   p3d[3 * (size_t)m] = pts[3 * (size_t)k];
@@ -249,38 +268,49 @@ __global__ void gather_kernel(const int32_t* __restrict__ idx, const int32_t* __
 
 }  // namespace
 
-extern "C" size_t isr_select_top_workspace_bytes(int P) {
-  if (P <= 0) return 0;
+static size_t select_ws_bytes(int P, int B) {
   const size_t nblocks = ((size_t)P + kChunk - 1) / kChunk;
-  return 256 /*state*/ + 3 * isr::align_up(2048 * 4, 256) + isr::align_up(nblocks * 4, 256) + 256;
+  return isr::align_up(sizeof(SelState) * B, 256) + isr::align_up((size_t)kHistInts * 4 * B, 256) +
+         isr::align_up(nblocks * 4 * B, 256) + 256;
 }
 
-static int select_top_impl(const float* logp, int P, const int32_t* n_dev, double frac, int min_n, int32_t* keep,
-                           int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes, isr_stream_t stream_) {
-  if (!ws || ws_bytes < isr_select_top_workspace_bytes(P)) {
-    isr::set_error("isr_select_top: workspace %zu < %zu", ws_bytes, isr_select_top_workspace_bytes(P));
+extern "C" size_t isr_select_top_workspace_bytes(int P) {
+  if (P <= 0) return 0;
+  return select_ws_bytes(P, 1);
+}
+
+extern "C" size_t isr_select_top_batch_workspace_bytes(int P, int B) {
+  if (P <= 0 || B <= 0) return 0;
+  return select_ws_bytes(P, B);
+}
+
+static int select_top_impl(const float* logp, int P, int64_t ld, int B, const int32_t* n_dev, double frac, int min_n,
+                           int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
+                           isr_stream_t stream_) {
+  if (!ws || ws_bytes < select_ws_bytes(P, B)) {
+    isr::set_error("isr_select_top: workspace %zu < %zu", ws_bytes, select_ws_bytes(P, B));
     return ISR_ERR_WORKSPACE;
   }
   hipStream_t stream = isr::as_stream(stream_);
   isr::Workspace w(ws, ws_bytes);
-  SelState* st = w.take<SelState>(1);
-  int32_t* h0 = w.take<int32_t>(2048);
-  int32_t* h1 = w.take<int32_t>(2048);
-  int32_t* h2 = w.take<int32_t>(2048);
+  SelState* st = w.take<SelState>(B);
+  int32_t* h0 = w.take<int32_t>((size_t)kHistInts * B);
+  int32_t* h1 = h0 + 2048;
+  int32_t* h2 = h0 + 4096;
   const int nblocks = (P + kChunk - 1) / kChunk;
-  int32_t* bc = w.take<int32_t>(nblocks);
+  int32_t* bc = w.take<int32_t>((size_t)nblocks * B);
+  const dim3 gI(1, 1, B), gP(nblocks, 1, B);
 
-  ISR_CHECK_HIP(hipMemsetAsync(h0, 0, (char*)bc - (char*)h0, stream));
-  init_state_kernel<<<1, 1, 0, stream>>>(st, P, n_dev, frac, min_n);
-  hist_kernel<21, 11><<<nblocks, kThreads, 0, stream>>>(logp, P, st, h0);
-  pick_kernel<21, 11, false><<<1, 1024, 0, stream>>>(h0, st, nullptr);
-  hist_kernel<10, 11><<<nblocks, kThreads, 0, stream>>>(logp, P, st, h1);
-  pick_kernel<10, 11, false><<<1, 1024, 0, stream>>>(h1, st, nullptr);
-  hist_kernel<0, 10><<<nblocks, kThreads, 0, stream>>>(logp, P, st, h2);
-  pick_kernel<0, 10, true><<<1, 1024, 0, stream>>>(h2, st, thr_dev);
-  count_kernel<<<nblocks, kThreads, 0, stream>>>(logp, P, st, bc);
-  scan_blocks_kernel<<<1, 1024, 0, stream>>>(bc, nblocks, M_dev);
-  scatter_kernel<<<nblocks, kThreads, 0, stream>>>(logp, P, st, bc, keep);
+  init_state_kernel<<<gI, 256, 0, stream>>>(st, h0, P, n_dev, frac, min_n);
+  hist_kernel<21, 11><<<gP, kThreads, 0, stream>>>(logp, ld, st, h0);
+  pick_kernel<21, 11, false><<<gI, 1024, 0, stream>>>(h0, st, nullptr);
+  hist_kernel<10, 11><<<gP, kThreads, 0, stream>>>(logp, ld, st, h1);
+  pick_kernel<10, 11, false><<<gI, 1024, 0, stream>>>(h1, st, nullptr);
+  hist_kernel<0, 10><<<gP, kThreads, 0, stream>>>(logp, ld, st, h2);
+  pick_kernel<0, 10, true><<<gI, 1024, 0, stream>>>(h2, st, thr_dev);
+  count_kernel<<<gP, kThreads, 0, stream>>>(logp, ld, st, bc);
+  scan_blocks_kernel<<<gI, 1024, 0, stream>>>(bc, nblocks, M_dev);
+  scatter_kernel<<<gP, kThreads, 0, stream>>>(logp, ld, st, bc, keep, (int64_t)P);
   ISR_CHECK_LAUNCH("select_top kernels");
   return ISR_OK;
 }
@@ -292,7 +322,7 @@ extern "C" int isr_select_top(const float* logp, int P, double frac, int min_n, 
   ISR_REQUIRE(P > 0, "isr_select_top: P=%d (the reference indexes an empty sort and raises)", P);
   const long rank = select_rank(P, frac, min_n);
   ISR_REQUIRE(rank >= 0 && rank < P, "isr_select_top: rank %ld out of range for P=%d (IndexError in the reference)", rank, P);
-  return select_top_impl(logp, P, nullptr, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_);
+  return select_top_impl(logp, P, P, 1, nullptr, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_);
 }
 
 extern "C" int isr_select_top_dev(const float* logp, int P_cap, const int32_t* n_dev, double frac, int min_n,
@@ -300,7 +330,27 @@ extern "C" int isr_select_top_dev(const float* logp, int P_cap, const int32_t* n
                                   isr_stream_t stream_) {
   ISR_REQUIRE(logp && keep && M_dev && n_dev, "isr_select_top_dev: null pointer");
   ISR_REQUIRE(P_cap > 0, "isr_select_top_dev: P_cap=%d", P_cap);
-  return select_top_impl(logp, P_cap, n_dev, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_);
+  return select_top_impl(logp, P_cap, P_cap, 1, n_dev, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_);
+}
+
+extern "C" int isr_select_top_batch(const float* logp, int P, int B, const int32_t* n_dev, double frac, int min_n,
+                                    int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
+                                    isr_stream_t stream_) {
+  ISR_REQUIRE(logp && keep && M_dev, "isr_select_top_batch: null pointer");
+  ISR_REQUIRE(P > 0 && B > 0 && B <= 65535, "isr_select_top_batch: P=%d B=%d", P, B);
+  if (!n_dev) {
+    const long rank = select_rank(P, frac, min_n);
+    ISR_REQUIRE(rank >= 0 && rank < P, "isr_select_top_batch: rank %ld out of range for P=%d", rank, P);
+  }
+  return select_top_impl(logp, P, P, B, n_dev, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_);
+}
+
+static int gather_impl(const int32_t* idx, const int32_t* keep, const int32_t* M_dev, int P, int B, const float* pts,
+                       const float* pix_xy, int64_t pix_stride, float* p3d, float* p2d, isr_stream_t stream) {
+  gather_kernel<<<dim3((P + 255) / 256, 1, B), 256, 0, isr::as_stream(stream)>>>(idx, keep, M_dev, pts, pix_xy,
+                                                                                 p3d, p2d, (int64_t)P, pix_stride);
+  ISR_CHECK_LAUNCH("gather_kernel");
+  return ISR_OK;
 }
 
 extern "C" int isr_gather_corr(const int32_t* idx, const int32_t* keep, const int32_t* M_dev, int P,
@@ -308,8 +358,13 @@ extern "C" int isr_gather_corr(const int32_t* idx, const int32_t* keep, const in
                                isr_stream_t stream) {
   ISR_REQUIRE(idx && keep && M_dev && pts && pix_xy && p3d && p2d, "isr_gather_corr: null pointer");
   ISR_REQUIRE(P > 0 && N > 0, "isr_gather_corr: P=%d N=%d", P, N);
-  gather_kernel<<<(P + 255) / 256, 256, 0, isr::as_stream(stream)>>>(idx, keep, M_dev, pts, pix_xy,
-                                                                     p3d, p2d);
-  ISR_CHECK_LAUNCH("gather_kernel");
-  return ISR_OK;
+  return gather_impl(idx, keep, M_dev, P, 1, pts, pix_xy, 0, p3d, p2d, stream);
+}
+
+extern "C" int isr_gather_corr_batch(const int32_t* idx, const int32_t* keep, const int32_t* M_dev, int P, int B,
+                                     const float* pts, int N, const float* pix_xy, int shared_pix, float* p3d,
+                                     float* p2d, isr_stream_t stream) {
+  ISR_REQUIRE(idx && keep && M_dev && pts && pix_xy && p3d && p2d, "isr_gather_corr_batch: null pointer");
+  ISR_REQUIRE(P > 0 && N > 0 && B > 0 && B <= 65535, "isr_gather_corr_batch: P=%d N=%d B=%d", P, N, B);
+  return gather_impl(idx, keep, M_dev, P, B, pts, pix_xy, shared_pix ? 0 : (int64_t)P * 2, p3d, p2d, stream);
 }

@@ -378,6 +378,79 @@ def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
     return PnPResult(pose, inl, n_inl, status)
 
 
+# ------------------------------------------------------------------ the per-group (batched) chain
+def select_top_batch(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500, n_dev: torch.Tensor | None = None):
+    """isr_select_top_batch: logp (B, P) -> keep (B, P) i32 (first M[b] valid, ascending), M (B,) i32,
+    thr (B,) f32.  One chain of ten launches for the whole group; outputs are not pre-filled."""
+    dev = require_cuda(logp, n_dev)
+    logp = _f32c(logp)
+    B, P = logp.shape
+    keep = torch.empty((B, P), dtype=torch.int32, device=dev)
+    M_dev = torch.empty(B, dtype=torch.int32, device=dev)
+    thr = torch.empty(B, dtype=torch.float32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_select_top_batch_workspace_bytes(P, B), "select")
+    with torch.cuda.device(dev), _timed("select_top", 4.0 * P * B):
+        rc = L.isr_select_top_batch(ptr(logp), P, B, ptr(n_dev), float(frac), int(min_n), ptr(keep), ptr(M_dev),
+                                    ptr(thr), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_select_top_batch")
+    return keep, M_dev, thr
+
+
+def gather_corr_batch(idx, keep, M_dev, pts, pix_xy):
+    """isr_gather_corr_batch: idx, keep (B, P); pix_xy (P, 2) shared or (B, P, 2) -> p3d (B, P, 3), p2d (B, P, 2)."""
+    dev = require_cuda(idx, keep, M_dev, pts, pix_xy)
+    pts, pix_xy = _f32c(pts), _f32c(pix_xy)
+    B, P = keep.shape
+    shared = pix_xy.ndim == 2
+    if tuple(pix_xy.shape) != ((P, 2) if shared else (B, P, 2)) or tuple(idx.shape) != (B, P):
+        raise ValueError(f"gather_corr_batch: idx {tuple(idx.shape)} / keep {tuple(keep.shape)} / pix_xy {tuple(pix_xy.shape)}")
+    p3d = torch.empty((B, P, 3), dtype=torch.float32, device=dev)
+    p2d = torch.empty((B, P, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_gather_corr_batch(ptr(idx.contiguous()), ptr(keep), ptr(M_dev), P, B, ptr(pts), pts.shape[0],
+                                         ptr(pix_xy), int(shared), ptr(p3d), ptr(p2d), current_stream(dev))
+    check(rc, "isr_gather_corr_batch")
+    return p3d, p2d
+
+
+@dataclass
+class PnPBatchResult:
+    pose: torch.Tensor      # (B,3,4) f64 device
+    inl_idx: torch.Tensor   # (B,cap) i32 device, first n_inl[b] valid
+    n_inl: torch.Tensor     # (B,) i32 device
+    status: torch.Tensor    # (B,) i32 device
+
+
+def pnp_ransac_batch(p3d, p2d, Kcams, M_dev, H: int = 500, reperr: float = 2.0, seeds=None,
+                     refine_iters: int = 10) -> PnPBatchResult:
+    """isr_pnp_ransac_batch: p3d (B, cap, 3), p2d (B, cap, 2), M_dev (B,) i32; Kcams one 3x3 or (B, 3, 3)
+    host array; seeds B ints.  Every output stays on the device, nothing is pre-filled."""
+    import ctypes
+    import numpy as np
+    dev = require_cuda(p3d, p2d, M_dev)
+    p3d, p2d = _f32c(p3d), _f32c(p2d)
+    B, cap = p3d.shape[0], p3d.shape[1]
+    K = np.asarray(Kcams, dtype=np.float64)
+    K = np.ascontiguousarray(np.broadcast_to(K.reshape(-1, 3, 3), (B, 3, 3)) if K.size == 9 else K.reshape(B, 3, 3))
+    sd = np.ascontiguousarray(np.asarray([0] * B if seeds is None else [int(x) & 0xFFFFFFFFFFFFFFFF for x in seeds],
+                                         dtype=np.uint64))
+    if sd.shape != (B,):
+        raise ValueError("pnp_ransac_batch: one seed per image")
+    pose = torch.empty((B, 3, 4), dtype=torch.float64, device=dev)
+    inl = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    n_inl = torch.empty(B, dtype=torch.int32, device=dev)
+    status = torch.empty(B, dtype=torch.int32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_pnp_ransac_batch_workspace_bytes(cap, H, B), "ransac")
+    with torch.cuda.device(dev), _timed("pnp_ransac", 30.0 * H * cap * B):
+        rc = L.isr_pnp_ransac_batch(ptr(p3d), ptr(p2d), ptr(M_dev), cap, B, K.ctypes.data_as(ctypes.c_void_p), int(H),
+                                    sd.ctypes.data_as(ctypes.c_void_p), float(reperr), int(refine_iters), ptr(pose),
+                                    ptr(inl), ptr(n_inl), ptr(status), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_pnp_ransac_batch")
+    return PnPBatchResult(pose, inl, n_inl, status)
+
+
 def add_metric(verts: torch.Tensor, Ta: torch.Tensor | None, Tb: torch.Tensor | None) -> torch.Tensor:
     """isr_add_metric: (B,) f64 mean vertex distance between poses Ta[b] and Tb[b]."""
     dev = require_cuda(verts, Ta, Tb)

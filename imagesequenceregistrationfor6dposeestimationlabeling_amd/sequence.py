@@ -77,6 +77,16 @@ def register_crop(model: SequenceModel, feat: torch.Tensor, mask: torch.Tensor, 
     return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp), n_dev
 
 
+def _publish(results: list[ImageResult], consumer: torch.cuda.Stream) -> None:
+    """The tensors of `results` were allocated on side streams and are about to be read on `consumer`
+    (which has been made to wait for those streams).  Tell the caching allocator: without
+    record_stream a dropped result's block goes back to its side stream's pool at once, and the next
+    step's allocations there may overwrite it while `consumer` is still reading."""
+    for r in results:
+        for t in (r.pose, r.status, r.n_inl, r.inl_idx, r.keep, r.M, r.idx, r.logp):
+            t.record_stream(consumer)
+
+
 _streams: dict[tuple, list] = {}
 
 
@@ -129,47 +139,63 @@ def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: f
         out.append(ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp))
     for s in pool:
         cur.wait_stream(s)
+    _publish(out, cur)
     return out
+
+
+def register_group(model: SequenceModel, idx_g: torch.Tensor, logp_g: torch.Tensor, pix_xy: torch.Tensor, cams,
+                   itr: int, reperr: float, seeds, refine_iters: int) -> list[ImageResult]:
+    """inference.py:282-293 for a GROUP of images whose K1 results are idx_g / logp_g (B, P): the
+    top-80 % filter, the correspondence assembly and pnp() run as ONE chain of launches with the
+    image on blockIdx.z (isr_select_top_batch, isr_gather_corr_batch, isr_pnp_ransac_batch) — the
+    same kernels as the per-image calls, so every image's outputs are bit-identical to
+    register_image's.  pix_xy (P, 2) shared or (B, P, 2); cams one 3x3 or (B, 3, 3)."""
+    B = idx_g.shape[0]
+    keep, M, _ = ops.select_top_batch(logp_g)
+    p3d, p2d = ops.gather_corr_batch(idx_g, keep, M, model.pts, pix_xy)
+    r = ops.pnp_ransac_batch(p3d, p2d, cams, M, H=itr, reperr=reperr, seeds=seeds, refine_iters=refine_iters)
+    return [ImageResult(r.pose[b], r.status[b:b + 1], r.n_inl[b:b + 1], r.inl_idx[b], keep[b], M[b:b + 1], idx_g[b], logp_g[b])
+            for b in range(B)]
 
 
 def register_block(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Tensor, cam, itr: int = 500,
                    reperr: float = 2.0, seed0: int = 0, refine_iters: int = 10, n_streams: int = 3,
                    group: int = 8) -> list[ImageResult]:
-    """register_images for a block held as ONE tensor: queries (n, P, D), pix_xy (n, P, 2).
-    K1 runs once per `group` images on (group * P) query rows — the images are independent, so this
-    only changes the launch shape: a 640x480 image alone is 1.17 rounds of resident workgroups, eight
-    together are 9.4, and the launch tail shrinks from ~20 % to ~3 % of K1's time.  The per-image
-    filter / assembly / RANSAC chains then run on the side streams as in register_images."""
+    """register_images for a block held as ONE tensor: queries (n, P, D), pix_xy (n, P, 2) or (P, 2).
+    K1 runs once per `group` images on (group * P) query rows — K1's result for a query does not
+    depend on the launch it rides in, so this only changes the launch shape: a 640x480 image alone is
+    1.17 rounds of resident workgroups, sixteen together are 18.8, and the launch tail shrinks from
+    ~20 % to ~2 % of K1's time.  The group's filter / assembly / RANSAC chain (register_group: ~30
+    launches for the whole group instead of ~35 per image) runs on a side stream beside the next K1
+    launch; groups alternate between the side streams."""
     dev = model.keys.device
     n, P = queries.shape[0], queries.shape[1]
     cur = torch.cuda.current_stream(dev)
-    cam_of = (lambda j: cam) if np.ndim(cam) == 2 else (lambda j: cam[j])
+    cams = np.asarray(cam, np.float64)
+    cams = np.broadcast_to(cams, (n, 3, 3)) if cams.ndim == 2 else cams
     pool = _stream_pool(dev, max(n_streams, 2))
     for s in pool:
         s.wait_stream(cur)
     k1_stream, side = pool[0], pool[1:]
     out = []
-    for g0 in range(0, n, group):
+    for gi, g0 in enumerate(range(0, n, group)):
         g1 = min(n, g0 + group)
         with torch.cuda.stream(k1_stream):
             idx_g, logp_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys,
                                              log2_prescaled=model.log2_queries)
             done = torch.cuda.Event()
             done.record(k1_stream)
-        for j in range(g0, g1):
-            s = side[j % len(side)]
-            s.wait_event(done)
-            idx, logp = idx_g[(j - g0) * P:(j - g0 + 1) * P], logp_g[(j - g0) * P:(j - g0 + 1) * P]
-            idx_g.record_stream(s)
-            logp_g.record_stream(s)
-            with torch.cuda.stream(s):
-                keep, M, _ = ops.select_top(logp)
-                p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix_xy[j])
-                r = ops.pnp_ransac(p3d, p2d, cam_of(j), H=itr, reperr=reperr, seed=seed0 + j,
-                                   refine_iters=refine_iters, M_dev=M)
-            out.append(ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp))
+        s = side[gi % len(side)]
+        s.wait_event(done)
+        idx_g.record_stream(s)
+        logp_g.record_stream(s)
+        with torch.cuda.stream(s):
+            out += register_group(model, idx_g.view(g1 - g0, P), logp_g.view(g1 - g0, P),
+                                  pix_xy if pix_xy.ndim == 2 else pix_xy[g0:g1], cams[g0:g1], itr, reperr,
+                                  [seed0 + j for j in range(g0, g1)], refine_iters)
     for s in pool:
         cur.wait_stream(s)
+    _publish(out, cur)
     return out
 
 

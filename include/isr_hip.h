@@ -114,12 +114,26 @@ int isr_select_top_dev(const float* logp, int P_cap, const int32_t* n_dev, doubl
                        int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
                        isr_stream_t stream);
 
+/* The cut for a GROUP of B images in one chain of ten launches (the per-image loop of inference.py:163
+ * over the group): logp (B, P), keep (B, P), M_dev (B), thr_dev (B, nullable); n_dev (B) device counts
+ * or NULL (every image has P values).  Same kernels as the single-image calls: identical results. */
+size_t isr_select_top_batch_workspace_bytes(int P, int B);
+int isr_select_top_batch(const float* logp, int P, int B, const int32_t* n_dev, double frac, int min_n,
+                         int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
+                         isr_stream_t stream);
+
 /* a3  correspondence assembly  (inference.py:274-280, 289-290)
  * p3d[m] = pts[idx[keep[m]]], p2d[m] = pix_xy[keep[m]]  for m < *M_dev.  pts (N,3), pix_xy (P,2)
  * = (col,row) of every query pixel, both f32.  p3d (P,3) / p2d (P,2) have capacity P rows. */
 int isr_gather_corr(const int32_t* idx, const int32_t* keep, const int32_t* M_dev, int P,
                     const float* pts, int N, const float* pix_xy, float* p3d, float* p2d,
                     isr_stream_t stream);
+
+/* a3 for a group of B images: idx, keep (B, P), M_dev (B), p3d (B, P, 3), p2d (B, P, 2); pix_xy is
+ * (P, 2) shared by all images (shared_pix != 0, e.g. a full pixel grid) or (B, P, 2). */
+int isr_gather_corr_batch(const int32_t* idx, const int32_t* keep, const int32_t* M_dev, int P, int B,
+                          const float* pts, int N, const float* pix_xy, int shared_pix, float* p3d,
+                          float* p2d, isr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K2  PnP + RANSAC:  pnp(h3d, h2d, cam, itr, reperr, P3P)
@@ -156,6 +170,16 @@ int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int
                    const double* Kcam, int H, uint64_t seed, float reperr, int refine_iters,
                    double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev, int32_t* status_dev,
                    void* ws, size_t ws_bytes, isr_stream_t stream);
+
+/* isr_pnp_ransac for a GROUP of B images as one chain of launches (image = blockIdx.z of every kernel):
+ * p3d (B, M_cap, 3), p2d (B, M_cap, 2), M_dev (B); Kcams HOST (B, 9) f64, seeds HOST (B) u64;
+ * pose_dev (B, 12), inl_idx (B, M_cap), n_inl_dev (B), status_dev (B).  Same kernels as the
+ * single-image call: image b's outputs are bit-identical to isr_pnp_ransac on image b alone. */
+size_t isr_pnp_ransac_batch_workspace_bytes(int M_cap, int H, int B);
+int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B,
+                         const double* Kcams, int H, const uint64_t* seeds, float reperr,
+                         int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
+                         int32_t* status_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3 / K4  batched brute-force nearest neighbour with fused reductions

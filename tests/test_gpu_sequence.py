@@ -89,3 +89,58 @@ def test_vote_choose_image_matches_reference_double_loop(cuda0):
     sums = rerr.sum(1)
     assert img == int(np.argmax(sums)) and img not in (2, 5)
     assert list(top) == list(np.argsort(-sums, kind="stable")[:50])
+
+
+def test_group_chain_equals_per_image_chain(cuda0):
+    """isr_select_top_batch / isr_gather_corr_batch / isr_pnp_ransac_batch (image = blockIdx.z, 18 images:
+    two kernel-argument chunks) against the per-image entry points: every output bit-identical, with
+    per-image cameras, seeds and kept counts, and with device-side element counts (ragged images)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, sequence
+    B, P = 18, 3000
+    model, Q, pix, K, R, t, _ = _block(cuda0, n=B, P=P, N=1500, seed=4)
+    idx, logp = ops.corr_argmax(Q.reshape(B * P, -1), model.keys)
+    idx, logp = idx.view(B, P), logp.view(B, P)
+    cams = np.stack([K + np.diag([b * 0.5, -b * 0.25, 0.0]) for b in range(B)])
+    seeds = [100 + 7 * b for b in range(B)]
+    n_dev = torch.tensor([P - 37 * b for b in range(B)], dtype=torch.int32, device=cuda0)
+    for nd in (None, n_dev):
+        keep, M, thr = ops.select_top_batch(logp, n_dev=nd)
+        p3d, p2d = ops.gather_corr_batch(idx, keep, M, model.pts, pix)
+        r = ops.pnp_ransac_batch(p3d, p2d, cams, M, H=150, reperr=2.0, seeds=seeds, refine_iters=6)
+        torch.cuda.synchronize()
+        for b in range(B):
+            k1, M1, t1 = ops.select_top(logp[b], n_dev=None if nd is None else nd[b:b + 1])
+            m = int(M1.item())
+            assert int(M[b].item()) == m and torch.equal(keep[b, :m], k1[:m]) and torch.equal(thr[b:b + 1], t1)
+            a3, a2 = ops.gather_corr(idx[b], k1, M1, model.pts, pix[b])
+            assert torch.equal(p3d[b, :m], a3[:m]) and torch.equal(p2d[b, :m], a2[:m])
+            r1 = ops.pnp_ransac(a3, a2, cams[b], H=150, reperr=2.0, seed=seeds[b], refine_iters=6, M_dev=M1)
+            n = int(r1.n_inl.item())
+            assert int(r.n_inl[b].item()) == n and int(r.status[b].item()) == int(r1.status.item()) == 1
+            assert torch.equal(r.pose[b], r1.pose) and torch.equal(r.inl_idx[b, :n], r1.inl_idx[:n])
+    # a shared pixel grid (one (P, 2) array for every image) gathers the same rows
+    p3s, p2s = ops.gather_corr_batch(idx, keep, M, model.pts, pix[0])
+    m0 = int(M[3].item())
+    assert torch.equal(p3s, p3d) and torch.equal(p2s[3, :m0], pix[0][keep[3, :m0].long()])
+
+
+def test_pipelined_steps_with_dropped_results(cuda0):
+    """Steps issued back to back on alternating streams with each step's ImageResults dropped as soon as
+    its poses are stacked (what bench.py does): the outputs were allocated on side streams, so without
+    record_stream the next step's allocations could overwrite them before the stack has read them.
+    group=1 and small P make K1 too short to hide such a race."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence
+    model, Q, pix, K, R, t, _ = _block(cuda0, n=8, P=2500, N=1200, seed=6)
+    ref, _ = sequence.stack_poses(sequence.register_block(model, Q, pix, K, itr=100, seed0=3, group=1))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=cuda0), torch.cuda.Stream(device=cuda0)]
+    outs = []
+    for step in range(6):
+        with torch.cuda.stream(streams[step & 1]):
+            res = sequence.register_block(model, Q, pix, K, itr=100, seed0=3, group=1 if step % 2 else 3)
+            poses, status = sequence.stack_poses(res)
+        del res
+        outs.append((poses, status))
+    torch.cuda.synchronize()
+    for poses, status in outs:
+        assert torch.equal(poses, ref) and int(status.sum().item()) == 8
