@@ -70,6 +70,10 @@ def parse_args():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish a step's ICP + final Chamfer before the next step's registration starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--confidence", type=float, default=0.99,
+                    help="RANSAC confidence (cv2.solvePnPRansac's parameter; its default 0.99 is what the reference's "
+                         "call uses); 1 scores every hypothesis")
+    ap.add_argument("--ablate", default="", help="debug only (not a valid bench line): 'noverify' skips a13-a15")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg")
     return ap.parse_args()
 
@@ -202,10 +206,11 @@ def main():
             if args.group > 1:
                 res = sequence.register_block(model, Q_all, pix_all, Kcam, itr=args.itr, reperr=2.0,
                                               seed0=(s << 20) + lo, refine_iters=args.refine_iters,
-                                              n_streams=args.streams, group=args.group)
+                                              n_streams=args.streams, group=args.group, confidence=args.confidence)
             else:
                 res = sequence.register_images(model, images, Kcam, itr=args.itr, reperr=2.0, seed0=(s << 20) + lo,
-                                               refine_iters=args.refine_iters, n_streams=args.streams)
+                                               refine_iters=args.refine_iters, n_streams=args.streams,
+                                               confidence=args.confidence)
             poses, status = sequence.stack_poses(res)
             ev = torch.cuda.Event()
             ev.record(reg_streams[s & 1])
@@ -220,6 +225,9 @@ def main():
         stream and, pipelined, in a worker thread (current device and stream are thread-local; this
         thread issues the step's collectives, the main thread issues none inside the timed loop)."""
         torch.cuda.set_device(dev)
+        if args.ablate == "noverify":
+            ev.synchronize()
+            return {"ablate": "noverify", "registered_this_rank": int(status.sum().item())}
         with torch.cuda.stream(tail_stream):
             tail_stream.wait_event(ev)
             poses_all = shard.allgather_rows(poses, n_total)
@@ -313,6 +321,7 @@ def main():
                                     f"({args.itr} P3P hypotheses, 2 px); per step consecutive-pair Chamfer pick "
                                     f"(packed min all-reduce), ICP + final Chamfer on rank 0"),
                        "images_per_gpu": n_local, "P": P, "N": N, "D": D, "hypotheses": args.itr,
+                       "ransac_confidence": args.confidence,
                        "parallelism": f"image-sharded x{world}",
                        "step_overlap": ("none" if args.no_pipeline else
                                         "verification (all-gather, Chamfer pick, ICP, final Chamfer) of batch s "

@@ -50,7 +50,7 @@ SIGNATURES = {
     "isr_select_top_batch": (_i, [_vp, _i, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "isr_pnp_ransac_batch_workspace_bytes": (_sz, [_i, _i, _i]),
-    "isr_pnp_ransac_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_pnp_ransac_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_prep_queries_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_prep_queries": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
@@ -58,7 +58,7 @@ SIGNATURES = {
     "isr_p3p_hypotheses": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp]),
     "isr_ransac_score": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_pnp_refine": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
-    "isr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _f, _i, _vp, _vp, _vp, _vp, _vp,
+    "isr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _f, _d, _i, _vp, _vp, _vp, _vp, _vp,
                             _sz, _vp]),
     "isr_nn_batched_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_nn_batched": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -99,8 +99,8 @@ def lib() -> C.CDLL:
             raise IsrError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if L.isr_abi_version() != 1:
-        raise IsrError(f"ABI version {L.isr_abi_version()} != 1")
+    if L.isr_abi_version() != 2:
+        raise IsrError(f"ABI version {L.isr_abi_version()} != 2")
     _lib = L
     return L
 

@@ -18,6 +18,12 @@
 //                   hypotheses with the 3x4 projection in SGPRs; ballot + s_bcnt1 counts a wave's
 //                   inliers, LDS integer atomics per block, one global integer atomic per
 //                   (block, hypothesis): deterministic.
+//                   Adaptive termination (cv2.solvePnPRansac's `confidence`, default 0.99): hypotheses
+//                   are scored in stages [0,32), [32,96), [96,224), ... (boundaries 32 (2^k - 1)); a
+//                   stage runs only if, at the boundary b before it, the best count c so far does
+//                   NOT yet give the confidence:  (1 - (c/M)^4)^b > 1 - confidence  (the standard
+//                   RANSAC rule for 4-point samples, evaluated with multiplications only so that
+//                   oracle and device decide identically).  confidence >= 1: every hypothesis.
 //   3. best         arg-max count, lowest h on ties; its inlier bitmask.
 //   4. refit        Gauss-Newton on the reprojection error over the inliers, f64, fixed-shape
 //                   tree reduction of J^T J / J^T r, 6x6 Cholesky on the device.
@@ -147,11 +153,30 @@ constexpr int kScoreThreads = 256;
 constexpr int kCPL = ISR_SCORE_CPL;   // correspondences per lane
 constexpr int kHC = ISR_SCORE_HC;     // hypotheses per block: grid.y = ceil(H / kHC) keeps >= 8 waves per SIMD
 constexpr int kMaxH = 8192;
+constexpr int kStage0 = 32;           // hypotheses of the first scoring stage (a multiple of kHC)
+static_assert(kStage0 % kHC == 0, "stage boundaries are chunk boundaries");
 
+// RANSAC's stopping rule after b hypotheses with best inlier count c of M, 4-point samples:
+//   (1 - (c/M)^4)^b <= 1 - confidence.   Multiplications only (binary powering in a fixed order):
+// IEEE arithmetic, the same decision in oracle/pnp_oracle.py:stop_rule bit for bit.
+__host__ __device__ inline bool ransac_stop(int c, int M, int b, double one_minus_conf) {
+  if (c < 4 || M <= 0 || !(one_minus_conf > 0.0)) return false;
+  const double w = (double)c / (double)M;
+  const double w2 = w * w;
+  double base = 1.0 - w2 * w2, q = 1.0;
+  for (int e = b; e > 0; e >>= 1) {
+    if (e & 1) q = q * base;
+    base = base * base;
+  }
+  return q <= one_minus_conf;
+}
+
+// Hypotheses [h_lo, h_hi) of every image; blockIdx.y counts kHC-chunks from h_lo.  h_lo > 0: the stage
+// first applies the stopping rule at its lower boundary (best count over hypotheses < h_lo).
 __global__ __launch_bounds__(kScoreThreads) void score_kernel(
     const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev, int M_cap,
-    const float* __restrict__ Pm, const uint8_t* __restrict__ ok, int H, float reperr,
-    int32_t* __restrict__ n_inl) {
+    const float* __restrict__ Pm, const uint8_t* __restrict__ ok, int H, int h_lo, int h_hi, double one_minus_conf,
+    float reperr, int32_t* __restrict__ n_inl) {
   __shared__ int32_t cnt[kHC];
   __shared__ __attribute__((aligned(16))) float Ps[kHC][12];   // the block's projection matrices: one
   __shared__ uint8_t oks[kHC];                                  // coalesced load, then LDS broadcasts
@@ -161,8 +186,19 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
   const int M = M_dev[b];
   const int base = blockIdx.x * (kScoreThreads * kCPL);
   if (base >= M) return;  // block-uniform
-  const int h0 = blockIdx.y * kHC;
-  const int h1 = min(H, h0 + kHC);
+  if (h_lo > 0) {         // stage gate (block-uniform): counts of the earlier stages are final
+    __shared__ int32_t cmax[kScoreThreads / 64];
+    int c = 0;
+    for (int i = threadIdx.x; i < h_lo; i += kScoreThreads) c = max(c, ok[i] ? n_inl[i] : 0);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c = max(c, __shfl_xor(c, o, 64));
+    if ((threadIdx.x & 63) == 0) cmax[threadIdx.x >> 6] = c;
+    __syncthreads();
+    c = max(max(cmax[0], cmax[1]), max(cmax[2], cmax[3]));
+    if (ransac_stop(c, M, h_lo, one_minus_conf)) return;
+  }
+  const int h0 = h_lo + blockIdx.y * kHC;
+  const int h1 = min(h_hi, h0 + kHC);
   if (threadIdx.x < kHC) {
     cnt[threadIdx.x] = 0;
     oks[threadIdx.x] = (h0 + (int)threadIdx.x < h1) ? ok[h0 + threadIdx.x] : 0;
@@ -561,12 +597,19 @@ extern "C" int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int3
 }
 
 static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgBatch& ib,
-                      const double* Rt, const uint8_t* ok, int H, float reperr, float* Pm, int32_t* n_inl,
-                      int32_t* best_dev, uint32_t* best_mask, int32_t* status_dev, double* pose_dev,
+                      const double* Rt, const uint8_t* ok, int H, double confidence, float reperr, float* Pm,
+                      int32_t* n_inl, int32_t* best_dev, uint32_t* best_mask, int32_t* status_dev, double* pose_dev,
                       int32_t* gn_state, hipStream_t stream) {
   proj_matrix_kernel<<<dim3((H * 12 + 255) / 256, 1, B), 256, 0, stream>>>(Rt, ib, H, Pm, n_inl);
   const int nblk = (M_cap + kScoreThreads * kCPL - 1) / (kScoreThreads * kCPL);
-  score_kernel<<<dim3(nblk, (H + kHC - 1) / kHC, B), kScoreThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, Pm, ok, H, reperr, n_inl);
+  const double omc = (confidence >= 1.0) ? 0.0 : 1.0 - confidence;
+  // stages [0,32), [32,96), [96,224), ...: boundaries 32 (2^k - 1); one stage when every hypothesis is wanted
+  for (int lo = 0, len = (omc > 0.0) ? kStage0 : H; lo < H; lo += len, len *= 2) {
+    const int hi = (lo + len < H) ? lo + len : H;
+    score_kernel<<<dim3(nblk, (hi - lo + kHC - 1) / kHC, B), kScoreThreads, 0, stream>>>(
+        p3d, p2d, M_dev, M_cap, Pm, ok, H, lo, hi, omc, reperr, n_inl);
+    if (hi == H) break;
+  }
   best_kernel<<<dim3(1, 1, B), 256, 0, stream>>>(n_inl, ok, H, best_dev, status_dev, Rt, pose_dev, gn_state);
   if (best_mask)
     best_mask_kernel<<<dim3((M_cap + 255) / 256, 1, B), 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, H, Pm, best_dev, reperr,
@@ -589,7 +632,7 @@ extern "C" int isr_ransac_score(const float* p3d, const float* p2d, const int32_
   }
   isr::Workspace w(ws, ws_bytes);
   float* Pm = w.take<float>((size_t)H * 12);
-  return score_impl(p3d, p2d, M_dev, M_cap, 1, ib, Rt, ok, H, reperr, Pm, n_inl, best_dev, best_mask,
+  return score_impl(p3d, p2d, M_dev, M_cap, 1, ib, Rt, ok, H, 1.0, reperr, Pm, n_inl, best_dev, best_mask,
                     nullptr, nullptr, nullptr, isr::as_stream(stream_));
 }
 
@@ -626,11 +669,11 @@ extern "C" int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t*
 
 // the chain for B <= kMaxBatch images: hypotheses, scoring, best + mask, refit, compaction
 static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgBatch& ib,
-                        int H, float reperr, int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
-                        int32_t* status_dev, const RansacWs& b, hipStream_t stream) {
+                        int H, double confidence, float reperr, int refine_iters, double* pose_dev, int32_t* inl_idx,
+                        int32_t* n_inl_dev, int32_t* status_dev, const RansacWs& b, hipStream_t stream) {
   p3p_kernel<<<dim3((H + 63) / 64, 1, B), 64, 0, stream>>>(p3d, p2d, M_dev, M_cap, ib, H, b.Rt, b.ok, nullptr);
   ISR_CHECK_LAUNCH("p3p_kernel");
-  int rc = score_impl(p3d, p2d, M_dev, M_cap, B, ib, b.Rt, b.ok, H, reperr, b.Pm, b.n_inl, b.best, b.mask,
+  int rc = score_impl(p3d, p2d, M_dev, M_cap, B, ib, b.Rt, b.ok, H, confidence, reperr, b.Pm, b.n_inl, b.best, b.mask,
                       status_dev, pose_dev, b.state, stream);
   if (rc != ISR_OK) return rc;
   rc = refine_impl(p3d, p2d, M_dev, M_cap, B, b.mask, ib, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
@@ -644,9 +687,9 @@ static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev
 }
 
 extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
-                              const double* Kcam, int H, uint64_t seed, float reperr, int refine_iters,
-                              double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev, int32_t* status_dev,
-                              void* ws, size_t ws_bytes, isr_stream_t stream_) {
+                              const double* Kcam, int H, uint64_t seed, float reperr, double confidence,
+                              int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
+                              int32_t* status_dev, void* ws, size_t ws_bytes, isr_stream_t stream_) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && pose_dev && inl_idx && n_inl_dev && status_dev,
               "isr_pnp_ransac: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH, "isr_pnp_ransac: M_cap=%d H=%d (H <= %d)", M_cap, H, kMaxH);
@@ -659,17 +702,19 @@ extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t*
   isr::Workspace w(ws, ws_bytes);
   RansacWs b;
   carve(w, M_cap, H, 1, &b);
-  return ransac_chain(p3d, p2d, M_dev, M_cap, 1, ib, H, reperr, refine_iters, pose_dev, inl_idx, n_inl_dev, status_dev,
-                      b, isr::as_stream(stream_));
+  ISR_REQUIRE(confidence > 0.0, "isr_pnp_ransac: confidence=%g must be > 0 (>= 1: score every hypothesis)", confidence);
+  return ransac_chain(p3d, p2d, M_dev, M_cap, 1, ib, H, confidence, reperr, refine_iters, pose_dev, inl_idx, n_inl_dev,
+                      status_dev, b, isr::as_stream(stream_));
 }
 
 extern "C" int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B,
-                                    const double* Kcams, int H, const uint64_t* seeds, float reperr, int refine_iters,
-                                    double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev, int32_t* status_dev,
-                                    void* ws, size_t ws_bytes, isr_stream_t stream_) {
+                                    const double* Kcams, int H, const uint64_t* seeds, float reperr, double confidence,
+                                    int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
+                                    int32_t* status_dev, void* ws, size_t ws_bytes, isr_stream_t stream_) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcams && seeds && pose_dev && inl_idx && n_inl_dev && status_dev,
               "isr_pnp_ransac_batch: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH && B > 0, "isr_pnp_ransac_batch: M_cap=%d H=%d (H <= %d) B=%d", M_cap, H, kMaxH, B);
+  ISR_REQUIRE(confidence > 0.0, "isr_pnp_ransac_batch: confidence=%g must be > 0 (>= 1: score every hypothesis)", confidence);
   if (!ws || ws_bytes < isr_pnp_ransac_batch_workspace_bytes(M_cap, H, B)) {
     isr::set_error("isr_pnp_ransac_batch: workspace %zu < %zu", ws_bytes, isr_pnp_ransac_batch_workspace_bytes(M_cap, H, B));
     return ISR_ERR_WORKSPACE;
@@ -683,7 +728,7 @@ extern "C" int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const in
     RansacWs wsb;
     carve(w, M_cap, H, nb, &wsb);
     const int rc = ransac_chain(p3d + (size_t)b0 * M_cap * 3, p2d + (size_t)b0 * M_cap * 2, M_dev + b0, M_cap, nb, ib, H,
-                                reperr, refine_iters, pose_dev + (size_t)b0 * 12, inl_idx + (size_t)b0 * M_cap,
+                                confidence, reperr, refine_iters, pose_dev + (size_t)b0 * 12, inl_idx + (size_t)b0 * M_cap,
                                 n_inl_dev + b0, status_dev + b0, wsb, stream);
     if (rc != ISR_OK) return rc;
   }

@@ -356,8 +356,9 @@ class PnPResult:
 
 
 def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
-               refine_iters: int = 10, M_dev=None) -> PnPResult:
-    """isr_pnp_ransac, fully asynchronous: every output stays on the device."""
+               refine_iters: int = 10, M_dev=None, confidence: float = 0.99) -> PnPResult:
+    """isr_pnp_ransac, fully asynchronous: every output stays on the device.  confidence: cv2's
+    solvePnPRansac parameter (default 0.99, what the reference's call uses); >= 1 scores every hypothesis."""
     import ctypes
     dev = require_cuda(p3d, p2d)
     p3d, p2d = _f32c(p3d), _f32c(p2d)
@@ -372,7 +373,7 @@ def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
     k = _kcam(Kcam)
     with torch.cuda.device(dev), _timed("pnp_ransac", 30.0 * H * cap):
         rc = L.isr_pnp_ransac(ptr(p3d), ptr(p2d), ptr(M_dev), cap, ctypes.cast(k, ctypes.c_void_p), int(H),
-                              seed & 0xFFFFFFFFFFFFFFFF, float(reperr), int(refine_iters), ptr(pose),
+                              seed & 0xFFFFFFFFFFFFFFFF, float(reperr), float(confidence), int(refine_iters), ptr(pose),
                               ptr(inl), ptr(n_inl), ptr(status), ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_pnp_ransac")
     return PnPResult(pose, inl, n_inl, status)
@@ -423,7 +424,7 @@ class PnPBatchResult:
 
 
 def pnp_ransac_batch(p3d, p2d, Kcams, M_dev, H: int = 500, reperr: float = 2.0, seeds=None,
-                     refine_iters: int = 10) -> PnPBatchResult:
+                     refine_iters: int = 10, confidence: float = 0.99) -> PnPBatchResult:
     """isr_pnp_ransac_batch: p3d (B, cap, 3), p2d (B, cap, 2), M_dev (B,) i32; Kcams one 3x3 or (B, 3, 3)
     host array; seeds B ints.  Every output stays on the device, nothing is pre-filled."""
     import ctypes
@@ -445,7 +446,8 @@ def pnp_ransac_batch(p3d, p2d, Kcams, M_dev, H: int = 500, reperr: float = 2.0, 
     ws = workspace(dev, L.isr_pnp_ransac_batch_workspace_bytes(cap, H, B), "ransac")
     with torch.cuda.device(dev), _timed("pnp_ransac", 30.0 * H * cap * B):
         rc = L.isr_pnp_ransac_batch(ptr(p3d), ptr(p2d), ptr(M_dev), cap, B, K.ctypes.data_as(ctypes.c_void_p), int(H),
-                                    sd.ctypes.data_as(ctypes.c_void_p), float(reperr), int(refine_iters), ptr(pose),
+                                    sd.ctypes.data_as(ctypes.c_void_p), float(reperr), float(confidence),
+                                    int(refine_iters), ptr(pose),
                                     ptr(inl), ptr(n_inl), ptr(status), ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_pnp_ransac_batch")
     return PnPBatchResult(pose, inl, n_inl, status)

@@ -90,14 +90,15 @@ def filter_top(in1, frac=0.8, min_n=500):
 
 # ---------------------------------------------------------------------------------- a5 pnp
 def pnp(h3d, h2d, cam, itr=100, reperr=2, flag=SOLVEPNP_P3P, gtR=None, gtT=None, spts=None, ret=None,
-        *, seed=0, refine_iters=10):
+        *, seed=0, refine_iters=10, confidence=0.99):
     """inference.py:123-134 (= finalposes.py:20-30 = choosePose.py:23-33).
 
     cv2.solvePnPRansac(h3d, h2d, cam, None, iterationsCount=itr, reprojectionError=reperr,
     flags=P3P) -> (Rodrigues(rvec) (3,3) f64, tvec (3,) f64, inlier indices (k,) int32), or the
     reference's int sentinel (1, 1, 1) after printing its message.  gtR/gtT/spts/ret are accepted
-    and ignored, as in the reference.  `itr` hypotheses are all scored (no early exit); `seed`
-    keys the Philox sampler (OpenCV's RNG is internal and fixed; ours is explicit)."""
+    and ignored, as in the reference.  `itr` is the maximum number of hypotheses; as with cv2's default
+    confidence=0.99 (the reference passes none) scoring stops once the best inlier count gives that
+    confidence (confidence=1 scores all).  `seed` keys the Philox sampler (OpenCV's RNG is internal)."""
     del flag, gtR, gtT, spts, ret
     p3d, p2d = _dev(h3d, torch.float32), _dev(h2d, torch.float32)
     if p3d.ndim != 2 or p3d.shape[1] != 3 or p2d.shape != (p3d.shape[0], 2):
@@ -106,7 +107,7 @@ def pnp(h3d, h2d, cam, itr=100, reperr=2, flag=SOLVEPNP_P3P, gtR=None, gtT=None,
         print("pose could not be estimated with these correspondences")
         return 1, 1, 1
     r = ops.pnp_ransac(p3d, p2d, np.asarray(cam, np.float64), H=int(itr), reperr=float(reperr),
-                       seed=int(seed), refine_iters=int(refine_iters))
+                       seed=int(seed), refine_iters=int(refine_iters), confidence=float(confidence))
     if int(r.status.item()) != 1:
         print("pose could not be estimated with these correspondences")
         return 1, 1, 1

@@ -37,7 +37,7 @@ class ImageResult:
 
 def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Tensor, cam,
                    itr: int = 500, reperr: float = 2.0, seed: int = 0, refine_iters: int = 10,
-                   timing: list | None = None) -> ImageResult:
+                   timing: list | None = None, confidence: float = 0.99) -> ImageResult:
     """inference.py:273-293 for one image, fully enqueued (no host synchronisation):
     getCors -> top-80 % filter -> correspondence assembly -> pnp(itr, reperr, P3P)."""
     if timing is not None:
@@ -49,13 +49,14 @@ def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
         timing.append((e0, e1))
     keep, M, _ = ops.select_top(logp)
     p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix_xy)
-    r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M)
+    r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M,
+                       confidence=confidence)
     return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp)
 
 
 def register_crop(model: SequenceModel, feat: torch.Tensor, mask: torch.Tensor, cam, c0: int = 0,
                   n_feat: int | None = None, down_sample: int = 3, itr: int = 500, reperr: float = 2.0,
-                  seed: int = 0, refine_iters: int = 10) -> tuple[ImageResult, torch.Tensor]:
+                  seed: int = 0, refine_iters: int = 10, confidence: float = 0.99) -> tuple[ImageResult, torch.Tensor]:
     """inference.py:248-293 from the network output on: `feat` = imfeatsfull (1, H, W, C) or (H, W, C)
     channels-last on the device, `mask` = cropMask (H, W[, 3]) uint8 on the device, `cam` the cropped
     and down-sampled camera matrix (formats.crop_camera).  Sub-sampling, masking, the compaction of the
@@ -73,7 +74,8 @@ def register_crop(model: SequenceModel, feat: torch.Tensor, mask: torch.Tensor, 
     idx, logp = ops.corr_argmax(Q, keys, log2_prescaled=model.log2_queries)
     keep, M, _ = ops.select_top(logp, n_dev=n_dev)
     p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix)
-    r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M)
+    r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M,
+                       confidence=confidence)
     return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp), n_dev
 
 
@@ -101,7 +103,8 @@ def _stream_pool(dev: torch.device, n: int) -> list:
 
 
 def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: float = 2.0,
-                    seed0: int = 0, refine_iters: int = 10, n_streams: int = 3) -> list[ImageResult]:
+                    seed0: int = 0, refine_iters: int = 10, n_streams: int = 3,
+                    confidence: float = 0.99) -> list[ImageResult]:
     """Register a block of images with the stages pipelined over HIP streams.
 
     Stream 0 runs nothing but K1 (getCors) back to back — the only kernel that fills the chip;
@@ -115,7 +118,7 @@ def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: f
     cur = torch.cuda.current_stream(dev)
     cam_of = (lambda j: cam) if np.ndim(cam) == 2 else (lambda j: cam[j])
     if n_streams <= 1:
-        return [register_image(model, q, pix, cam_of(j), itr, reperr, seed0 + j, refine_iters)
+        return [register_image(model, q, pix, cam_of(j), itr, reperr, seed0 + j, refine_iters, confidence=confidence)
                 for j, (q, pix) in enumerate(images)]
     pool = _stream_pool(dev, n_streams)
     for s in pool:
@@ -135,7 +138,7 @@ def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: f
             keep, M, _ = ops.select_top(logp)
             p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix)
             r = ops.pnp_ransac(p3d, p2d, cam_of(j), H=itr, reperr=reperr, seed=seed0 + j,
-                               refine_iters=refine_iters, M_dev=M)
+                               refine_iters=refine_iters, M_dev=M, confidence=confidence)
         out.append(ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp))
     for s in pool:
         cur.wait_stream(s)
@@ -144,7 +147,7 @@ def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: f
 
 
 def register_group(model: SequenceModel, idx_g: torch.Tensor, logp_g: torch.Tensor, pix_xy: torch.Tensor, cams,
-                   itr: int, reperr: float, seeds, refine_iters: int) -> list[ImageResult]:
+                   itr: int, reperr: float, seeds, refine_iters: int, confidence: float = 0.99) -> list[ImageResult]:
     """inference.py:282-293 for a GROUP of images whose K1 results are idx_g / logp_g (B, P): the
     top-80 % filter, the correspondence assembly and pnp() run as ONE chain of launches with the
     image on blockIdx.z (isr_select_top_batch, isr_gather_corr_batch, isr_pnp_ransac_batch) — the
@@ -153,14 +156,15 @@ def register_group(model: SequenceModel, idx_g: torch.Tensor, logp_g: torch.Tens
     B = idx_g.shape[0]
     keep, M, _ = ops.select_top_batch(logp_g)
     p3d, p2d = ops.gather_corr_batch(idx_g, keep, M, model.pts, pix_xy)
-    r = ops.pnp_ransac_batch(p3d, p2d, cams, M, H=itr, reperr=reperr, seeds=seeds, refine_iters=refine_iters)
+    r = ops.pnp_ransac_batch(p3d, p2d, cams, M, H=itr, reperr=reperr, seeds=seeds, refine_iters=refine_iters,
+                             confidence=confidence)
     return [ImageResult(r.pose[b], r.status[b:b + 1], r.n_inl[b:b + 1], r.inl_idx[b], keep[b], M[b:b + 1], idx_g[b], logp_g[b])
             for b in range(B)]
 
 
 def register_block(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Tensor, cam, itr: int = 500,
                    reperr: float = 2.0, seed0: int = 0, refine_iters: int = 10, n_streams: int = 3,
-                   group: int = 8) -> list[ImageResult]:
+                   group: int = 8, confidence: float = 0.99) -> list[ImageResult]:
     """register_images for a block held as ONE tensor: queries (n, P, D), pix_xy (n, P, 2) or (P, 2).
     K1 runs once per `group` images on (group * P) query rows — K1's result for a query does not
     depend on the launch it rides in, so this only changes the launch shape: a 640x480 image alone is
@@ -192,7 +196,7 @@ def register_block(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
         with torch.cuda.stream(s):
             out += register_group(model, idx_g.view(g1 - g0, P), logp_g.view(g1 - g0, P),
                                   pix_xy if pix_xy.ndim == 2 else pix_xy[g0:g1], cams[g0:g1], itr, reperr,
-                                  [seed0 + j for j in range(g0, g1)], refine_iters)
+                                  [seed0 + j for j in range(g0, g1)], refine_iters, confidence)
     for s in pool:
         cur.wait_stream(s)
     _publish(out, cur)

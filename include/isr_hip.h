@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ISR_ABI_VERSION 1
+#define ISR_ABI_VERSION 2
 
 #define ISR_OK 0
 #define ISR_ERR_ARG (-1)         /* bad shape / null pointer / unsupported value */
@@ -150,7 +150,11 @@ int isr_gather_corr_batch(const int32_t* idx, const int32_t* keep, const int32_t
  *   ws as for isr_pnp_ransac.
  * isr_pnp_refine: `iters` Gauss-Newton steps (f64) on the reprojection error over the masked
  *   correspondences, starting from Rt_io (12 f64), result written back.
- * isr_pnp_ransac: the three above + inlier index compaction, one enqueue.
+ * isr_pnp_ransac: the three above + inlier index compaction, one enqueue.  `confidence` is
+ *   cv2.solvePnPRansac's parameter of that name (its default, which the reference uses, is 0.99):
+ *   hypotheses are scored in stages [0,32), [32,96), [96,224), ... and a stage runs only while
+ *   (1 - (c/M)^4)^b > 1 - confidence for the best count c after the b hypotheses before it;
+ *   confidence >= 1 scores all H (isr_ransac_score always does).
  *   pose_dev: 12 f64 [R|t];  inl_idx: capacity M_cap;  n_inl_dev: i32;  status_dev: i32
  *   (1 = pose found, 0 = failed: the Python mirror then returns the reference's (1,1,1)).
  * Kcam: host pointer, 9 doubles row-major.
@@ -167,9 +171,9 @@ int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t* M_dev, int
                    const uint32_t* mask, const double* Kcam, int iters, double* Rt_io, void* ws,
                    size_t ws_bytes, isr_stream_t stream);
 int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
-                   const double* Kcam, int H, uint64_t seed, float reperr, int refine_iters,
-                   double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev, int32_t* status_dev,
-                   void* ws, size_t ws_bytes, isr_stream_t stream);
+                   const double* Kcam, int H, uint64_t seed, float reperr, double confidence,
+                   int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
+                   int32_t* status_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* isr_pnp_ransac for a GROUP of B images as one chain of launches (image = blockIdx.z of every kernel):
  * p3d (B, M_cap, 3), p2d (B, M_cap, 2), M_dev (B); Kcams HOST (B, 9) f64, seeds HOST (B) u64;
@@ -178,8 +182,9 @@ int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int
 size_t isr_pnp_ransac_batch_workspace_bytes(int M_cap, int H, int B);
 int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B,
                          const double* Kcams, int H, const uint64_t* seeds, float reperr,
-                         int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
-                         int32_t* status_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
+                         double confidence, int refine_iters, double* pose_dev, int32_t* inl_idx,
+                         int32_t* n_inl_dev, int32_t* status_dev, void* ws, size_t ws_bytes,
+                         isr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3 / K4  batched brute-force nearest neighbour with fused reductions

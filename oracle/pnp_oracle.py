@@ -17,6 +17,10 @@ its refit can be observed.  This module states the algorithm the build owns (DES
   * the root with the smallest reprojection error on the 4th point wins (z > 0 required);
   * inliers: z > 0 and |proj - obs|^2 <= reperr^2, evaluated division-free in f32
     (oracle/isr_oracle.c:orc_ransac_score); best = most inliers, lowest h on ties;
+  * adaptive termination = cv2.solvePnPRansac's `confidence` (default 0.99, which the reference's
+    call leaves in force) [rule from the RANSAC literature / OpenCV docs, from memory]: hypotheses are
+    scored in stages [0,32), [32,96), [96,224), ...; after b hypotheses with best count c of M the
+    loop stops when (1 - (c/M)^4)^b <= 1 - confidence (stop_rule below: multiplications only);
   * refit: Gauss-Newton on the reprojection error over the best hypothesis' inliers (f64).
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
@@ -197,18 +201,54 @@ def refine(p3d, p2d, K, Rt, sel, iters=10):
     return np.concatenate([R, t[:, None]], axis=1)
 
 
+def stop_rule(c: int, M: int, b: int, one_minus_conf: float) -> bool:
+    """csrc/ransac.hip:ransac_stop, operation for operation (IEEE doubles, binary powering)."""
+    if c < 4 or M <= 0 or not (one_minus_conf > 0.0):
+        return False
+    w = np.float64(c) / np.float64(M)
+    w2 = w * w
+    base, q, e = np.float64(1.0) - w2 * w2, np.float64(1.0), int(b)
+    while e > 0:
+        if e & 1:
+            q = q * base
+        base = base * base
+        e >>= 1
+    return bool(q <= one_minus_conf)
+
+
+def evaluated_hypotheses(n_inl, ok, M: int, confidence: float) -> int:
+    """How many hypotheses the staged loop scores: the first stage boundary 32 (2^k - 1) at which
+    stop_rule holds for the best count so far, else all."""
+    H = len(n_inl)
+    if confidence >= 1.0:
+        return H
+    lo, ln = 0, 32
+    while lo + ln < H:
+        b = lo + ln
+        c = int(np.max(np.where(ok[:b].astype(bool), n_inl[:b], 0))) if b else 0
+        if stop_rule(c, M, b, 1.0 - confidence):
+            return b
+        lo, ln = b, ln * 2
+    return H
+
+
 def unpack_mask(mask, M):
     bits = np.unpackbits(mask.view(np.uint8), bitorder="little")[:M]
     return bits.astype(bool)
 
 
-def pnp_ransac(p3d, p2d, K, H=500, reperr=2.0, seed=0, refine_iters=10):
-    """-> dict(status, Rt (3,4), inliers (k,) i32, n_inl (H,), best, Rt_all, ok)."""
+def pnp_ransac(p3d, p2d, K, H=500, reperr=2.0, seed=0, refine_iters=10, confidence=0.99):
+    """-> dict(status, Rt (3,4), inliers (k,) i32, n_inl (H,) [0 past n_eval], best, n_eval, Rt_all, ok)."""
     p3d = np.ascontiguousarray(p3d, np.float32)
     p2d = np.ascontiguousarray(p2d, np.float32)
     K = np.asarray(K, np.float64)
     Rt, ok, S = hypotheses(p3d, p2d, K, H, seed)
     sc = cbind.ransac_score(p3d, p2d, K, Rt, ok, reperr)
+    n_eval = evaluated_hypotheses(sc["n_inl"], ok, len(p3d), confidence)
+    if n_eval < H:                        # the staged loop never scored the rest
+        ok_e = ok.copy()
+        ok_e[n_eval:] = 0
+        sc = cbind.ransac_score(p3d, p2d, K, Rt, ok_e, reperr)
     best = sc["best"]
     inl = unpack_mask(sc["best_mask"], len(p3d))
     status = int(best >= 0 and sc["n_inl"][best] >= 4)
@@ -216,4 +256,4 @@ def pnp_ransac(p3d, p2d, K, H=500, reperr=2.0, seed=0, refine_iters=10):
     if status:
         pose = refine(p3d, p2d, K, pose, inl, refine_iters)
     return dict(status=status, Rt=pose, inliers=np.nonzero(inl)[0].astype(np.int32) if status else
-                np.zeros(0, np.int32), n_inl=sc["n_inl"], best=best, Rt_all=Rt, ok=ok, samples=S)
+                np.zeros(0, np.int32), n_inl=sc["n_inl"], best=best, n_eval=n_eval, Rt_all=Rt, ok=ok, samples=S)

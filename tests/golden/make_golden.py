@@ -73,7 +73,7 @@ def main():
     K = synth.camera()
     R, t = synth.random_poses(rng, 1)
     p3d, p2d, inl = synth.pnp_case(rng, pts, K, R[0], t[0], 1200)
-    o = pnp_oracle.pnp_ransac(p3d, p2d, K, H=100, reperr=2.0, seed=42)
+    o = pnp_oracle.pnp_ransac(p3d, p2d, K, H=100, reperr=2.0, seed=42, confidence=1.0)   # every hypothesis scored
     np.savez_compressed(OUT / "pnp_ransac.npz", p3d=p3d, p2d=p2d, K=K, R=R[0], t=t[0], seed=42, H=100,
                         samples=o["samples"], n_inl=o["n_inl"], best=o["best"], inliers=o["inliers"],
                         pose=o["Rt"], ok=o["ok"])
@@ -93,5 +93,27 @@ def main():
     print("golden vectors written to", OUT)
 
 
+def pnp_adaptive():
+    """PnP + RANSAC with the adaptive termination in force (confidence 0.99, cv2's default): 50 % wrong
+    matches make the staged loop stop at 96 of 500 hypotheses, and the best of those is not the best of
+    all 500 — the vector pins WHERE the loop stops.  Own RNG stream: does not disturb the files above."""
+    rng = np.random.default_rng(22)
+    pts = synth.tless_like(rng, 4000)
+    K = synth.camera()
+    R, t = synth.random_poses(rng, 1)
+    p3d, p2d, inl = synth.pnp_case(rng, pts, K, R[0], t[0], 4000, 0.5, 0.5)
+    o = pnp_oracle.pnp_ransac(p3d, p2d, K, H=500, reperr=2.0, seed=22, confidence=0.99)
+    full = pnp_oracle.pnp_ransac(p3d, p2d, K, H=500, reperr=2.0, seed=22, confidence=1.0)
+    assert o["n_eval"] == 96 and o["best"] != full["best"]
+    np.savez_compressed(OUT / "pnp_ransac_conf99.npz", p3d=p3d, p2d=p2d, K=K, R=R[0], t=t[0], seed=22, H=500,
+                        confidence=0.99, n_eval=o["n_eval"], n_inl=o["n_inl"], best=o["best"], inliers=o["inliers"],
+                        pose=o["Rt"], best_of_all=full["best"])
+    print("pnp_ransac_conf99.npz written")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pnp_adaptive":
+        pnp_adaptive()
+    else:
+        main()
+        pnp_adaptive()

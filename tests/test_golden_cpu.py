@@ -62,9 +62,15 @@ def test_vote_golden(oracle_lib):
 def test_pnp_golden():
     from oracle import pnp_oracle as po
     g = np.load(G / "pnp_ransac.npz")
-    o = po.pnp_ransac(g["p3d"], g["p2d"], g["K"], H=int(g["H"]), reperr=2.0, seed=int(g["seed"]))
+    o = po.pnp_ransac(g["p3d"], g["p2d"], g["K"], H=int(g["H"]), reperr=2.0, seed=int(g["seed"]), confidence=1.0)
     assert np.array_equal(o["samples"], g["samples"]) and np.array_equal(o["n_inl"], g["n_inl"])
     assert o["best"] == int(g["best"]) and np.array_equal(o["inliers"], g["inliers"])
+    np.testing.assert_allclose(o["Rt"], g["pose"], atol=1e-9)
+    # adaptive termination (confidence 0.99): the loop stops at 96 of 500 hypotheses
+    g = np.load(G / "pnp_ransac_conf99.npz")
+    o = po.pnp_ransac(g["p3d"], g["p2d"], g["K"], H=int(g["H"]), reperr=2.0, seed=int(g["seed"]), confidence=float(g["confidence"]))
+    assert o["n_eval"] == int(g["n_eval"]) == 96 and np.array_equal(o["n_inl"], g["n_inl"])
+    assert o["best"] == int(g["best"]) != int(g["best_of_all"]) and np.array_equal(o["inliers"], g["inliers"])
     np.testing.assert_allclose(o["Rt"], g["pose"], atol=1e-9)
 
 

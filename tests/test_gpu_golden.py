@@ -51,8 +51,13 @@ def test_vote(reg):
 
 def test_pnp(reg):
     g = np.load(G / "pnp_ransac.npz")
-    R, t, inl = reg.pnp(g["p3d"], g["p2d"], g["K"], itr=int(g["H"]), reperr=2, seed=int(g["seed"]))
+    R, t, inl = reg.pnp(g["p3d"], g["p2d"], g["K"], itr=int(g["H"]), reperr=2, seed=int(g["seed"]), confidence=1.0)
     assert np.array_equal(inl, g["inliers"])              # bit-exact inlier set for the fixed seed
+    assert synth.rot_angle(R, g["pose"][:, :3]) < 1e-4 and np.linalg.norm(t - g["pose"][:, 3]) < 1e-3
+    # default confidence (0.99, as cv2's): the staged loop stops at 96 of 500 hypotheses
+    g = np.load(G / "pnp_ransac_conf99.npz")
+    R, t, inl = reg.pnp(g["p3d"], g["p2d"], g["K"], itr=int(g["H"]), reperr=2, seed=int(g["seed"]))
+    assert np.array_equal(inl, g["inliers"])
     assert synth.rot_angle(R, g["pose"][:, :3]) < 1e-4 and np.linalg.norm(t - g["pose"][:, 3]) < 1e-3
 
 

@@ -75,21 +75,25 @@ def test_refine_matches_oracle(cuda0):
     assert abs(np.linalg.det(got[:, :3]) - 1) < 1e-9
 
 
+@pytest.mark.parametrize("confidence", [1.0, 0.99])
 @pytest.mark.parametrize("M,H,kind,seed", [(5000, 500, "tless", 11), (245760, 500, "tless", 12),
                                            (20000, 4096, "rev", 13), (300, 100, "ell", 14)])
-def test_pnp_ransac_pipeline(cuda0, M, H, kind, seed):
+def test_pnp_ransac_pipeline(cuda0, M, H, kind, seed, confidence):
+    """confidence = 1: every hypothesis is scored; 0.99 (cv2's default, what the reference's call uses):
+    the staged loop with RANSAC's stopping rule — the oracle applies the same rule."""
     from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
     from oracle import pnp_oracle as po
     pts, K, R, t, p3d, p2d, inl = _scene(seed, M, kind)
     r = ops.pnp_ransac(torch.from_numpy(p3d).to(cuda0), torch.from_numpy(p2d).to(cuda0), K, H=H,
-                       reperr=2.0, seed=seed, refine_iters=10)
+                       reperr=2.0, seed=seed, refine_iters=10, confidence=confidence)
     torch.cuda.synchronize()
     assert int(r.status.item()) == 1
     pose = r.pose.cpu().numpy()
     n = int(r.n_inl.item())
     idx = r.inl_idx[:n].cpu().numpy()
-    o = po.pnp_ransac(p3d, p2d, K, H=H, reperr=2.0, seed=seed, refine_iters=10) if M <= 20000 else None
+    o = po.pnp_ransac(p3d, p2d, K, H=H, reperr=2.0, seed=seed, refine_iters=10, confidence=confidence) if M <= 20000 else None
     if o is not None:
+        assert o["n_eval"] == H or confidence < 1.0
         if o["best"] == int(np.argmax(o["n_inl"])):
             # same winning hypothesis -> same inlier set (bit-exact scoring) -> same refit optimum
             assert np.array_equal(idx, o["inliers"])
@@ -103,6 +107,28 @@ def test_pnp_ransac_pipeline(cuda0, M, H, kind, seed):
     got[idx] = True
     if kind != "rev":
         assert (got & inl).sum() > 0.95 * inl.sum()
+
+
+def test_adaptive_termination_follows_the_stopping_rule(cuda0):
+    """The staged scoring loop stops exactly where oracle/pnp_oracle.py:evaluated_hypotheses says — the
+    inlier set must be the one of the best hypothesis among the EVALUATED ones, not of the best of all H.
+    Outlier fractions from 20 % to 85 % put the stop at different stage boundaries (32, 96, 224, none)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    from oracle import pnp_oracle as po
+    stops, differs = set(), 0
+    for seed, frac in [(21, 0.2), (22, 0.5), (23, 0.62), (24, 0.7), (25, 0.78), (26, 0.85), (27, 0.66), (28, 0.74)]:
+        pts, K, R, t, p3d, p2d, inl = _scene(seed, 4000, "tless", outlier_frac=frac)
+        H = 500
+        r = ops.pnp_ransac(torch.from_numpy(p3d).to(cuda0), torch.from_numpy(p2d).to(cuda0), K, H=H, reperr=2.0,
+                           seed=seed, refine_iters=10, confidence=0.99)
+        o = po.pnp_ransac(p3d, p2d, K, H=H, reperr=2.0, seed=seed, refine_iters=10, confidence=0.99)
+        full = po.pnp_ransac(p3d, p2d, K, H=H, reperr=2.0, seed=seed, refine_iters=10, confidence=1.0)
+        n = int(r.n_inl.item())
+        assert int(r.status.item()) == o["status"] == 1
+        assert np.array_equal(r.inl_idx[:n].cpu().numpy(), o["inliers"]), (seed, frac, o["n_eval"])
+        stops.add(o["n_eval"])
+        differs += int(o["best"] != full["best"])
+    assert len(stops) >= 3 and differs >= 1, (stops, differs)      # the cases do discriminate
 
 
 def test_pnp_ransac_failure_status(cuda0):
