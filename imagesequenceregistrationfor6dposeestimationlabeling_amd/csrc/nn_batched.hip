@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     const float* __restrict__ qry, int Nq, const float* __restrict__ tgt, int Nt,
     const double* __restrict__ Tq, const double* __restrict__ Tt, int split_len, int nsplit,
     float* __restrict__ part_d2, int32_t* __restrict__ part_idx, const int32_t* __restrict__ skip,
-    const int32_t* __restrict__ unresolved) {
+    const int32_t* __restrict__ unresolved, unsigned long long* __restrict__ packed = nullptr) {
   __shared__ __attribute__((aligned(16))) float lds[2][3][kTile];
   if (skip && *skip) return;  // device-side ICP loop: converged, later iterations are no-ops
   if (unresolved && *unresolved == 0) return;
@@ -149,6 +149,15 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
   for (int r = 0; r < RQ; ++r) {
     const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
     if (qi < Nq) {
+      if (packed) {
+        // one 64-bit atomic min per (query, target split) instead of per-split partial arrays: d2 >= 0, so
+        // its bit pattern orders like the value, and equal distances keep the lower index — the very
+        // winner the ascending merge of the partials picks, whatever order the atomics land in
+        if (bidx[r] >= 0)
+          atomicMin(&packed[(size_t)b * Nq + qi],
+                    ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned int)bidx[r]);
+        continue;
+      }
       const size_t o = ((size_t)b * nsplit + split) * Nq + qi;
       if (unresolved && part_idx[o] != kUnresolved) continue;
       part_d2[o] = best[r];
@@ -290,6 +299,7 @@ __global__ __launch_bounds__(kThreads) void add_metric_kernel(const float* __res
 struct IcpState {
   double prev_fit, prev_rmse;
   int32_t iter, done;
+  int32_t ticket, pad;   // workgroups that have delivered their sums in the current pass
 };
 
 // Cyclic Jacobi on a symmetric 4x4; every loop has constant bounds and is unrolled so A and V
@@ -297,12 +307,17 @@ struct IcpState {
 __device__ void jacobi4_largest(double A[4][4], double q[4]) {
   double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
   for (int sweep = 0; sweep < 16; ++sweep) {
-    double off = 0.0;
+    double off = 0.0, dia = 0.0;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+    for (int p = 0; p < 4; ++p) {
+      dia += A[p][p] * A[p][p];
 #pragma unroll
       for (int r = p + 1; r < 4; ++r) off += A[p][r] * A[p][r];
-    if (off < 1e-300) break;
+    }
+    // off-diagonal mass below 1e-34 of the diagonal's: the eigenvector is converged to ~1e-17 — Jacobi
+    // converges quadratically, so the sweeps this saves (it used to run until off underflowed) are pure
+    // serial latency in a one-thread tail
+    if (off <= 1e-34 * dia) break;
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -347,21 +362,19 @@ __device__ void jacobi4_largest(double A[4][4], double q[4]) {
 
 constexpr int kIcpLanes = 16;
 
-__global__ __launch_bounds__(kNV * kIcpLanes) void icp_update_kernel(const double* __restrict__ part_sums, int nblk, int Ns, int max_iter,
-                                  double rel_fitness, double rel_rmse, double* __restrict__ T,
-                                  IcpState* __restrict__ st, double* __restrict__ result) {
-  // launched with kIcpLanes lanes per sum: lane l of sum k adds blocks l, l + kIcpLanes, ... and the
-  // kIcpLanes partial sums are added in lane order (fixed shape: run-to-run reproducible)
+// The end of an ICP evaluation pass, by ONE workgroup of any size: reduce the block sums in a fixed
+// shape (lane l of sum k adds blocks l, l + kIcpLanes, ...; the kIcpLanes partials are added in lane
+// order: run-to-run reproducible and the same for every caller), apply the stopping rule, compose T.
+__device__ void icp_reduce_and_update(const double* __restrict__ part_sums, int nblk, int Ns, int max_iter,
+                                      double rel_fitness, double rel_rmse, double* __restrict__ T,
+                                      IcpState* __restrict__ st, double* __restrict__ result) {
   __shared__ double part[kNV][kIcpLanes];
   __shared__ double v[kNV];
-  if (st->done) return;
-  {
-    const int k = threadIdx.x / kIcpLanes, l = threadIdx.x % kIcpLanes;
-    if (k < kNV) {
-      double s = 0.0;
-      for (int i = l; i < nblk; i += kIcpLanes) s += part_sums[(size_t)i * kNV + k];
-      part[k][l] = s;
-    }
+  for (int idx = threadIdx.x; idx < kNV * kIcpLanes; idx += blockDim.x) {
+    const int k = idx / kIcpLanes, l = idx % kIcpLanes;
+    double s = 0.0;
+    for (int i = l; i < nblk; i += kIcpLanes) s += part_sums[(size_t)i * kNV + k];
+    part[k][l] = s;
   }
   __syncthreads();
   if (threadIdx.x < kNV) {
@@ -408,8 +421,78 @@ __global__ __launch_bounds__(kNV * kIcpLanes) void icp_update_kernel(const doubl
   for (int k = 0; k < 12; ++k) T[k] = Tn[k];
 }
 
-__global__ void icp_init_kernel(IcpState* st, double* T) {
-  st->prev_fit = 0; st->prev_rmse = 0; st->iter = 0; st->done = 0;
+// the update as a launch of its own (behind nn_finalize_kernel: the grid-search variants of the loop)
+__global__ __launch_bounds__(kThreads) void icp_update_kernel(const double* __restrict__ part_sums, int nblk, int Ns,
+                                                              int max_iter, double rel_fitness, double rel_rmse,
+                                                              double* __restrict__ T, IcpState* __restrict__ st,
+                                                              double* __restrict__ result) {
+  if (st->done) return;
+  icp_reduce_and_update(part_sums, nblk, Ns, max_iter, rel_fitness, rel_rmse, T, st, result);
+}
+
+// Brute-force loop: the search left one packed (f32 d2 bits, index) minimum per source point.  Every
+// workgroup finishes its 256 points exactly as nn_finalize_kernel<true> does (f64 distance of the
+// winner, radius test, the 18 sums by the same fixed tree), re-arms the packed slots, and takes a
+// ticket; the LAST workgroup to arrive (agent-scope fences order the block sums before the ticket)
+// runs the update.  Two launches per ICP iteration, no partial arrays.
+__global__ __launch_bounds__(kThreads) void icp_finalize_update_kernel(
+    const float* __restrict__ src, int Ns, const float* __restrict__ tgt, double radius,
+    unsigned long long* __restrict__ packed, double* __restrict__ part_sums, int max_iter, double rel_fitness,
+    double rel_rmse, double* __restrict__ T, IcpState* __restrict__ st, double* __restrict__ result) {
+  __shared__ double red[kThreads / 64][kNV];
+  __shared__ int last;
+  if (st->done) return;
+  const int tid = threadIdx.x;
+  const int qi = blockIdx.x * kThreads + tid;
+  double v[kNV];
+#pragma unroll
+  for (int k = 0; k < kNV; ++k) v[k] = 0.0;
+  if (qi < Ns) {
+    const unsigned long long pk = packed[qi];
+    packed[qi] = ~0ull;
+    if (pk != ~0ull) {
+      const int bi = (int)(unsigned int)pk;
+      double q0, q1, q2;
+      xform64(T, src[3 * (size_t)qi], src[3 * (size_t)qi + 1], src[3 * (size_t)qi + 2], q0, q1, q2);
+      const double t0 = tgt[3 * (size_t)bi], t1 = tgt[3 * (size_t)bi + 1], t2 = tgt[3 * (size_t)bi + 2];
+      const double ex = q0 - t0, ey = q1 - t1, ez = q2 - t2;
+      const double s2 = fma(ez, ez, fma(ey, ey, ex * ex));
+      if (s2 <= radius * radius) {
+        v[0] = sqrt(s2); v[1] = s2; v[2] = 1.0;
+        const double q[3] = {q0, q1, q2}, t[3] = {t0, t1, t2};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          v[3 + r] = q[r];
+          v[6 + r] = t[r];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[9 + 3 * r + c] = q[r] * t[c];
+        }
+      }
+    }
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int k = 0; k < kNV; ++k) {
+    const double s = wave_sum(v[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
+  if (tid < kNV) part_sums[(size_t)blockIdx.x * kNV + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+  __threadfence();                                  // the block's sums are visible device-wide ...
+  __syncthreads();
+  if (tid == 0) last = (atomicAdd(&st->ticket, 1) == (int)gridDim.x - 1);   // ... before its ticket is
+  __syncthreads();
+  if (!last) return;                                // block-uniform
+  __threadfence();
+  if (tid == 0) st->ticket = 0;
+  icp_reduce_and_update(part_sums, gridDim.x, Ns, max_iter, rel_fitness, rel_rmse, T, st, result);
+}
+
+__global__ void icp_init_kernel(IcpState* st, double* T, unsigned long long* packed, int Ns) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (packed && i < Ns) packed[i] = ~0ull;
+  if (i != 0) return;
+  st->prev_fit = 0; st->prev_rmse = 0; st->iter = 0; st->done = 0; st->ticket = 0;
   T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
 }
 
@@ -579,7 +662,8 @@ extern "C" int isr_add_metric(const float* verts, int V, const double* Ta, const
 
 extern "C" size_t isr_icp_workspace_bytes(int Ns, int Nt) {
   if (Ns <= 0 || Nt <= 0) return 0;
-  return isr_nn_batched_workspace_bytes(Ns, Nt, 1) + 1024;   // includes the grid when the plan uses one
+  // includes the grid when the plan uses one; + the packed minima of the brute-force loop
+  return isr_nn_batched_workspace_bytes(Ns, Nt, 1) + isr::align_up((size_t)Ns * 8, 256) + 1024;
 }
 
 extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt, int Nt, double threshold,
@@ -598,7 +682,9 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
   int32_t* part_idx = w.take<int32_t>((size_t)p.nsplit * Ns);
   double* part_sums = w.take<double>((size_t)p.fblocks * kNV);
   IcpState* st = w.take<IcpState>(1);
-  icp_init_kernel<<<1, 1, 0, stream>>>(st, T_io);
+  const bool brute = !p.grid && !p.tile;
+  unsigned long long* packed = brute ? w.take<unsigned long long>(Ns) : nullptr;
+  icp_init_kernel<<<brute ? (Ns + kThreads - 1) / kThreads : 1, kThreads, 0, stream>>>(st, T_io, packed, Ns);
   GridWs gw{};
   TileWs tw{};
   if (p.grid) {           // the target never moves: one grid serves every iteration
@@ -612,21 +698,37 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
   const float stop_radius = (float)(threshold * (1.0 + 1e-6));
   const dim3 grid(p.qblocks, p.nsplit, 1), fgrid(p.fblocks, 1);
   for (int it = 0; it <= max_iter; ++it) {
-    if (p.tile)
+    if (brute) {
+      // two launches per pass: search with one packed atomic min per (point, target split), then the
+      // finalize whose last workgroup runs the update
+      if (p.rq == 4)
+        nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
+                                                           nullptr, nullptr, &st->done, nullptr, packed);
+      else
+        nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
+                                                           nullptr, nullptr, &st->done, nullptr, packed);
+      icp_finalize_update_kernel<<<p.fblocks, kThreads, 0, stream>>>(src, Ns, tgt, threshold, packed, part_sums, max_iter,
+                                                                     rel_fitness, rel_rmse, T_io, st, result);
+      continue;
+    }
+    if (p.tile) {
       launch_tile_search(tw, Ns, Nt, T_io, nullptr, 1, stop_radius, part_d2, part_idx, &st->done, stream);
-    else if (p.grid)      // with a stop radius every query resolves: no brute-force pass
+    } else {
+      // per-lane grid: a point whose ring walk ends before the ring covers the radius is left to the
+      // brute-force pass (nsplit is 1 on this plan), as in isr_nn_batched
       nn_grid_search_kernel<<<dim3(p.fblocks, 1), kThreads, 0, stream>>>(src, Ns, gw.desc, gw.start, gw.sorted, T_io,
                                                                          nullptr, stop_radius, part_d2, part_idx,
                                                                          gw.unresolved, &st->done);
-    else if (p.rq == 4)
-      nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
-                                                         part_d2, part_idx, &st->done, nullptr);
-    else
-      nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
-                                                         part_d2, part_idx, &st->done, nullptr);
+      if (p.rq == 4)
+        nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
+                                                           part_d2, part_idx, &st->done, gw.unresolved);
+      else
+        nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
+                                                           part_d2, part_idx, &st->done, gw.unresolved);
+    }
     nn_finalize_kernel<true><<<fgrid, kThreads, 0, stream>>>(src, Ns, tgt, T_io, nullptr, p.nsplit, threshold, part_d2,
                                                              part_idx, 0, nullptr, nullptr, part_sums, &st->done);
-    icp_update_kernel<<<1, kNV * kIcpLanes, 0, stream>>>(part_sums, p.fblocks, Ns, max_iter, rel_fitness, rel_rmse, T_io, st, result);
+    icp_update_kernel<<<1, kThreads, 0, stream>>>(part_sums, p.fblocks, Ns, max_iter, rel_fitness, rel_rmse, T_io, st, result);
   }
   ISR_CHECK_LAUNCH("icp kernels");
   return ISR_OK;

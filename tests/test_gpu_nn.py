@@ -152,3 +152,29 @@ def test_nn_rejects_cpu_tensors(hip_lib):
     from imagesequenceregistrationfor6dposeestimationlabeling_amd._capi import IsrError
     with pytest.raises(IsrError):
         ops.nn_batched(torch.zeros(4, 3), torch.zeros(4, 3))
+
+
+def test_icp_loop_is_identical_on_every_nn_path(cuda0, monkeypatch):
+    """isr_icp_point_to_point on partially overlapping halves (many source points have no target within
+    a few grid cells, only within the 20 mm radius): brute force (packed atomic minima + fused
+    finalize/update), the per-lane grid (unresolved points get their brute-force pass) and the
+    block-cooperative grid give bit-identical T, fitness and rmse."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration, synth
+    rng = np.random.default_rng(31)
+    cloud = synth.tless_like(rng, 24000)
+    upper, lower = synth.split_halves(rng, cloud, 6000)
+    R, t = synth.random_poses(rng, 1)
+    Rp, tp = synth.perturb_pose(rng, R[0], t[0], 2.0, 2.0)
+    src = (upper.astype(np.float64) @ R[0].T + t[0]).astype(np.float32)
+    init = np.linalg.inv(np.vstack([np.hstack([Rp, tp[:, None]]), [0, 0, 0, 1]]))
+    out = {}
+    for mode in ("0", "1", "2"):
+        monkeypatch.setenv("ISR_NN_GRID", mode)
+        out[mode] = registration.icp_point_to_point(src, lower, 20, init)
+    monkeypatch.delenv("ISR_NN_GRID")
+    T0, f0, r0 = out["0"]
+    assert 0.5 < f0 <= 1.0 and r0 > 1.0          # far from a trivial all-matched case
+    for mode in ("1", "2"):
+        T, f, r = out[mode]
+        assert np.array_equal(T, T0) and f == f0 and r == r0, mode
+    assert np.array_equal(registration.icp_point_to_point(src, lower, 20, init)[0], T0)     # default plan

@@ -1,0 +1,46 @@
+"""ICP + final Chamfer timing at the bench's shape (20 000-point halves, threshold 20, Open3D defaults), for the
+three exact NN searches: python tools/time_icp.py.  Also one ICP evaluation pass and one ADD-S."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration, synth
+rng = np.random.default_rng(20240)
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+cloud = synth.tless_like(rng, 4 * N)
+upper, lower = synth.split_halves(rng, cloud, N)
+cad = synth.tless_like(rng, 5000)
+R, t = synth.random_poses(rng, 1)
+Rp, tp = synth.perturb_pose(rng, R[0], t[0], 0.02, 0.1)
+src = (upper.astype(np.float64) @ R[0].T + t[0]).astype(np.float32)
+init = np.linalg.inv(np.vstack([np.hstack([Rp, tp[:, None]]), [0, 0, 0, 1]]))
+dev = torch.device("cuda:0")
+s, l, c = (torch.from_numpy(x).to(dev) for x in (src, lower, cad))
+ref = None
+for mode in ("0", "1", "2", ""):
+    if mode:
+        os.environ["ISR_NN_GRID"] = mode
+    else:
+        os.environ.pop("ISR_NN_GRID", None)
+    T, fit, rmse = registration.icp_point_to_point(s, l, 20, init)
+    ch = registration.final_chamfer(s, l, T, c)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        T, fit, rmse = registration.icp_point_to_point(s, l, 20, init)
+    torch.cuda.synchronize()
+    t_icp = (time.perf_counter() - t0) / 5 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(5):
+        ch = registration.final_chamfer(s, l, T, c)
+    torch.cuda.synchronize()
+    t_ch = (time.perf_counter() - t0) / 5 * 1e3
+    t0 = time.perf_counter()
+    for _ in range(20):
+        registration.evaluate_registration(s, l, 20, T)
+    torch.cuda.synchronize()
+    t_ev = (time.perf_counter() - t0) / 20 * 1e3
+    if ref is None:
+        ref = (T, fit, rmse, ch)
+    same = np.array_equal(T, ref[0]) and fit == ref[1] and rmse == ref[2] and ch == ref[3]
+    print(f"ISR_NN_GRID={mode or 'default':7s} N={N}: ICP {t_icp:7.3f} ms  final Chamfer {t_ch:6.3f} ms  one evaluation pass {t_ev:6.3f} ms"
+          f"  fitness {fit:.4f} rmse {rmse:.4f} chamfer {ch:.4f}  bit-identical to brute force: {same}")
