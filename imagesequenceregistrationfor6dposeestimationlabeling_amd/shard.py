@@ -58,11 +58,18 @@ def allreduce_min_pair(val: float | None, idx: int, device=None) -> tuple[float,
     """Global (min value, its index) over ranks; val None = this rank owns nothing."""
     packed = EMPTY if val is None else pack_min(val, idx)
     rank, size = world()
-    if size == 1:
+    if size == 1 and not _forced():
         return unpack_min(packed)
     t = torch.tensor([packed], dtype=torch.int64, device=device or _coll_device())
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return unpack_min(int(t.item()))
+
+
+def _forced() -> bool:
+    """ISR_FORCE_DIST=1 with an initialised group: run the collectives even at world size 1 — a one-GPU
+    box can then exercise the RCCL calls themselves (init with device_id, all_gather_into_tensor,
+    all_reduce(MIN) on int64, issued from the bench's worker thread on its side stream)."""
+    return os.environ.get("ISR_FORCE_DIST") == "1" and dist.is_available() and dist.is_initialized()
 
 
 def _coll_device():
@@ -72,7 +79,7 @@ def _coll_device():
 def allgather_rows(local: torch.Tensor, n_total: int) -> torch.Tensor:
     """Concatenate the ranks' (n_local, k) blocks (block_range layout) into (n_total, k)."""
     rank, size = world()
-    if size == 1:
+    if size == 1 and not _forced():
         return local
     k = local.shape[1]
     nmax = -(-n_total // size)
@@ -98,7 +105,7 @@ def init_from_env(backend: str | None = None) -> tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
     dev_index = local % ndev if ndev else 0
-    if size > 1 and not dist.is_initialized():
+    if (size > 1 or os.environ.get("ISR_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = backend or os.environ.get("ISR_DIST_BACKEND") or ("nccl" if ndev else "gloo")
