@@ -26,7 +26,11 @@
 //                   oracle and device decide identically).  confidence >= 1: every hypothesis.
 //   3. best         arg-max count, lowest h on ties; its inlier bitmask.
 //   4. refit        Gauss-Newton on the reprojection error over the inliers, f64, fixed-shape
-//                   tree reduction of J^T J / J^T r, 6x6 Cholesky on the device.
+//                   tree reduction of J^T J / J^T r, 6x6 Cholesky on the device.  Then ONE round of
+//                   local optimisation: the inlier mask is recomputed under the refitted pose (same
+//                   f32 test) and the refit repeated on it — a hypothesis from 4 noisy points captures
+//                   only part of the consensus set, and with the adaptive termination the loop may
+//                   stop after 32 of them; the reported inliers are those of the refitted pose.
 //   5. compaction   inlier mask -> ascending int32 indices.
 // Every step reads M and the status from device memory: the whole chain is enqueued without a
 // host round trip.
@@ -280,6 +284,20 @@ __global__ void best_kernel(const int32_t* __restrict__ n_inl, const uint8_t* __
   }
 }
 
+// Local-optimisation round: the f32 projection matrix of each image's REFITTED pose (same f64 fma order
+// as proj_matrix_kernel) and a fresh Gauss-Newton convergence flag.
+__global__ void refined_proj_kernel(const double* __restrict__ pose, ImgBatch ib, float* __restrict__ Pm,
+                                    int32_t* __restrict__ gn_state) {
+  const int b = blockIdx.x, e = threadIdx.x;
+  const Cam& cam = ib.cam[b];
+  const double* T = pose + 12 * (size_t)b;
+  if (e < 12) {
+    const int r = e / 4, c = e % 4;
+    Pm[12 * (size_t)b + e] = (float)fma(cam.k[3 * r + 2], T[8 + c], fma(cam.k[3 * r + 1], T[4 + c], cam.k[3 * r] * T[c]));
+  }
+  if (e == 0) gn_state[4 * b] = 0;
+}
+
 __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
                                  const int32_t* __restrict__ M_dev, int M_cap, int H,
                                  const float* __restrict__ Pm, const int32_t* __restrict__ best_dev,
@@ -289,7 +307,7 @@ __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __r
   mask += (size_t)img * mask_words;
   const int m = blockIdx.x * blockDim.x + threadIdx.x;  // blockDim multiple of 64
   const int M = M_dev[img];
-  const int b = best_dev[img];
+  const int b = best_dev ? best_dev[img] : 0;             // no table of hypotheses: Pm holds one matrix per image
   bool in = false;
   if (m < M && b >= 0)
     in = inlier_f32(Pm + 12 * (size_t)b, p3d[3 * (size_t)m], p3d[3 * (size_t)m + 1], p3d[3 * (size_t)m + 2],
@@ -678,6 +696,13 @@ static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev
   if (rc != ISR_OK) return rc;
   rc = refine_impl(p3d, p2d, M_dev, M_cap, B, b.mask, ib, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
   if (rc != ISR_OK) return rc;
+  if (refine_iters > 0) {   // local optimisation: inliers of the refitted pose, refit on them (b.Pm's first B rows are free now)
+    refined_proj_kernel<<<B, 64, 0, stream>>>(pose_dev, ib, b.Pm, b.state);
+    best_mask_kernel<<<dim3((M_cap + 255) / 256, 1, B), 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, 1, b.Pm, nullptr, reperr,
+                                                                          b.mask, mask_words_of(M_cap));
+    rc = refine_impl(p3d, p2d, M_dev, M_cap, B, b.mask, ib, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
+    if (rc != ISR_OK) return rc;
+  }
   const int cb = comp_blocks_of(M_cap), mw = mask_words_of(M_cap);
   mask_count_kernel<<<dim3(cb, 1, B), kCompBlock, 0, stream>>>(b.mask, mw, M_dev, status_dev, b.cblocks);
   mask_scan_kernel<<<dim3(1, 1, B), 1024, 0, stream>>>(b.cblocks, cb, n_inl_dev);

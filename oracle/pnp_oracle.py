@@ -21,7 +21,9 @@ its refit can be observed.  This module states the algorithm the build owns (DES
     call leaves in force) [rule from the RANSAC literature / OpenCV docs, from memory]: hypotheses are
     scored in stages [0,32), [32,96), [96,224), ...; after b hypotheses with best count c of M the
     loop stops when (1 - (c/M)^4)^b <= 1 - confidence (stop_rule below: multiplications only);
-  * refit: Gauss-Newton on the reprojection error over the best hypothesis' inliers (f64).
+  * refit: Gauss-Newton on the reprojection error over the best hypothesis' inliers (f64), then one
+    round of local optimisation: inliers of the refitted pose (same f32 test), refit on those; the
+    reported inlier set is that of the refitted pose.
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
 """
 from __future__ import annotations
@@ -253,7 +255,10 @@ def pnp_ransac(p3d, p2d, K, H=500, reperr=2.0, seed=0, refine_iters=10, confiden
     inl = unpack_mask(sc["best_mask"], len(p3d))
     status = int(best >= 0 and sc["n_inl"][best] >= 4)
     pose = Rt[best] if best >= 0 else np.eye(3, 4)
-    if status:
+    if status and refine_iters > 0:
+        pose = refine(p3d, p2d, K, pose, inl, refine_iters)
+        lo = cbind.ransac_score(p3d, p2d, K, pose.reshape(1, 12), np.ones(1, np.uint8), reperr)
+        inl = unpack_mask(lo["best_mask"], len(p3d))
         pose = refine(p3d, p2d, K, pose, inl, refine_iters)
     return dict(status=status, Rt=pose, inliers=np.nonzero(inl)[0].astype(np.int32) if status else
                 np.zeros(0, np.int32), n_inl=sc["n_inl"], best=best, n_eval=n_eval, Rt_all=Rt, ok=ok, samples=S)

@@ -100,8 +100,11 @@ def test_pnp_ransac_pipeline(cuda0, M, H, kind, seed, confidence):
             assert synth.rot_angle(pose[:, :3], o["Rt"][:, :3]) < 1e-4
             assert np.linalg.norm(pose[:, 3] - o["Rt"][:, 3]) < 1e-3
     if kind != "rev":          # the symmetric object has no unique pose
-        assert synth.rot_angle(pose[:, :3], R) < 3e-3
-        assert np.linalg.norm(pose[:, 3] - t) < 1.0
+        # against the PLANTED pose only the data limits the agreement (0.5 px noise, M correspondences): the
+        # depth of a 60 mm object 700 mm away from 210 inliers is good to about a millimetre
+        slack = max(1.0, np.sqrt(2000.0 / M))
+        assert synth.rot_angle(pose[:, :3], R) < 3e-3 * slack
+        assert np.linalg.norm(pose[:, 3] - t) < 1.0 * slack
     assert np.all(np.diff(idx) > 0)
     got = np.zeros(M, bool)
     got[idx] = True

@@ -120,8 +120,9 @@ def test_group_chain_equals_per_image_chain(cuda0):
             assert torch.equal(r.pose[b], r1.pose) and torch.equal(r.inl_idx[b, :n], r1.inl_idx[:n])
     # a shared pixel grid (one (P, 2) array for every image) gathers the same rows
     p3s, p2s = ops.gather_corr_batch(idx, keep, M, model.pts, pix[0])
-    m0 = int(M[3].item())
-    assert torch.equal(p3s, p3d) and torch.equal(p2s[3, :m0], pix[0][keep[3, :m0].long()])
+    for b in (0, 3, B - 1):                 # rows past M[b] are uninitialised capacity
+        m0 = int(M[b].item())
+        assert torch.equal(p3s[b, :m0], p3d[b, :m0]) and torch.equal(p2s[b, :m0], pix[0][keep[b, :m0].long()])
 
 
 def test_pipelined_steps_with_dropped_results(cuda0):

@@ -51,7 +51,11 @@ def test_ransac_recovers_planted_pose_with_outliers():
     p3d, p2d, inl = synth.pnp_case(rng, pts, K, R[0], t[0], 2000, noise_px=0.5, outlier_frac=0.3)
     out = po.pnp_ransac(p3d, p2d, K, H=200, reperr=2.0, seed=7)
     assert out["status"] == 1
-    assert synth.rot_angle(out["Rt"][:, :3], R[0]) < 2e-3
+    # the maximum-likelihood refit on the PLANTED inliers, started from the true pose, is itself 2.0e-3 rad
+    # off on this scene (a 60 mm object 700 mm away, 0.5 px noise): the local-optimisation round reaches it
+    assert synth.rot_angle(out["Rt"][:, :3], R[0]) < 3e-3
+    ml = po.refine(p3d, p2d, K, np.concatenate([R[0], t[0][:, None]], 1), inl, 10)
+    assert synth.rot_angle(out["Rt"][:, :3], ml[:, :3]) < 2e-4
     assert np.linalg.norm(out["Rt"][:, 3] - t[0]) < 1.0
     # the inlier set is (almost) the planted one
     got = np.zeros(len(p3d), bool)
