@@ -196,7 +196,7 @@ def cpu_baseline(args, keys_bf16, pts, Q0, pix0, Kcam, upper, lower, cad, R_gt, 
     }
 
 
-def measure_nn(pts, dev, pairs=8):
+def measure_nn(pts, dev, pairs=32):
     """K3 brute force (nn_search_kernel, ISR_NN_GRID=0) on `pairs` Chamfer-pair items of N x N points with
     unrelated orientations, timed with HIP events on the launch stream.  Three figures:
     the VALU fraction under the 8-FLOP/pair convention, the algorithmic bytes against HBM, and — from

@@ -11,8 +11,11 @@ from pathlib import Path
 
 import torch  # noqa: F401  (must be loaded before libisr_hip.so: shared HIP runtime)
 
+import os
+
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libisr_hip.so"
+# ISR_HIP_LIB: tooling only (A/B timing of two builds of the library in one GPU session)
+LIB_PATH = Path(os.environ["ISR_HIP_LIB"]) if os.environ.get("ISR_HIP_LIB") else _PKG / "libisr_hip.so"
 
 ISR_OK = 0
 DTYPE_BF16 = 0

@@ -323,8 +323,6 @@ __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
   }
 }
 
-#include "corr_direct.hpp"   // corr_bf16_direct_kernel: the VALU-minimal bf16 loop (log2 and natural units)
-
 // ------------------------------------------------------------------------------------- f32
 // Exact path: v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fmaf chain.  Per canonical chunk the
 // lane state restarts; the range keeps the exact (maximum, lowest key).
@@ -475,7 +473,9 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
 
 // ------------------------------------------------------------------------------- finalize
 // Per query: the winner over the key ranges (ascending, strict >: ties keep the lower key), the
-// canonical f64 sum over the chunks
+// canonical f64 sum over the chunks (added in ascending order starting from the first chunk — exactly what
+// the direct kernel does in registers when ONE workgroup owns the whole key range, in which case it also
+// finishes the query itself and nothing is written for this kernel to read)
 //     L = sum_c l_c 2^(R_c - Rf),   Rf = max_c R_c
 // and   logp = -(ln L + Rf ln2 - m)   [natural logits; log2-domain logits: -(ln L + (Rf - m') ln2)],
 // formed without the m - lse cancellation.  MODE 0: f32 path (every chunk carries its maximum).
@@ -486,22 +486,60 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
 // gamma_n bound with u = 2^-23; Cauchy-Schwarz on sum |q_d k_d|), so a winner more than 2 eps above the
 // runner-up is the exact arg-max; everything else goes on the recheck list with the threshold below
 // which no key can be the exact winner.
+// The last step for one query, shared by corr_finalize_kernel and the direct kernel's own epilogue (same
+// code, same f64 operations: the two routes give bit-identical outputs): log-probability and lse from the
+// canonical sum, then the margin test.
+template <int MODE>
+__device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, bool anybad, double L, double Rf, int D,
+                                            float qn2, float kn2, const CorrWs& ws, int32_t* __restrict__ idx,
+                                            float* __restrict__ logp, float* __restrict__ lse) {
+  const double ln2 = 0.6931471805599453094;
+  // <= 0 like log_softmax (the sum contains the maximum's own term); rounding can leave it a few 1e-6 above
+  double lp, ls;
+  if (MODE == 1) {
+    lp = fmin(0.0, -(log(L) + (Rf - (double)G1) * ln2));
+    ls = (double)G1 * ln2 - lp;
+  } else {
+    lp = fmin(0.0, -(log(L) + (Rf * ln2 - (double)G1)));
+    ls = (double)G1 - lp;
+  }
+  idx[q] = bi;
+  if (logp) logp[q] = (float)lp;
+  if (lse) lse[q] = (float)ls;
+  if (MODE != 0) {
+    const double eps = (double)(D + 2) * 1.1920928955078125e-7 * sqrt((double)qn2 * (double)kn2) * 1.0001;
+    const double margin = (double)G1 - (double)G2;
+    if (anybad || !(margin > 2.0 * eps)) {
+      // exact winner x* >= exact(winner) >= G1 - eps, so its MFMA logit is >= G1 - 2 eps; bad ranges carry
+      // logits shifted by their reference (error up to ~3 eps) and the f32 rounding of M2 + mr
+      const double thr = anybad ? (double)G1 - 8.0 * eps - 1e-5 * fabs((double)G1) : (double)G1 - 2.0 * eps;
+      ws.qn2[q] = (float)(thr - 1e-6 * fabs(thr) - 1e-30);      // rounded down
+      ws.rlist[atomicAdd(ws.rcount, 1)] = q;
+    }
+  }
+}
+
+__device__ __forceinline__ float kn2_max(const CorrWs& ws) {      // every lane of the wave gets max_n |k_n|^2
+  float v = ws.kn2[threadIdx.x & 63];
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+#include "corr_direct.hpp"   // corr_bf16_direct_kernel: the VALU-minimal bf16 loop (log2 and natural units)
+
 template <int MODE>
 __global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, int nsplit, int range_chunks,
                                                             int nchunks, CorrWs ws, int32_t* __restrict__ idx,
                                                             float* __restrict__ logp, float* __restrict__ lse) {
-  __shared__ float s_kn2;
-  if (MODE != 0) {
-    if (threadIdx.x < 64) {
-      float v = ws.kn2[threadIdx.x];
-#pragma unroll
-      for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-      if (threadIdx.x == 0) s_kn2 = v;
-    }
-    __syncthreads();
-  }
+  // bf16, ONE key range: the direct kernel finished its good queries itself; only workgroups that hold a bad
+  // query (the same 256-query blocks there and here) have anything left to do
+  const bool finished_in_kernel = MODE != 0 && nsplit == 1;
+  if (finished_in_kernel && ws.flags[blockIdx.x] == 0) return;
+  const float kn2 = MODE != 0 ? kn2_max(ws) : 0.f;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= P) return;
+  if (finished_in_kernel && !ws.pbad[q]) return;
   float G1 = -__builtin_inff(), G2 = -__builtin_inff();
   int bi = 0;
   bool anybad = false;
@@ -528,30 +566,7 @@ __global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, int ns
     if ((double)R > Rf) { L = L * exp2(Rf - (double)R) + l; Rf = R; }
     else L += l * exp2((double)R - Rf);
   }
-  const double ln2 = 0.6931471805599453094;
-  // <= 0 like log_softmax (the sum contains the maximum's own term); rounding can leave it a few 1e-6 above
-  double lp, ls;
-  if (MODE == 1) {
-    lp = fmin(0.0, -(log(L) + (Rf - (double)G1) * ln2));
-    ls = (double)G1 * ln2 - lp;
-  } else {
-    lp = fmin(0.0, -(log(L) + (Rf * ln2 - (double)G1)));
-    ls = (double)G1 - lp;
-  }
-  idx[q] = bi;
-  if (logp) logp[q] = (float)lp;
-  if (lse) lse[q] = (float)ls;
-  if (MODE != 0) {
-    const double eps = (double)(D + 2) * 1.1920928955078125e-7 * sqrt((double)ws.qn2[q] * (double)s_kn2) * 1.0001;
-    const double margin = (double)G1 - (double)G2;
-    if (anybad || !(margin > 2.0 * eps)) {
-      // exact winner x* >= exact(winner) >= G1 - eps, so its MFMA logit is >= G1 - 2 eps; bad ranges carry
-      // logits shifted by their reference (error up to ~3 eps) and the f32 rounding of M2 + mr
-      const double thr = anybad ? (double)G1 - 8.0 * eps - 1e-5 * fabs((double)G1) : (double)G1 - 2.0 * eps;
-      ws.qn2[q] = (float)(thr - 1e-6 * fabs(thr) - 1e-30);      // rounded down
-      ws.rlist[atomicAdd(ws.rcount, 1)] = q;
-    }
-  }
+  corr_finish<MODE>(q, G1, G2, bi, anybad, L, Rf, D, MODE != 0 ? ws.qn2[q] : 0.f, kn2, ws, idx, logp, lse);
 }
 
 // ------------------------------------------------------------------------------ exact recheck
@@ -849,13 +864,13 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
   do {                                                                                                        \
     if (log2) {                                                                                               \
       corr_bf16_direct_kernel<DKv, kQB, false><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,          \
-                                                                              p.range_chunks, ws);           \
+                                                                              p.range_chunks, ws, idx, logp, lse); \
       corr_bf16_kernel<DKv, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws);  \
       corr_finalize_kernel<1><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
     } else {                                                                                                  \
       corr_bf16_direct_kernel<DKv, kQB, true><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,           \
-                                                                             p.range_chunks, ws);            \
+                                                                             p.range_chunks, ws, idx, logp, lse); \
       corr_bf16_kernel<DKv, false><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws); \
       corr_finalize_kernel<2><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \

@@ -34,6 +34,7 @@ struct DirectState {
   float m2;  // second largest tile maximum (with multiplicity)
   float l;   // sum 2^(s') over the current chunk
   int tb;    // first key of the first 32-key tile whose maximum reached m
+  double L;  // the canonical f64 sum of the chunk sums so far (what corr_finalize_kernel forms from memory)
 };
 
 // max of the 16 logits of a tile: seven v_max3_f32 + one v_max_f32
@@ -50,7 +51,8 @@ __device__ __forceinline__ float tile_max(const f32x16& acc) {
 template <int DK, int QB, bool NAT>
 __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
-    int range_chunks, CorrWs ws) {
+    int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
+    float* __restrict__ lse_out) {
   constexpr int NCH = 2 * DK;
   constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;
   constexpr int CHUNKS = kTK * NCH;
@@ -72,27 +74,31 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
 #pragma unroll
     for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
   }
-  // |q|^2 for the error bound of the margin test (f32, upper bound to rounding; finalize inflates it)
-  if (split == 0) {
+  // ONE key range (gridDim.y == 1: every launch whose query blocks alone fill the chip): this workgroup sees
+  // every chunk of its queries, adds the chunk sums in f64 in ascending order itself — the very operations
+  // corr_finalize_kernel performs on the stored chunk sums — and finishes its good queries in its epilogue.
+  const bool whole = gridDim.y == 1;
+  // |q|^2 for the error bound of the margin test (f32, upper bound to rounding; corr_finish inflates it)
+  float qn2[QB];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      float n2 = 0.f;
+  for (int qb = 0; qb < QB; ++qb) {
+    float n2 = 0.f;
 #pragma unroll
-      for (int s = 0; s < DK; ++s)
+    for (int s = 0; s < DK; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float v = __uint_as_float((uint32_t)(uint16_t)bq[qb][s][e] << 16);
-          n2 = __builtin_fmaf(v, v, n2);
-        }
-      n2 += __shfl_xor(n2, 32, 64);
-      const int q = q0 + qb * 32 + r;
-      if (h == 0 && q < P) ws.qn2[q] = n2;
-    }
+      for (int e = 0; e < 8; ++e) {
+        const float v = __uint_as_float((uint32_t)(uint16_t)bq[qb][s][e] << 16);
+        n2 = __builtin_fmaf(v, v, n2);
+      }
+    n2 += __shfl_xor(n2, 32, 64);
+    qn2[qb] = n2;
+    const int q = q0 + qb * 32 + r;
+    if (!whole && split == 0 && h == 0 && q < P) ws.qn2[q] = n2;
   }
   DirectState st[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    st[qb].m = -__builtin_inff(); st[qb].m2 = -__builtin_inff(); st[qb].l = 0.f; st[qb].tb = 0;
+    st[qb].m = -__builtin_inff(); st[qb].m2 = -__builtin_inff(); st[qb].l = 0.f; st[qb].tb = 0; st[qb].L = 0.0;
   }
 
   const int c0 = split * range_chunks;                 // first canonical chunk of this key range
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       const float lc = st[qb].l + __shfl_xor(st[qb].l, 32, 64);
       over[qb] |= !(lc <= 3.0e38f);     // the same on both lanes of the query
       const int q = q0 + qb * 32 + r;
-      if (h == 0 && q < P) ws.plc[(size_t)c * P + q] = lc;
+      if (whole) st[qb].L += (double)lc;                    // the first chunk: 0 + l_0 = l_0, as in the finalize merge
+      else if (h == 0 && q < P) ws.plc[(size_t)c * P + q] = lc;
       st[qb].l = 0.f;
     }
   }
@@ -304,7 +311,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     const float mlog2 = NAT ? cmax * kLog2e : cmax;
     const bool bad_q = over[qb] || !(mlog2 >= kLow);      // the same on both lanes of the query
     const int q = q0 + qb * 32 + r;
-    if (h == 0 && q < P) {
+    if (whole) {
+      st[qb].m = cmax; st[qb].m2 = run; st[qb].tb = cand;     // kept for the epilogue below
+      over[qb] = bad_q;
+    } else if (h == 0 && q < P) {
       const size_t off = (size_t)split * P + q;
       ws.pm[off] = cmax;
       ws.pm2[off] = run;
@@ -315,4 +325,17 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   }
   const int any_bad = __syncthreads_or(any_bad_lane ? 1 : 0);
   if (tid == 0) ws.flags[blockIdx.y * gridDim.x + blockIdx.x] = any_bad;
+  if (!whole) return;
+  // ---- one key range: finish the good queries here (corr_finalize_kernel only revisits workgroups with a
+  // bad query, and needs the per-query marks only then)
+  const float kn2 = kn2_max(ws);
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int q = q0 + qb * 32 + r;
+    if (h != 0 || q >= P) continue;
+    if (any_bad) ws.pbad[q] = over[qb] ? 1 : 0;
+    if (!over[qb])
+      corr_finish<NAT ? 2 : 1>(q, st[qb].m, st[qb].m2, st[qb].tb, false, st[qb].L, 0.0, 16 * DK, qn2[qb], kn2, ws, idx_out,
+                               logp_out, lse_out);
+  }
 }

@@ -58,6 +58,23 @@ def revolution(rng, n):
     return np.stack([r * np.cos(ang), r * np.sin(ang), z], 1).astype(np.float32)
 
 
+def revolution_keys(rng, pts, D=64, tau=5.0, azimuth=0.25, noise=1e-3):
+    """Descriptors for the continuous-symmetry object of config 4: random Fourier features of the PROFILE
+    coordinates (height z, radius rho) — constant along the azimuth — plus a weak azimuth-dependent part
+    (amplitude `azimuth`) and a tiny noise, normalised to |k| = tau.  Keys of points on the same parallel
+    are nearly identical: top-2 margins are small by construction (the exact-recheck path gets work) and a
+    correspondence's azimuth is only weakly determined (RANSAC sees a low inlier ratio)."""
+    z, rho = pts[:, 2] / 30.0, np.hypot(pts[:, 0], pts[:, 1]) / 30.0
+    phi = np.arctan2(pts[:, 1], pts[:, 0])
+    na = 8
+    W = rng.normal(0, 2.5, size=(2, D - na))
+    b = rng.uniform(0, 2 * np.pi, D - na)
+    prof = np.cos(np.stack([z, rho], 1) @ W + b)
+    az = np.concatenate([np.cos(np.outer(phi, np.arange(1, na // 2 + 1))), np.sin(np.outer(phi, np.arange(1, na // 2 + 1)))], 1)
+    k = np.concatenate([prof, azimuth * np.sqrt((D - na) / na) * az], 1) + noise * rng.normal(size=(len(pts), D))
+    return (tau * k / np.linalg.norm(k, axis=1, keepdims=True)).astype(np.float32)
+
+
 def diameter(pts, sample=2000, rng=None):
     rng = rng or np.random.default_rng(0)
     s = pts[rng.choice(len(pts), min(sample, len(pts)), replace=False)].astype(np.float64)

@@ -145,3 +145,25 @@ def test_pipelined_steps_with_dropped_results(cuda0):
     torch.cuda.synchronize()
     for poses, status in outs:
         assert torch.equal(poses, ref) and int(status.sum().item()) == 8
+
+
+def test_vote_choose_image_config1_size(cuda0):
+    """BASELINE configs[0]: 8 second-sequence images, 5 000-point clouds — the n x n ADD-S vote of
+    choosePose.py:121-151 (64 KD-tree builds in the reference) against the oracle's double loop with the
+    reference's own sklearn KDTree(leaf_size=2): identical error matrix, row sums, chosen image, top list."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence
+    from oracle import registration_oracle as ro
+    rng = np.random.default_rng(108)
+    S = synth.bumpy_ellipsoid(rng, 5000)
+    V = synth.bumpy_ellipsoid(rng, 5000)
+    diam = synth.diameter(S)
+    n = 8
+    Rg, tg = synth.random_poses(rng, n)
+    P = [synth.perturb_pose(rng, Rg[i], tg[i], 3.0 if i != 5 else 60.0, 3.0) for i in range(n)]     # image 5: a 60 degree outlier
+    Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
+    img, top, err = sequence.vote_choose_image(V, S, Rg, tg, Rp, tp, diam)
+    rerr, radds = ro.vote(V.astype(np.float64), S.astype(np.float64), ro.rel_pose_table(Rg, tg), ro.rel_pose_table(Rp, tp), diam)
+    assert np.array_equal(err, rerr)
+    sums = rerr.sum(1)
+    assert img == int(np.argmax(sums)) and img != 5 and sums[5] == sums.min()
+    assert list(top) == list(np.argsort(-sums, kind="stable")[:50])
