@@ -57,6 +57,7 @@ SIGNATURES = {
     "isr_prep_queries_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_prep_queries": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "isr_p3p_all_roots": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "isr_pnp_ransac_workspace_bytes": (_sz, [_i, _i]),
     "isr_p3p_hypotheses": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp]),
     "isr_ransac_score": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -120,6 +120,32 @@ __global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restric
   }
 }
 
+// Every root of the P3P solver for S independent 3-point problems (test / diagnostic entry point: the
+// production kernels keep one root per sample, this one shows the whole set so it can be compared with
+// the oracle's root set): X (S,3,3) f64 object points, uv (S,3,2) f64 pixels -> poses (S,4,12), n (S).
+__global__ void p3p_all_roots_kernel(const double* __restrict__ X, const double* __restrict__ uv, Cam cam, int S,
+                                     double* __restrict__ poses, int32_t* __restrict__ n_out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  P3PIn in;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    in.x[j] = {X[9 * (size_t)s + 3 * j], X[9 * (size_t)s + 3 * j + 1], X[9 * (size_t)s + 3 * j + 2]};
+    in.y[j] = bearing(cam, uv[6 * (size_t)s + 2 * j], uv[6 * (size_t)s + 2 * j + 1]);
+  }
+  double lam[4][3];
+  const int n = p3p_depths(in, lam);
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    double cand[12];
+    if (!pose_from_depths(in, lam[i], cand)) continue;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) poses[48 * (size_t)s + 12 * k + e] = cand[e];
+    ++k;
+  }
+  n_out[s] = k;
+}
+
 // ------------------------------------------------------------------------------- scoring
 // Pm (H,12) f32 = float(K [R|t]) with the f64 fma order of oracle/isr_oracle.c:proj_matrix_f32.
 // Also zeroes the image's inlier counters (no memset launch).
@@ -611,6 +637,16 @@ extern "C" int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int3
   ISR_REQUIRE(make_batch(Kcam, &seed, 1, &ib), "isr_p3p_hypotheses: singular camera matrix");
   p3p_kernel<<<dim3((H + 63) / 64, 1, 1), 64, 0, isr::as_stream(stream)>>>(p3d, p2d, M_dev, M_cap, ib, H, Rt, ok, sample);
   ISR_CHECK_LAUNCH("p3p_kernel");
+  return ISR_OK;
+}
+
+extern "C" int isr_p3p_all_roots(const double* X, const double* uv, const double* Kcam, int S, double* poses,
+                                 int32_t* n_roots, isr_stream_t stream) {
+  ISR_REQUIRE(X && uv && Kcam && poses && n_roots && S > 0, "isr_p3p_all_roots: bad argument");
+  Cam cam;
+  ISR_REQUIRE(make_cam(Kcam, &cam), "isr_p3p_all_roots: singular camera matrix");
+  p3p_all_roots_kernel<<<(S + 63) / 64, 64, 0, isr::as_stream(stream)>>>(X, uv, cam, S, poses, n_roots);
+  ISR_CHECK_LAUNCH("p3p_all_roots_kernel");
   return ISR_OK;
 }
 

@@ -310,6 +310,22 @@ def p3p_hypotheses(p3d, p2d, Kcam, H: int, seed: int, M_dev=None, want_samples: 
     return (Rt, ok, smp) if want_samples else (Rt, ok)
 
 
+def p3p_all_roots(X, uv, Kcam):
+    """isr_p3p_all_roots (diagnostics): X (S,3,3), uv (S,3,2) f64 on the device -> poses (S,4,3,4), n (S,)."""
+    import ctypes
+    dev = require_cuda(X, uv)
+    X, uv = _f64c(X), _f64c(uv)
+    S = X.shape[0]
+    poses = torch.zeros((S, 4, 3, 4), dtype=torch.float64, device=dev)
+    n = torch.zeros(S, dtype=torch.int32, device=dev)
+    k = _kcam(Kcam)
+    with torch.cuda.device(dev):
+        rc = lib().isr_p3p_all_roots(ptr(X), ptr(uv), ctypes.cast(k, ctypes.c_void_p), S, ptr(poses), ptr(n),
+                                     current_stream(dev))
+    check(rc, "isr_p3p_all_roots")
+    return poses, n
+
+
 def ransac_score(p3d, p2d, Kcam, Rt, ok, reperr: float, M_dev=None):
     import ctypes
     dev = require_cuda(p3d, p2d, Rt, ok)

@@ -159,6 +159,10 @@ int isr_gather_corr_batch(const int32_t* idx, const int32_t* keep, const int32_t
  *   (1 = pose found, 0 = failed: the Python mirror then returns the reference's (1,1,1)).
  * Kcam: host pointer, 9 doubles row-major.
  */
+/* Diagnostics: EVERY root of the device P3P solver for S independent 3-point problems (the production
+ * kernels keep one per sample): X (S,3,3), uv (S,3,2) device f64 -> poses (S,4,12) [R|t], n_roots (S). */
+int isr_p3p_all_roots(const double* X, const double* uv, const double* Kcam, int S, double* poses,
+                      int32_t* n_roots, isr_stream_t stream);
 size_t isr_pnp_ransac_workspace_bytes(int M_cap, int H);
 int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
                        const double* Kcam, int H, uint64_t seed, double* Rt, uint8_t* ok,

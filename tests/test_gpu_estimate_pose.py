@@ -106,6 +106,9 @@ def test_p3p_samples_vs_oracle(cuda0):
         R, t = sols[int((int(pk[i]) * len(sols)) >> 32)]
         checked += 1
         agree += int(synth.rot_angle(R, poses[i][:, :3]) < 1e-5 and np.linalg.norm(t - poses[i][:, 3]) < 1e-3)
+    # rounded pixels make many of these 3-point problems marginal (a root pair close to merging): the two
+    # solvers may then count a different number of roots and the Philox pick lands elsewhere.  The root SETS
+    # themselves are compared, sample by sample, in tests/test_gpu_ransac.py::test_p3p_root_sets_match_...
     assert agree >= 0.93 * checked, (agree, checked)
 
 

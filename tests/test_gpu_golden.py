@@ -66,6 +66,6 @@ def test_icp(reg):
     f0, r0 = reg.evaluate_registration(g["source"], g["target"], 20, g["init"])
     assert abs(f0 - float(g["fitness0"])) < 1e-12 and abs(r0 - float(g["rmse0"])) < 1e-6
     T, fit, rmse = reg.icp_point_to_point(g["source"], g["target"], 20, g["init"])
-    assert synth.rot_angle(T[:3, :3], g["T"][:3, :3]) < 1e-4
-    assert np.linalg.norm(T[:3, 3] - g["T"][:3, 3]) < 1e-3 * max(1.0, np.linalg.norm(g["T"][:3, 3]) / 100)
+    assert synth.rot_angle(T[:3, :3], g["T"][:3, :3]) < 1e-9          # north_star: 1e-4 rad / 1e-3 mm
+    assert np.linalg.norm(T[:3, 3] - g["T"][:3, 3]) < 1e-6 and abs(fit - float(g["fitness"])) < 1e-12
     assert abs(reg.final_chamfer(g["source"], g["target"], T, g["cad"]) - float(g["final_chamfer"])) < 1e-3

@@ -136,9 +136,12 @@ def test_icp_and_final_chamfer(reg, ro):
     assert abs(f - rf) < 1e-12 and abs(r - rr) < 1e-6
     T, fit, rmse = reg.icp_point_to_point(actual_upper, lower, 20, init)
     Tr, rfit, rrmse, traj = ro.icp_point_to_point(actual_upper, lower, 20, init)
-    assert synth.rot_angle(T[:3, :3], Tr[:3, :3]) < 1e-4
-    assert np.linalg.norm(T[:3, 3] - Tr[:3, 3]) < 1e-3 * max(1.0, np.linalg.norm(Tr[:3, 3]) / 100)
-    assert abs(fit - rfit) < 1e-3 and abs(rmse - rrmse) < 1e-4
+    # north_star: 1e-4 rad / 1e-3 mm.  Measured (tools/diag_icp.py, profiles/r02_icp_vs_oracle.txt): the device
+    # loop (f32 search, f64 re-evaluation, Horn/Jacobi) and the oracle (f64 cKDTree, Kabsch/SVD) pick the same
+    # neighbours in every iteration and agree to 1e-15 rad / 1e-12 mm — asserted absolutely, with slack
+    assert synth.rot_angle(T[:3, :3], Tr[:3, :3]) < 1e-9
+    assert np.linalg.norm(T[:3, 3] - Tr[:3, 3]) < 1e-6
+    assert abs(fit - rfit) < 1e-12 and abs(rmse - rrmse) < 1e-9
     c = reg.final_chamfer(actual_upper, lower, T, cad)
     assert abs(c - ro.final_chamfer(actual_upper, lower, Tr, cad)) < 1e-3
     # ICP lowered its own objective (the inlier rmse); with half-overlapping clouds and the
