@@ -46,6 +46,8 @@ SIGNATURES = {
     "isr_corr_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_corr_argmax_recheck_count": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_corr_logsoftmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "isr_mask_bbox": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "isr_crop_normalize": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "isr_select_top_workspace_bytes": (_sz, [_i]),
     "isr_select_top": (_i, [_vp, _i, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_select_top_dev": (_i, [_vp, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

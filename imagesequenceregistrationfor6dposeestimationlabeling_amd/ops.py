@@ -265,6 +265,48 @@ def prep_queries(feat: torch.Tensor, mask: torch.Tensor, c0: int = 0, D: int | N
     return Q, pix, n_dev
 
 
+IMAGENET_MEAN = (0.485, 0.456, 0.406)      # normalize(), inference.py:135-141
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def mask_bbox(mask: torch.Tensor) -> torch.Tensor:
+    """isr_mask_bbox: mask (B, H, W[, C]) u8 on the device -> (B, 4) i32 {x, y, w, h} (cv2.boundingRect of channel 0)."""
+    dev = require_cuda(mask)
+    m = mask if mask.ndim == 4 else mask[..., None]
+    m = m.contiguous()
+    B, H, W, C = m.shape
+    out = torch.empty((B, 4), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_mask_bbox(ptr(m), B, H, W, C, ptr(out), current_stream(dev))
+    check(rc, "isr_mask_bbox")
+    return out
+
+
+def crop_normalize(rgb: torch.Tensor, mask: torch.Tensor, M, out_size: int = 224, use_mask: bool = True,
+                   mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """isr_crop_normalize: rgb (B, H, W, 3) u8, mask (B, H, W[, C]) u8 on the device, M (B, 2, 3) host f64 (the
+    reference's source -> crop affine) -> inputIM (B, 3, r, r) f32, cropMask (B, r, r) u8."""
+    import ctypes
+    import numpy as np
+    dev = require_cuda(rgb, mask)
+    rgb = rgb.contiguous()
+    m = (mask if mask.ndim == 4 else mask[..., None]).contiguous()
+    B, H, W, _ = rgb.shape
+    if rgb.dtype != torch.uint8 or m.dtype != torch.uint8 or tuple(m.shape[:3]) != (B, H, W) or rgb.shape[3] != 3:
+        raise ValueError(f"crop_normalize: rgb {tuple(rgb.shape)} {rgb.dtype} / mask {tuple(m.shape)} {m.dtype}")
+    Mh = np.ascontiguousarray(np.asarray(M, np.float64).reshape(B, 6))
+    mu = (ctypes.c_double * 3)(*[float(v) for v in mean])
+    sd = (ctypes.c_double * 3)(*[float(v) for v in std])
+    out = torch.empty((B, 3, out_size, out_size), dtype=torch.float32, device=dev)
+    cm = torch.empty((B, out_size, out_size), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_crop_normalize(ptr(rgb), ptr(m), B, H, W, m.shape[3], Mh.ctypes.data_as(ctypes.c_void_p), int(out_size),
+                                      int(bool(use_mask)), ctypes.cast(mu, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p),
+                                      ptr(out), ptr(cm), current_stream(dev))
+    check(rc, "isr_crop_normalize")
+    return out, cm
+
+
 def gather_corr(idx, keep, M_dev, pts, pix_xy):
     """isr_gather_corr: p3d (P,3) f32, p2d (P,2) f32 (first M rows valid)."""
     dev = require_cuda(idx, keep, M_dev, pts, pix_xy)

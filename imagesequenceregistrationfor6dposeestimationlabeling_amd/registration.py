@@ -79,6 +79,30 @@ def masked_queries(imfeatsfull, cropMask, down_sample: int = 3, n_feat: int = 12
     return Q[:n], pix[:n].double().cpu().numpy()
 
 
+def crop_inputs(rgb, mask, camparams, out_size: int = 224, useMask: bool = True, down_sample: int = 3, bbox=None):
+    """inference.py:196-232 and 260-263 for one image or a batch: the bounding box of the visible mask
+    (cv2.boundingRect(mask[:, :, 0])), the crop affine M and the crop's camera matrix (formats.crop_affine /
+    crop_camera, host f64 as in the reference), cv2.warpAffine of image and mask, the useMask blanking and
+    normalize() — box, warp, blanking and normalisation on the device (isr_mask_bbox, isr_crop_normalize).
+    rgb (H, W, 3) or (B, H, W, 3) uint8 as cv2.imread delivers it (array or device tensor), mask likewise with 1
+    or 3 channels, camparams (3, 3) or (B, 3, 3).  Returns (inputIM (B, 3, r, r) f32 on the device — the encoder's
+    input of inference.py:232 —, cropMask (B, r, r) uint8 on the device = cropMask[:, :, 0], camMat (B, 3, 3) f64 host
+    after the ::down_sample scaling, M (B, 2, 3)); a single image gives B = 1.  The only host round trip is the
+    box (4 ints per image), which the reference's cv2 calls make too."""
+    from . import formats
+    r_t, m_t = _dev(rgb), _dev(mask)
+    if r_t.ndim == 3:
+        r_t, m_t = r_t[None], m_t[None]
+    B = r_t.shape[0]
+    K = np.broadcast_to(np.asarray(camparams, np.float64), (B, 3, 3))
+    boxes = ops.mask_bbox(m_t).cpu().numpy() if bbox is None else np.asarray(bbox, np.int64).reshape(B, 4)
+    M = np.stack([formats.crop_affine(tuple(int(v) for v in boxes[b]), out_size) for b in range(B)])
+    cam = np.stack([formats.crop_camera(K[b], tuple(int(v) for v in boxes[b]), out_size, down_sample=down_sample)
+                    for b in range(B)])
+    inputIM, cropMask = ops.crop_normalize(r_t, m_t, M, out_size, useMask)
+    return inputIM, cropMask, cam, M
+
+
 def filter_top(in1, frac=0.8, min_n=500):
     """inference.py:282-290: threshold at the reference's order statistic, keep strictly above.
     in1 (P,1) or (P,) log-probs on the device.  Returns nidx as a NumPy int64 array (the

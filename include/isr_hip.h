@@ -97,6 +97,21 @@ int isr_prep_queries(const float* feat, int H, int W, int C, int c0, int D, cons
                      int32_t* n_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * image front end of the per-image loop, image = blockIdx.z: a group costs two launches
+ * isr_mask_bbox       x, y, w, h = cv2.boundingRect(mask[:, :, 0])         inference.py:202
+ *   mask (B, H, W, C) u8, channel 0 -> bbox_dev (B, 4) i32 {x, y, w, h}; all-zero mask -> {0, 0, 0, 0}.
+ * isr_crop_normalize  cropRGB = cv2.warpAffine(rgb, M, (r, r)); cropMask = cv2.warpAffine(mask, M, (r, r));
+ *   if useMask: cropRGB[cropMask[:, :, 0] == 0] = 0; normalize(cropRGB).astype(f32)   inference.py:224-232, 135-141
+ *   rgb (B, H, W, 3) u8, mask (B, H, W, mask_channels) u8; M_host: HOST (B, 6) f64, the reference's 2x3 M
+ *   (source -> crop; inverted here as warpAffine does); mean3 / std3 HOST (3) f64;
+ *   out (B, 3, r, r) f32 channels-first (the network input), crop_mask (B, r, r) u8 = cropMask[:, :, 0].
+ *   Bilinear warp as defined in csrc/crop_normalize.hip (OpenCV is absent: parity unpinned). */
+int isr_mask_bbox(const uint8_t* mask, int B, int H, int W, int C, int32_t* bbox_dev, isr_stream_t stream);
+int isr_crop_normalize(const uint8_t* rgb, const uint8_t* mask, int B, int H, int W, int mask_channels,
+                       const double* M_host, int out_size, int use_mask, const double* mean3,
+                       const double* std3, float* out, uint8_t* crop_mask, isr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * a2  top-80 % correspondence filter
  * replaces  torch.sort(in1[:,0])[0][-perc+1] ; torch.where(in1[:,0] > thr)   inference.py:282-290
  * n = P; if n > min_n: perc = (int)(frac*n), rank = n - perc + 1 else rank = 1  (0-based rank into
