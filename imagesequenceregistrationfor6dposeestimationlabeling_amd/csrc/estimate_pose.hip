@@ -78,6 +78,81 @@ __global__ void ep_queries_kernel(const float* __restrict__ qimg, int r, int e, 
   q[(size_t)o * e + c] = sum / (float)(s * s);
 }
 
+// ------------------------------------------------ avg_queries = False: per-pixel correlation, pooled
+// poseEstSurf.py:72-96.  The reference evaluates log_softmax(pixel descriptor . keys) at FULL resolution
+// (in patches, to fit memory), keeps the value at each scale x scale block's centre pixel (offset scale // 2) as
+// the sampling matrix and the block MAXIMUM as the scoring matrix.  Here: one workgroup per output cell holds
+// the block's scale^2 descriptors in LDS and sweeps the keys three times (per-pixel max, per-pixel sum, write),
+// logits recomputed each time as k-ordered f32 fmaf chains — the full-resolution (r^2 x m) matrix (15.8 GB at
+// r = 222, m = 80 000) never exists.
+constexpr int kMaxBlockPix = 16;   // scale <= 4
+constexpr int kMaxE = 64;
+
+__global__ __launch_bounds__(256) void ep_patch_corr_kernel(const float* __restrict__ query_img, const float* __restrict__ keys,
+                                                            int r, int e, int scale, int res, int m,
+                                                            float* __restrict__ corr_centre, float* __restrict__ corr_blockmax) {
+  __shared__ float q[kMaxBlockPix][kMaxE];
+  __shared__ float red[4][kMaxBlockPix];
+  __shared__ float lse_s[kMaxBlockPix];
+  const int o = blockIdx.x, oy = o / res, ox = o % res;
+  const int npix = scale * scale;
+  for (int i = threadIdx.x; i < npix * e; i += 256) {
+    const int p = i / e, d = i % e;
+    const int y = oy * scale + p / scale, x = ox * scale + p % scale;
+    q[p][d] = query_img[((size_t)y * r + x) * e + d];
+  }
+  __syncthreads();
+  auto logits = [&](int k, float* out) {
+    const float* kr = keys + (size_t)k * e;
+    for (int p = 0; p < npix; ++p) out[p] = 0.f;
+    for (int d = 0; d < e; ++d) {
+      const float kv = kr[d];
+      for (int p = 0; p < npix; ++p) out[p] = __builtin_fmaf(q[p][d], kv, out[p]);
+    }
+  };
+  auto block_reduce = [&](float* v, bool is_max) {       // v[npix] -> lse_s[npix] (as broadcast storage)
+    for (int p = 0; p < npix; ++p) {
+      float a = v[p];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const float b = __shfl_down(a, off, 64);
+        a = is_max ? fmaxf(a, b) : a + b;
+      }
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][p] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < npix) {
+      const int p = threadIdx.x;
+      lse_s[p] = is_max ? fmaxf(fmaxf(red[0][p], red[1][p]), fmaxf(red[2][p], red[3][p]))
+                        : ((red[0][p] + red[1][p]) + red[2][p]) + red[3][p];
+    }
+    __syncthreads();
+  };
+  float l[kMaxBlockPix], mx[kMaxBlockPix], sm[kMaxBlockPix];
+  for (int p = 0; p < npix; ++p) mx[p] = -__builtin_inff();
+  for (int k = threadIdx.x; k < m; k += 256) {
+    logits(k, l);
+    for (int p = 0; p < npix; ++p) mx[p] = fmaxf(mx[p], l[p]);
+  }
+  block_reduce(mx, true);
+  for (int p = 0; p < npix; ++p) { mx[p] = lse_s[p]; sm[p] = 0.f; }
+  __syncthreads();
+  for (int k = threadIdx.x; k < m; k += 256) {
+    logits(k, l);
+    for (int p = 0; p < npix; ++p) sm[p] += __expf(l[p] - mx[p]);
+  }
+  block_reduce(sm, false);
+  for (int p = 0; p < npix; ++p) mx[p] = mx[p] + __logf(lse_s[p]);     // per-pixel log-sum-exp
+  const int centre = (scale / 2) * scale + scale / 2;
+  for (int k = threadIdx.x; k < m; k += 256) {
+    logits(k, l);
+    float best = -__builtin_inff();
+    for (int p = 0; p < npix; ++p) best = fmaxf(best, l[p] - mx[p]);
+    corr_centre[(size_t)o * m + k] = l[centre] - mx[centre];
+    corr_blockmax[(size_t)o * m + k] = best;
+  }
+}
+
 // ------------------------------------------------------- 3x3 spatial max-pool of corr_log (n x m)
 __global__ void ep_pool_corr_kernel(const float* __restrict__ in, int res, int m, float* __restrict__ out) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -341,6 +416,18 @@ extern "C" int isr_ep_pool_corr(const float* corr_log, int res, int m, float* po
   ISR_REQUIRE(res > 0 && m > 0 && res * res <= 65535, "isr_ep_pool_corr: res=%d m=%d", res, m);
   ep_pool_corr_kernel<<<dim3((m + 255) / 256, res * res), 256, 0, isr::as_stream(stream)>>>(corr_log, res, m, pooled);
   ISR_CHECK_LAUNCH("ep_pool_corr_kernel");
+  return ISR_OK;
+}
+
+extern "C" int isr_ep_patch_corr(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
+                                 float* corr_centre, float* corr_blockmax, isr_stream_t stream) {
+  ISR_REQUIRE(query_img && obj_keys && corr_centre && corr_blockmax, "isr_ep_patch_corr: null pointer");
+  ISR_REQUIRE(r > 0 && m > 0 && e > 0 && e <= kMaxE && scale >= 1 && scale * scale <= kMaxBlockPix && r / scale > 0,
+              "isr_ep_patch_corr: r=%d e=%d (<= %d) scale=%d (<= 4) m=%d", r, e, kMaxE, scale, m);
+  const int res = r / scale;
+  ep_patch_corr_kernel<<<res * res, 256, 0, isr::as_stream(stream)>>>(query_img, obj_keys, r, e, scale, res, m, corr_centre,
+                                                                      corr_blockmax);
+  ISR_CHECK_LAUNCH("ep_patch_corr_kernel");
   return ISR_OK;
 }
 

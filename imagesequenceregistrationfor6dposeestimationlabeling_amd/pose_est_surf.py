@@ -64,6 +64,21 @@ def pool_corr(corr_log: torch.Tensor, res: int) -> torch.Tensor:
     return out
 
 
+def patch_corr(query_img: torch.Tensor, obj_keys: torch.Tensor, scale: int = 3):
+    """isr_ep_patch_corr (avg_queries=False, poseEstSurf.py:72-96) -> corr_centre (n, m), corr_blockmax (n, m), res."""
+    dev = require_cuda(query_img, obj_keys)
+    qi, ok = query_img.to(torch.float32).contiguous(), obj_keys.to(torch.float32).contiguous()
+    r, e = qi.shape[0], qi.shape[-1]
+    m = ok.shape[0]
+    res = r // scale
+    centre = torch.empty((res * res, m), dtype=torch.float32, device=dev)
+    bmax = torch.empty((res * res, m), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_ep_patch_corr(ptr(qi), ptr(ok), r, e, int(scale), m, ptr(centre), ptr(bmax), current_stream(dev))
+    check(rc, "isr_ep_patch_corr")
+    return centre, bmax, res
+
+
 def sample(corr_log: torch.Tensor, mask_prob: torch.Tensor, alpha: float, n_samples: int, seed: int) -> torch.Tensor:
     dev = require_cuda(corr_log, mask_prob)
     n, m = corr_log.shape
@@ -116,8 +131,6 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     Returns R (n_poses,3,3) f32, t (n_poses,3) f32, pose_scores, mask_scores, coord_scores (device),
     dist_2d, size_mask, normals_mask (NumPy, pre-prune length) [+ p3dCp, p2dCp if returnPoints]."""
     del pnp_method
-    if not avg_queries:
-        raise IsrError("estimate_pose(avg_queries=False) — the patch-wise variant (poseEstSurf.py:72-96) is not built")
     if visualize:
         raise IsrError("estimate_pose(visualize=True) needs cv2.imshow; not available")
     mask_lgts, query_img = _dev(mask_lgts, torch.float32), _dev(query_img, torch.float32)
@@ -126,8 +139,13 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     m = obj_keys_d.shape[0]
     Ks = _k_scaled(K, down_sample_scale)
     mlp, nmlp, mprob, queries, res = prepare(mask_lgts, query_img, down_sample_scale, max_pool)
-    corr_raw = ops.corr_logsoftmax(queries, obj_keys_d)                        # (n, m) f32
-    corr_log = pool_corr(corr_raw, res) if max_pool else corr_raw
+    if avg_queries:
+        corr_raw = ops.corr_logsoftmax(queries, obj_keys_d)                    # (n, m) f32, :70
+        corr_blk = corr_raw
+    else:
+        # :72-96: per-pixel log-softmax; block-centre values feed the sampler, block maxima the scores
+        corr_raw, corr_blk, _ = patch_corr(query_img, obj_keys_d, down_sample_scale)
+    corr_log = pool_corr(corr_blk, res) if max_pool else corr_blk
     dist_2d = size_mask = normals_mask = None
     p3dCp = p2dCp = None
     if poses is None:

@@ -254,6 +254,12 @@ int isr_ep_prepare(const float* mask_lgts, const float* query_img, int r, int e,
                    float* mask_log_prob, float* neg_mask_log_prob, float* mask_prob, float* queries,
                    void* ws, size_t ws_bytes, isr_stream_t stream);
 int isr_ep_pool_corr(const float* corr_log, int res, int m, float* pooled, isr_stream_t stream);
+/* isr_ep_patch_corr :72-96 (avg_queries = False): per-PIXEL log_softmax(query_img[y, x] . obj_keys) pooled per
+ *                  scale x scale block without ever forming the (r^2 x m) matrix: corr_centre (n, m) = the value at
+ *                  the block's centre pixel (offset scale // 2: the sampling matrix before exp), corr_blockmax (n, m) =
+ *                  the block maximum (the scoring matrix before the 3x3 pool).  query_img (r, r, e), obj_keys (m, e) f32. */
+int isr_ep_patch_corr(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
+                      float* corr_centre, float* corr_blockmax, isr_stream_t stream);
 size_t isr_ep_sample_workspace_bytes(int n, int m);
 int isr_ep_sample(const float* corr_log, const float* mask_prob, int n, int m, double alpha, int n_samples,
                   uint64_t seed, int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream);

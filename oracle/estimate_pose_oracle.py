@@ -69,6 +69,24 @@ def corr_matrices(queries, obj_keys, mask_prob, res, max_pool=True):
     return corr_log.contiguous(), corr
 
 
+def corr_matrices_patch(query_img, obj_keys, res, down_sample_scale=3, max_pool=True):
+    """poseEstSurf.py:72-107, avg_queries=False, without the memory patching: per-pixel log_softmax over the
+    keys; the value at each block's centre pixel (offset scale // 2) is the sampling log-matrix, the block
+    maximum (then the 3x3 spatial max-pool) the scoring matrix.  -> corr_log (n, m), corr_centre_log (n, m)."""
+    ds = down_sample_scale
+    e = query_img.shape[-1]
+    m = obj_keys.shape[0]
+    R = res * ds
+    q = query_img[:R, :R]
+    full = torch.log_softmax(q.reshape(R * R, e) @ obj_keys.T, dim=1).view(R, R, m)
+    off = ds // 2
+    centre = full[off::ds, off::ds].reshape(res * res, m)
+    blk = F.max_pool2d(full.permute(2, 0, 1), ds)                                  # (m, res, res)
+    if max_pool:
+        blk = F.max_pool2d(blk, kernel_size=3, stride=1, padding=1)
+    return blk.permute(1, 2, 0).reshape(res * res, m).contiguous(), centre.contiguous()
+
+
 def sample(corr_log_raw, mask_prob, alpha, n_samples, seed):
     """poseEstSurf.py:111-119 with explicit uniforms and an f64 cumulative sum.  The weight
     (exp(corr_log) * mask_prob)^alpha is evaluated in f64 as exp(alpha*corr_log) * mask_prob^alpha

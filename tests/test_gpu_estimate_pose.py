@@ -168,3 +168,9 @@ def test_estimate_pose_end_to_end(cuda0):
     o2 = pes.estimate_pose(*(a.to(cuda0) if isinstance(a, torch.Tensor) else a for a in args), poses=given)
     r2, _ = eo.estimate_pose(*args, poses=given)
     assert o2[5] is None and abs(o2[2][0].item() - r2[2][0].item()) < 5e-3
+    # avg_queries=False (poseEstSurf.py:72-96): per-pixel correlation, block-centre sampling, block-max scoring
+    o3 = pes.estimate_pose(*(a.to(cuda0) if isinstance(a, torch.Tensor) else a for a in args), max_poses=1500,
+                           max_pose_evaluations=300, avg_queries=False, seed=11)
+    b3 = int(torch.argmax(o3[2]).item())
+    assert o3[0].shape[0] > 0 and bool(torch.isfinite(o3[2][b3]))
+    assert synth.rot_angle(o3[0][b3].cpu().numpy().astype(np.float64), s["R"]) < 0.5

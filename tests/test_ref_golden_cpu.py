@@ -92,6 +92,17 @@ def test_estimate_pose_front_matches_reference_statements():
     assert np.array_equal(g["avg_img_pts"], np.stack([np.arange(n) % res, np.arange(n) // res], 1))
 
 
+def test_estimate_pose_patch_branch_matches_reference_statements():
+    """poseEstSurf.py:72-107 with avg_queries=False executed from the reference (its patch loop included) vs the
+    oracle's un-patched restatement: block-centre sampling matrix and block-max scoring matrix."""
+    g = np.load(G / "ref_estimate_front.npz")
+    ml, q, keys = (torch.from_numpy(g[f"patch_{k}"]) for k in ("mask_lgts", "query_img", "obj_keys"))
+    _, _, mp, _, res = epo.prepare(ml, q, int(g["down_sample_scale"]), True)
+    corr_log, centre = epo.corr_matrices_patch(q, keys, res, int(g["down_sample_scale"]), True)
+    np.testing.assert_allclose(corr_log.numpy(), g["patch_corr_matrix_log"], atol=2e-6)
+    np.testing.assert_allclose((centre.exp() * mp[:, None]).numpy(), g["patch_corr_matrix"], atol=1e-7)
+
+
 def test_refine_objective_matches_reference_statements():
     """pose_refine.py:60-68 (`sample`) and 78-87 (objective body) executed from the reference, with
     autograd through them, vs the oracle's objective — including poses whose projections leave the
