@@ -54,13 +54,24 @@ class _timed:
 
 
 def workspace(device: torch.device, nbytes: int, tag: str = "default") -> torch.Tensor:
-    """A cached, grow-only scratch buffer per (device, stream, tag)."""
+    """A cached, grow-only scratch buffer per (device, stream, tag).
+    While the current stream is being captured into a HIP graph nothing is cached: a buffer allocated during
+    capture lives in the graph's private pool, and handing it to later eager calls (or to another capture)
+    would share that memory with no ordering — a capture gets a fresh buffer per call, which the graph owns.
+    Pre-warm (run the call once eagerly) if the capture should reuse the cached buffer instead."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
     buf = _workspaces.get(key)
-    if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _workspaces[key] = buf
-    return buf
+    if buf is not None and buf.numel() >= nbytes:
+        return buf
+    fresh = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+    if not torch.cuda.is_current_stream_capturing():
+        _workspaces[key] = fresh
+    return fresh
+
+
+def clear_workspaces() -> None:
+    """Drop every cached scratch buffer (e.g. after destroying streams: stream handles are reused as keys)."""
+    _workspaces.clear()
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
