@@ -382,7 +382,7 @@ def main():
     run_steps(0, args.warmup)
     # K1 with the chip to itself (untimed region, rank 0): the in-step figure below shares the GPU with the
     # RANSAC chains and the previous batch's verification, this one is the kernel alone
-    k1_alone_ms = None
+    k1_alone_ms = k1_clock_mhz = k1_rechecked = None
     if rank == 0:
         g_rows = Q_all[:max(args.group, 1)].reshape(-1, D)
         ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries)
@@ -394,6 +394,8 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         k1_alone_ms = e0.elapsed_time(e1) / 2
+        k1_clock_mhz = ops.corr_clock_mhz()        # shader clock held under the kernel (s_memtime / s_memrealtime)
+        k1_rechecked = ops.corr_recheck_count()
     # untimed region, rank 0: the brute-force NN rate at the Chamfer-pair shape and the exact-f32 K1 on one image
     nn_live = f32_exact = None
     if rank == 0:
@@ -448,6 +450,11 @@ def main():
                          "unit": "TFLOP/s", "frac": k1 / PEAK_BF16_MFMA, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": 2.0 * P * max(args.group, 1) * D + 2.0 * N * D + 8.0 * P * max(args.group, 1),
                          "ms_per_launch": k1_ms, "launches": calls,
+                         "clock_mhz_under_kernel": k1_clock_mhz,
+                         "frac_at_held_clock": (k1 / (PEAK_BF16_MFMA * k1_clock_mhz / 2400.0)) if k1_clock_mhz else None,
+                         "clock_note": "peak is quoted at the 2400 MHz boost clock; frac_at_held_clock scales it to the clock "
+                                       "one workgroup of the kernel measured (alone on the GPU, untimed region)",
+                         "queries_decided_by_exact_recheck": k1_rechecked,
                          "alone": {"ms_per_launch": k1_alone_ms,
                                    "frac": (flop / max(calls, 1) / (k1_alone_ms * 1e-3) / PEAK_BF16_MFMA
                                             if calls and k1_alone_ms else None),

@@ -63,6 +63,7 @@ struct CorrWs {
   int32_t* flags;   // (nsplit, qblocks) workgroup holds a bad query
   float* kn2;       // (kKnBlocks) per-block max |k|^2
   int32_t* rcount;  // recheck list length
+  long long* clk;   // diagnostics: {shader-clock ticks, 100 MHz reference ticks} over the life of workgroup (0, 0)
   int32_t* rlist;   // (P) queries to decide exactly
   double* rval;     // (rsplit, P) exact best value per recheck key range and list entry
   int32_t* ridx;    // (rsplit, P)
@@ -791,6 +792,7 @@ size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   o->flags = bf16 ? w.take<int32_t>((size_t)ns * qblocks) : nullptr;
   o->kn2 = bf16 ? w.take<float>(kKnBlocks) : nullptr;
   o->rcount = bf16 ? w.take<int32_t>(4) : nullptr;
+  o->clk = bf16 ? w.take<long long>(2) : nullptr;
   o->rlist = bf16 ? w.take<int32_t>(P) : nullptr;
   o->rval = bf16 ? w.take<double>((size_t)rs * P) : nullptr;
   o->ridx = bf16 ? w.take<int32_t>((size_t)rs * P) : nullptr;
@@ -805,6 +807,26 @@ extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype
   isr::Workspace w(nullptr, 0);
   CorrWs o;
   return carve(w, P, N, dtype, &o) + 256;
+}
+
+// Diagnostics: the shader clock the direct kernel actually ran at in the LAST call on this workspace:
+// workgroup (0, 0) reads s_memtime (counts at the shader clock) and s_memrealtime (constant 100 MHz) when it
+// starts and when it ends (~0.8 ms at the bench's shape, under full load).  Synchronises the stream.
+extern "C" int isr_corr_argmax_clock_mhz(const void* ws_, size_t ws_bytes, int P, int N, int dtype,
+                                         double* mhz_host, isr_stream_t stream_) {
+  ISR_REQUIRE(ws_ && mhz_host && P > 0 && N > 0, "isr_corr_argmax_clock_mhz: bad argument");
+  ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, 0, dtype), "isr_corr_argmax_clock_mhz: workspace too small");
+  *mhz_host = 0.0;
+  if (dtype == ISR_DTYPE_F32) return ISR_OK;
+  isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
+  CorrWs ws;
+  carve(w, P, N, dtype, &ws);
+  hipStream_t stream = isr::as_stream(stream_);
+  long long t[2] = {0, 0};
+  ISR_CHECK_HIP(hipMemcpyAsync(t, ws.clk, sizeof t, hipMemcpyDeviceToHost, stream));
+  ISR_CHECK_HIP(hipStreamSynchronize(stream));
+  if (t[1] > 0) *mhz_host = 100.0 * (double)t[0] / (double)t[1];
+  return ISR_OK;
 }
 
 // Diagnostics: how many queries of the LAST call that used this workspace (same P, N, dtype) went to

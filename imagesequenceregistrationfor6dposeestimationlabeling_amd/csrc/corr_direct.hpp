@@ -64,6 +64,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   const int r = lane & 31, h = lane >> 5;
   const int split = blockIdx.y;
   const int q0 = (blockIdx.x * kWaves + wave) * (QB * 32);
+  // diagnostics (workgroup (0, 0) only): shader-clock and 100 MHz reference counters at start and end
+  const bool probe = blockIdx.x == 0 && blockIdx.y == 0;
+  const long long t_sclk0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
+  const long long t_ref0 = probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 
   bf16x8 bq[QB][DK];
 #pragma unroll
@@ -325,6 +329,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   }
   const int any_bad = __syncthreads_or(any_bad_lane ? 1 : 0);
   if (tid == 0) ws.flags[blockIdx.y * gridDim.x + blockIdx.x] = any_bad;
+  if (probe && tid == 0) {
+    ws.clk[0] = (long long)__builtin_amdgcn_s_memtime() - t_sclk0;
+    ws.clk[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_ref0;
+  }
   if (!whole) return;
   // ---- one key range: finish the good queries here (corr_finalize_kernel only revisits workgroups with a
   // bad query, and needs the per-query marks only then)

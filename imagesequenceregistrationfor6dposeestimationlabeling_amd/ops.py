@@ -205,6 +205,19 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
 _last_corr = None
 
 
+def corr_clock_mhz() -> float:
+    """Diagnostics: the shader clock (MHz) the last bf16 corr_argmax launch held (0.0 for the f32 path)."""
+    import ctypes
+    if _last_corr is None:
+        return 0.0
+    ws, P, N, dtype, dev = _last_corr
+    out = ctypes.c_double(0.0)
+    with torch.cuda.device(dev):
+        rc = lib().isr_corr_argmax_clock_mhz(ptr(ws), ws.numel(), P, N, dtype, ctypes.addressof(out), current_stream(dev))
+    check(rc, "isr_corr_argmax_clock_mhz")
+    return float(out.value)
+
+
 def corr_recheck_count() -> int:
     """Diagnostics: how many queries of the last corr_argmax call were decided by the exact recheck
     (-1 on the f32 path).  Synchronises the current stream."""

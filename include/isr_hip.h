@@ -74,6 +74,11 @@ int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, 
 int isr_corr_argmax_recheck_count(const void* ws, size_t ws_bytes, int P, int N, int dtype,
                                   int32_t* count_host, isr_stream_t stream);
 
+/* Diagnostics: the shader clock (MHz) the bf16 kernel held during the last isr_corr_argmax call on this
+ * workspace, from s_memtime / s_memrealtime over the life of one workgroup; 0 for ISR_DTYPE_F32. */
+int isr_corr_argmax_clock_mhz(const void* ws, size_t ws_bytes, int P, int N, int dtype, double* mhz_host,
+                              isr_stream_t stream);
+
 /* K1 materialising variant for small P: out (P, N) f32 = log_softmax(Q K^T) row-wise.
  * replaces poseEstSurf.py:70 (corr_matrix_log) and getCors with leaves > 1 (caller runs topk). */
 int isr_corr_logsoftmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,

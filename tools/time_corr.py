@@ -28,4 +28,4 @@ for name, q, l2 in cases:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
     print(f"{name}: P={P} N={N} D={D}  {ms:.3f} ms  {2.0*P*N*D/ms*1e-9:.1f} TFLOP/s  {P*N/ms*1e-9:.2f} Texp/s"
-          f"  rechecked {ops.corr_recheck_count()} of {P}")
+          f"  rechecked {ops.corr_recheck_count()} of {P}  shader clock {ops.corr_clock_mhz():.0f} MHz")
