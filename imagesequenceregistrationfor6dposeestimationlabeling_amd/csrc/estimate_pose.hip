@@ -419,6 +419,111 @@ extern "C" int isr_ep_pool_corr(const float* corr_log, int res, int m, float* po
   return ISR_OK;
 }
 
+// ------------------------------------------------------------------------ hypothesis pruning
+// poseEstSurf.py:147-169, one thread per sample: the largest pairwise pixel distance of the first three
+// correspondences (f32, as the reference's float32 p2d), the depth window from the object diameter, and the
+// sign of normal . camera-ray at the three object points (f64: f32 points, f64 normals and poses, as there).
+__global__ void ep_prune_kernel(const int64_t* __restrict__ corr_idx, const double* __restrict__ poses,
+                                const uint8_t* __restrict__ ok, const float* __restrict__ obj_pts,
+                                const double* __restrict__ normals, int S, int res, int m, double dist_min_px,
+                                double z_min, double z_max, int do_prune, float* __restrict__ dist_2d,
+                                uint8_t* __restrict__ size_mask, uint8_t* __restrict__ normals_mask,
+                                uint8_t* __restrict__ keep) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  float px[3], py[3];
+  int k3[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int64_t c = corr_idx[4 * (size_t)s + j];
+    const int pix = (int)(c / m);
+    k3[j] = (int)(c % m);
+    px[j] = (float)(pix % res);
+    py[j] = (float)(pix / res);
+  }
+  float d = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float dx = px[a] - px[b], dy = py[a] - py[b];
+      d = fmaxf(d, sqrtf(dx * dx + dy * dy));
+    }
+  const double* T = poses + 12 * (size_t)s;
+  const double z = T[11];
+  const bool sz = (z_min < z) && (z < z_max);
+  bool nm = true;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const double X = obj_pts[3 * (size_t)k3[j]], Y = obj_pts[3 * (size_t)k3[j] + 1], Z = obj_pts[3 * (size_t)k3[j] + 2];
+    const double nx = normals[3 * (size_t)k3[j]], ny = normals[3 * (size_t)k3[j] + 1], nz = normals[3 * (size_t)k3[j] + 2];
+    double dot = 0.0;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double nc = (nx * T[4 * r] + ny * T[4 * r + 1]) + nz * T[4 * r + 2];                  // n3d @ R^T
+      const double pc = ((X * T[4 * r] + Y * T[4 * r + 1]) + Z * T[4 * r + 2]) + T[4 * r + 3];     // p3d @ R^T + t
+      dot += nc * pc;
+    }
+    nm = nm && (dot < 0.0);
+  }
+  dist_2d[s] = d;
+  size_mask[s] = sz;
+  normals_mask[s] = nm;
+  keep[s] = ok[s] && (!do_prune || (((double)d >= dist_min_px) && sz && nm));
+}
+
+// One block: ordered compaction of the kept samples (S <= a few 10 000) and the f32 [R|t] rows of the first
+// max_eval of them — the poses handed to batch_score (poseEstSurf.py:167, 174-177).
+__global__ __launch_bounds__(1024) void ep_compact_kernel(const uint8_t* __restrict__ keep, const double* __restrict__ poses, int S,
+                                                          int max_eval, int32_t* __restrict__ keep_idx, int32_t* __restrict__ n_keep,
+                                                          float* __restrict__ Rt32) {
+  __shared__ int32_t tsum[1024];
+  const int t = threadIdx.x;
+  const int per = (S + 1023) / 1024;
+  int c = 0;
+  for (int j = 0; j < per; ++j) {
+    const int s = t * per + j;
+    if (s < S) c += keep[s];
+  }
+  tsum[t] = c;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = (t >= off) ? tsum[t - off] : 0;
+    __syncthreads();
+    tsum[t] += v;
+    __syncthreads();
+  }
+  int o = (t > 0) ? tsum[t - 1] : 0;
+  for (int j = 0; j < per; ++j) {
+    const int s = t * per + j;
+    if (s < S && keep[s]) {
+      keep_idx[o] = s;
+      if (o < max_eval)
+        for (int e = 0; e < 12; ++e) Rt32[12 * (size_t)o + e] = (float)poses[12 * (size_t)s + e];
+      ++o;
+    }
+  }
+  if (t == 1023) *n_keep = tsum[1023];
+}
+
+extern "C" int isr_ep_prune(const int64_t* corr_idx, const double* poses, const uint8_t* ok, const float* obj_pts,
+                            const double* obj_normals, int S, int res, int m, double K00, double obj_diameter,
+                            double dist_2d_min, int do_prune, int max_eval, float* dist_2d, uint8_t* size_mask,
+                            uint8_t* normals_mask, uint8_t* keep, int32_t* keep_idx, int32_t* n_keep, float* Rt32,
+                            isr_stream_t stream_) {
+  ISR_REQUIRE(corr_idx && poses && ok && obj_pts && obj_normals && dist_2d && size_mask && normals_mask && keep && keep_idx &&
+                  n_keep && Rt32, "isr_ep_prune: null pointer");
+  ISR_REQUIRE(S > 0 && res > 0 && m > 0 && max_eval > 0, "isr_ep_prune: S=%d res=%d m=%d max_eval=%d", S, res, m, max_eval);
+  hipStream_t stream = isr::as_stream(stream_);
+  const double z_min = K00 * obj_diameter / ((double)res * 20.0), z_max = K00 * obj_diameter / ((double)res * 0.5);
+  ep_prune_kernel<<<(S + 255) / 256, 256, 0, stream>>>(corr_idx, poses, ok, obj_pts, obj_normals, S, res, m,
+                                                       dist_2d_min * (double)res, z_min, z_max, do_prune, dist_2d, size_mask,
+                                                       normals_mask, keep);
+  ep_compact_kernel<<<1, 1024, 0, stream>>>(keep, poses, S, max_eval, keep_idx, n_keep, Rt32);
+  ISR_CHECK_LAUNCH("ep_prune kernels");
+  return ISR_OK;
+}
+
 extern "C" int isr_ep_patch_corr(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
                                  float* corr_centre, float* corr_blockmax, isr_stream_t stream) {
   ISR_REQUIRE(query_img && obj_keys && corr_centre && corr_blockmax, "isr_ep_patch_corr: null pointer");

@@ -1,12 +1,13 @@
 """estimate_pose() with the reference's signature (poseEstSurf.py:11-15, returns :258-261), the device
 stages in csrc/estimate_pose.hip + isr_corr_logsoftmax.
 
-What moved to the device: mask / query pooling, the (n x m) log-softmax correspondence matrix and its
-3x3 spatial max-pool, inversion sampling (no 4.4e8-element cumsum), the 10 000-iteration cv2.solveP3P
-Python loop (one thread per sample), and batch_score's scatter_min z-buffer.  What stays on the host,
-as in the reference: the pruning masks (NumPy on <= 10 000 poses, poseEstSurf.py:147-169) and the
-slicing to max_pose_evaluations.  `seed` is an addition: the reference draws torch.rand on the device
-and an unseeded np.random.randint.
+What runs on the device: mask / query pooling, the (n x m) log-softmax correspondence matrix (or its per-pixel
+variant for avg_queries=False) and its 3x3 spatial max-pool, inversion sampling (no 4.4e8-element cumsum), the
+10 000-iteration cv2.solveP3P Python loop (one thread per sample), the pruning masks and the ordered selection
+of the poses to score (poseEstSurf.py:147-177), and batch_score's scatter_min z-buffer.  The host sees one
+integer (how many poses survive: it sizes the returned tensors) and the three mask arrays the signature
+returns as NumPy.  `seed` is an addition: the reference draws torch.rand on the device and an unseeded
+np.random.randint.
 """
 from __future__ import annotations
 
@@ -105,6 +106,28 @@ def p3p_samples(corr_idx: torch.Tensor, res: int, m: int, obj_pts: torch.Tensor,
     return poses, ok
 
 
+def prune(corr_idx, poses, ok, obj_pts, obj_normals, res: int, m: int, K00: float, obj_diameter: float,
+          dist_2d_min: float = 0.1, do_prune: bool = True, max_eval: int = 1000):
+    """isr_ep_prune (poseEstSurf.py:147-177) -> dist_2d (S) f32, size_mask, normals_mask, keep (S) u8,
+    keep_idx (S) i32 (first n_keep valid, ascending), n_keep (1) i32, Rt32 (max_eval, 3, 4) f32 — all on the device."""
+    dev = require_cuda(corr_idx, poses, ok, obj_pts, obj_normals)
+    S = corr_idx.shape[0]
+    normals = obj_normals.to(torch.float64).contiguous()
+    dist = torch.empty(S, dtype=torch.float32, device=dev)
+    sm = torch.empty(S, dtype=torch.uint8, device=dev)
+    nm = torch.empty(S, dtype=torch.uint8, device=dev)
+    keep = torch.empty(S, dtype=torch.uint8, device=dev)
+    kidx = torch.empty(S, dtype=torch.int32, device=dev)
+    nk = torch.empty(1, dtype=torch.int32, device=dev)
+    Rt32 = torch.empty((max_eval, 3, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_ep_prune(ptr(corr_idx), ptr(poses.contiguous()), ptr(ok), ptr(obj_pts), ptr(normals), S, int(res), int(m),
+                                float(K00), float(obj_diameter), float(dist_2d_min), int(bool(do_prune)), int(max_eval),
+                                ptr(dist), ptr(sm), ptr(nm), ptr(keep), ptr(kidx), ptr(nk), ptr(Rt32), current_stream(dev))
+    check(rc, "isr_ep_prune")
+    return dist, sm, nm, keep, kidx, nk, Rt32
+
+
 def zbuf_score(obj_pts, R, t, K, res, mask_log_prob, neg_mask_log_prob, corr_log):
     """batch_score (poseEstSurf.py:182-237) for R (B,3,3), t (B,3) f32 on the device -> 3 x (B,) f32."""
     dev = require_cuda(obj_pts, R, t)
@@ -151,34 +174,29 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     if poses is None:
         corr_idx = sample(corr_raw, mprob, alpha, max_poses, seed)
         poses_d, ok = p3p_samples(corr_idx, res, m, obj_pts_d, Ks, seed)
-        ci = corr_idx.cpu().numpy()
+        normals_d = _dev(np.asarray(obj_normals, np.float64))                      # normals_scaled.npy is float64 (:121)
+        dist_d, sm_d, nm_d, keep_d, kidx_d, nk_d, Rt32 = prune(corr_idx, poses_d, ok, obj_pts_d, normals_d, res, m, Ks[0, 0],
+                                                                obj_diameter, dist_2d_min, do_prune, max_pose_evaluations)
+        n_keep = int(nk_d.item())                  # the one host round trip: it sizes the outputs
+        n_poses = min(n_keep, max_pose_evaluations)
+        # the reference's arrays have one entry per SOLVED sample (poses_mask, :145), in sample order
         pmask = ok.cpu().numpy().astype(bool)
-        poses = poses_d.cpu().numpy()
-        p2d_idx, p3d_idx = ci // m, ci % m
-        p2d = np.stack([p2d_idx % res, p2d_idx // res], axis=-1).astype(np.float32)       # img_pts[p2d_idx].float()
-        p3d = obj_pts_d.cpu().numpy()[p3d_idx]
-        n3d = np.asarray(obj_normals)[p3d_idx[:, :3]]
-        poses, p2d, p3d, n3d = [a[pmask] for a in (poses, p2d, p3d, n3d)]
-        # pruning, verbatim NumPy (poseEstSurf.py:147-169)
-        dist_2d = np.linalg.norm(p2d[:, :3, None] - p2d[:, None, :3], axis=-1).max(axis=(1, 2)) if len(p2d) else np.zeros(0)
-        dist_2d_mask = dist_2d >= dist_2d_min * res
-        z = poses[:, 2, 3]
-        z_min = Ks[0, 0] * obj_diameter / (res * 20)
-        z_max = Ks[0, 0] * obj_diameter / (res * 0.5)
-        size_mask = (z_min < z) & (z < z_max)
-        Rt = poses[:, :3, :3].transpose(0, 2, 1)
-        n3d_cam = n3d @ Rt
-        p3d_cam = p3d[:, :3] @ Rt + poses[:, None, :3, 3]
-        normals_mask = np.all((n3d_cam * p3d_cam).sum(axis=-1) < 0, axis=-1)
-        if do_prune:
-            keep = dist_2d_mask & size_mask & normals_mask
-            poses, p3dCp, p2dCp = poses[keep], p3d[keep], p2d[keep]
-    poses = np.asarray(poses)[slice(None, max_pose_evaluations)]
-    n_poses = len(poses)
+        dist_2d = dist_d.cpu().numpy()[pmask]
+        size_mask = sm_d.cpu().numpy().astype(bool)[pmask]
+        normals_mask = nm_d.cpu().numpy().astype(bool)[pmask]
+        R, t = Rt32[:n_poses, :, :3].contiguous(), Rt32[:n_poses, :, 3].contiguous()
+        if returnPoints:
+            kept = kidx_d[:n_keep].long()
+            ci = corr_idx[kept]
+            p2dCp = torch.stack([(ci // m) % res, (ci // m) // res], dim=-1).float().cpu().numpy()   # img_pts[p2d_idx].float()
+            p3dCp = obj_pts_d[ci % m].cpu().numpy()
+    else:
+        poses = np.asarray(poses)[slice(None, max_pose_evaluations)]
+        n_poses = len(poses)
+        R = torch.from_numpy(np.ascontiguousarray(poses[:, :3, :3])).float().to(dev)
+        t = torch.from_numpy(np.ascontiguousarray(poses[:, :3, 3])).float().to(dev)
     if debug:
         print('n_poses', n_poses)
-    R = torch.from_numpy(np.ascontiguousarray(poses[:, :3, :3])).float().to(dev)
-    t = torch.from_numpy(np.ascontiguousarray(poses[:, :3, 3])).float().to(dev)
     pose_scores = torch.empty(n_poses, device=dev)
     mask_scores = torch.empty(n_poses, device=dev)
     coord_scores = torch.empty(n_poses, device=dev)

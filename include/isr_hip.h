@@ -270,6 +270,16 @@ int isr_ep_sample(const float* corr_log, const float* mask_prob, int n, int m, d
                   uint64_t seed, int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream);
 int isr_ep_p3p(const int64_t* corr_idx, int res, int m, const float* obj_pts, const double* Kcam, int S,
                uint64_t seed, double* poses, uint8_t* ok, isr_stream_t stream);
+/* isr_ep_prune      :147-177 per sample: dist_2d (S) f32 = largest pairwise pixel distance of the first three
+ *                  correspondences, size_mask / normals_mask (S) u8, keep (S) u8 = ok and (all three masks, when
+ *                  do_prune); then the ordered list keep_idx of the kept samples, their number *n_keep, and the f32
+ *                  [R|t] rows Rt32 (max_eval, 12) of the first max_eval of them (the poses batch_score evaluates).
+ *                  obj_normals (m, 3) f64 (normals_scaled.npy is float64), K00 = the down-scaled focal length. */
+int isr_ep_prune(const int64_t* corr_idx, const double* poses, const uint8_t* ok, const float* obj_pts,
+                 const double* obj_normals, int S, int res, int m, double K00, double obj_diameter,
+                 double dist_2d_min, int do_prune, int max_eval, float* dist_2d, uint8_t* size_mask,
+                 uint8_t* normals_mask, uint8_t* keep, int32_t* keep_idx, int32_t* n_keep, float* Rt32,
+                 isr_stream_t stream);
 size_t isr_zbuf_score_workspace_bytes(int B, int res);
 int isr_zbuf_score(const float* obj_pts, int m, const float* Rt, int B, const double* Kcam, int res,
                    const float* mask_log_prob, const float* neg_mask_log_prob, const float* corr_log,
