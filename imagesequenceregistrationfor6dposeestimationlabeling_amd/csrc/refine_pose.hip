@@ -6,7 +6,10 @@
 // p_norm = (p + 0.5) * 2 / res - 1, i.e. the sample position in pixel units is p itself (pixel
 // centres at integers) clamped to [0, res-1].  The reference differentiates this with autograd and
 // a cv2.Rodrigues round trip; only the translation is live there (pose_refine.py:73-76 builds R from
-// a constant), so the analytic gradient returned here is d score / d t.
+// a constant), so the analytic gradient the reference-shaped entry returns is d score / d t.
+// isr_refine_objective_full adds d score / d R (9, row-major: sum_i g_i X_i^T with g_i the gradient with
+// respect to the camera-frame point) for the evidently intended variant that also optimises the rotation
+// (the caller chains it with the Rodrigues Jacobian).
 // One thread per visible surface point, f64 accumulation, fixed-shape tree reduction.
 #include "isr_common.hpp"
 
@@ -14,6 +17,7 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kBlocks = 64;
+constexpr int kAcc = 14;
 
 struct P34 { double p[12]; double k[9]; };
 
@@ -21,8 +25,10 @@ __global__ __launch_bounds__(kThreads) void refine_obj_kernel(const float* __res
                                                               int N, int e, const float* __restrict__ qimg,
                                                               const float* __restrict__ denom, int res, P34 P,
                                                               double* __restrict__ partial) {
-  __shared__ double red[kThreads / 64][5];
-  double acc[5] = {0, 0, 0, 0, 0};  // sum nominator, sum denominator, d/dt (3) of (nom - den)
+  __shared__ double red[kThreads / 64][kAcc];
+  double acc[kAcc];                 // sum nominator, sum denominator, d/dt (3) and d/dR (9) of (nom - den)
+#pragma unroll
+  for (int q = 0; q < kAcc; ++q) acc[q] = 0.0;
   for (int i = blockIdx.x * kThreads + threadIdx.x; i < N; i += kBlocks * kThreads) {
     const double x = X[3 * (size_t)i], y = X[3 * (size_t)i + 1], z = X[3 * (size_t)i + 2];
     const double px = P.p[0] * x + P.p[1] * y + P.p[2] * z + P.p[3];
@@ -59,46 +65,49 @@ __global__ __launch_bounds__(kThreads) void refine_obj_kernel(const float* __res
     acc[1] += den;
     // d(u,v)/dt = (K_row0 - u K_row2, K_row1 - v K_row2) / pz
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-      acc[2 + j] += (fx * (P.k[j] - u * P.k[6 + j]) + fy * (P.k[3 + j] - v * P.k[6 + j])) * ipz;
+    for (int j = 0; j < 3; ++j) {
+      const double g = (fx * (P.k[j] - u * P.k[6 + j]) + fy * (P.k[3 + j] - v * P.k[6 + j])) * ipz;   // d/d(camera point)_j
+      acc[2 + j] += g;
+      acc[5 + 3 * j] += g * x;
+      acc[5 + 3 * j + 1] += g * y;
+      acc[5 + 3 * j + 2] += g * z;
+    }
   }
 #pragma unroll
-  for (int q = 0; q < 5; ++q) {
+  for (int q = 0; q < kAcc; ++q) {
     double s = acc[q];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 5)
-    partial[(size_t)blockIdx.x * 5 + threadIdx.x] =
+  if (threadIdx.x < kAcc)
+    partial[(size_t)blockIdx.x * kAcc + threadIdx.x] =
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-__global__ void refine_obj_reduce_kernel(const double* __restrict__ partial, int N, double* __restrict__ out) {
-  if (threadIdx.x >= 5 || blockIdx.x) return;
-  double s = 0.0;
-  for (int b = 0; b < kBlocks; ++b) s += partial[(size_t)b * 5 + threadIdx.x];
-  __shared__ double v[5];
-  v[threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double n = (double)N;
-    out[0] = -(v[0] / n - v[1] / n) / 2.0;
-    out[1] = -(v[2] / n) / 2.0;
-    out[2] = -(v[3] / n) / 2.0;
-    out[3] = -(v[4] / n) / 2.0;
+// nout = 4: {score, d/dt}; 13: {score, d/dt (3), d/dR (9)}
+__global__ void refine_obj_reduce_kernel(const double* __restrict__ partial, int N, double* __restrict__ out, int nout) {
+  __shared__ double v[kAcc];
+  if (threadIdx.x < kAcc) {
+    double s = 0.0;
+    for (int b = 0; b < kBlocks; ++b) s += partial[(size_t)b * kAcc + threadIdx.x];
+    v[threadIdx.x] = s;
   }
+  __syncthreads();
+  const double n = (double)N;
+  if (threadIdx.x == 0) out[0] = -(v[0] / n - v[1] / n) / 2.0;
+  if (threadIdx.x >= 1 && threadIdx.x < nout) out[threadIdx.x] = -(v[1 + threadIdx.x] / n) / 2.0;
 }
 
 }  // namespace
 
-extern "C" int isr_refine_objective(const float* X, const float* keys, int N, int e, const float* query_img,
-                                    const float* denom_img, int res, const double* Kcrop, const double* Rt,
-                                    double* out4, void* ws, size_t ws_bytes, isr_stream_t stream_) {
-  ISR_REQUIRE(X && keys && query_img && denom_img && Kcrop && Rt && out4, "isr_refine_objective: null pointer");
+static int refine_impl(const float* X, const float* keys, int N, int e, const float* query_img, const float* denom_img,
+                       int res, const double* Kcrop, const double* Rt, double* out, int nout, void* ws, size_t ws_bytes,
+                       isr_stream_t stream_) {
+  ISR_REQUIRE(X && keys && query_img && denom_img && Kcrop && Rt && out, "isr_refine_objective: null pointer");
   ISR_REQUIRE(N > 0 && e > 0 && res > 0, "isr_refine_objective: N=%d e=%d res=%d", N, e, res);
-  const size_t need = sizeof(double) * kBlocks * 5 + 256;
+  const size_t need = sizeof(double) * kBlocks * kAcc + 256;
   if (!ws || ws_bytes < need) {
     isr::set_error("isr_refine_objective: workspace %zu < %zu", ws_bytes, need);
     return ISR_ERR_WORKSPACE;
@@ -110,9 +119,21 @@ extern "C" int isr_refine_objective(const float* X, const float* keys, int N, in
   for (int i = 0; i < 9; ++i) P.k[i] = Kcrop[i];
   hipStream_t stream = isr::as_stream(stream_);
   isr::Workspace w(ws, ws_bytes);
-  double* partial = w.take<double>((size_t)kBlocks * 5);
+  double* partial = w.take<double>((size_t)kBlocks * kAcc);
   refine_obj_kernel<<<kBlocks, kThreads, 0, stream>>>(X, keys, N, e, query_img, denom_img, res, P, partial);
-  refine_obj_reduce_kernel<<<1, 64, 0, stream>>>(partial, N, out4);
+  refine_obj_reduce_kernel<<<1, 64, 0, stream>>>(partial, N, out, nout);
   ISR_CHECK_LAUNCH("refine objective kernels");
   return ISR_OK;
+}
+
+extern "C" int isr_refine_objective(const float* X, const float* keys, int N, int e, const float* query_img,
+                                    const float* denom_img, int res, const double* Kcrop, const double* Rt,
+                                    double* out4, void* ws, size_t ws_bytes, isr_stream_t stream) {
+  return refine_impl(X, keys, N, e, query_img, denom_img, res, Kcrop, Rt, out4, 4, ws, ws_bytes, stream);
+}
+
+extern "C" int isr_refine_objective_full(const float* X, const float* keys, int N, int e, const float* query_img,
+                                         const float* denom_img, int res, const double* Kcrop, const double* Rt,
+                                         double* out13, void* ws, size_t ws_bytes, isr_stream_t stream) {
+  return refine_impl(X, keys, N, e, query_img, denom_img, res, Kcrop, Rt, out13, 13, ws, ws_bytes, stream);
 }

@@ -293,10 +293,17 @@ int isr_zbuf_score(const float* obj_pts, int m, const float* Rt, int B, const do
  *   padding_mode='border') on (p + 0.5) * 2 / res - 1.  X (N,3) object coordinates, keys (N,e),
  *   query_img (res,res,e), denom_img (res,res) all f32; Kcrop (9) and Rt (12, [R|t]) HOST doubles.
  *   The reference's rotation is constant inside the objective (pose_refine.py:73-76), so only the
- *   translation gradient exists.  ws >= 64*5*8 + 256 bytes. */
+ *   translation gradient exists.  ws >= 64*14*8 + 256 bytes. */
 int isr_refine_objective(const float* X, const float* keys, int N, int e, const float* query_img,
                          const float* denom_img, int res, const double* Kcrop, const double* Rt,
                          double* out4, void* ws, size_t ws_bytes, isr_stream_t stream);
+
+ /* The same objective with the rotation live (the evidently intended variant): out13 (device, 13 f64)
+ * = { score, d score / d t (3), d score / d R (9, row-major) }; the caller chains d/dR with the Rodrigues Jacobian.
+ * ws >= 64*14*8 + 256 bytes (also enough for isr_refine_objective). */
+int isr_refine_objective_full(const float* X, const float* keys, int N, int e, const float* query_img,
+                              const float* denom_img, int res, const double* Kcrop, const double* Rt,
+                              double* out13, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* a8  ADD(verts, gtR, gtT, R, T)   inference.py:116-117
  * mean_out[b] = mean_v || Ta[b] v - Tb[b] v ||  (f64; Ta/Tb (B,12) f64 [R|t], NULL = identity). */

@@ -35,6 +35,33 @@ def objective(t, R, coord_masked, keys_masked, query_img, denom_img, K_crop, ret
     return score.item()
 
 
+def rodrigues_torch(rvec: torch.Tensor) -> torch.Tensor:
+    """Rotation matrix of a rotation vector, differentiable (what cv2.Rodrigues computes; the reference wraps it in
+    an autograd Function, pose_refine.py:7-18)."""
+    th = torch.sqrt((rvec * rvec).sum())
+    k = rvec / th
+    Kx = torch.stack([torch.stack([torch.zeros(()), -k[2], k[1]]), torch.stack([k[2], torch.zeros(()), -k[0]]),
+                      torch.stack([-k[1], k[0], torch.zeros(())])]).to(rvec.dtype)
+    return torch.eye(3, dtype=rvec.dtype) + torch.sin(th) * Kx + (1 - torch.cos(th)) * (Kx @ Kx)
+
+
+def objective_with_rotation(pose6, coord_masked, keys_masked, query_img, denom_img, K_crop):
+    """The objective of pose_refine.py:70-91 with Rt = [Rodrigues(pose[:3]) | pose[3:]] (the evidently intended
+    variant: the reference builds R from a constant), value and 6-gradient by torch autograd in f64."""
+    res = query_img.shape[0]
+    pose = torch.tensor(np.asarray(pose6, np.float64), dtype=torch.float64, requires_grad=True)
+    Rt = torch.cat((rodrigues_torch(pose[:3]), pose[3:, None]), dim=1)
+    P = torch.from_numpy(np.asarray(K_crop, np.float64)) @ Rt
+    X = torch.cat((coord_masked.double(), torch.ones(len(coord_masked), 1, dtype=torch.float64)), dim=1)
+    p_img = X @ P.T
+    p_img = p_img[..., :2] / p_img[..., 2:]
+    p_norm = (p_img + 0.5) * (2 / res) - 1
+    q = sample(query_img.double(), p_norm)
+    score = -((keys_masked.double() * q).sum(dim=-1).mean() - sample(denom_img.double(), p_norm)[:, 0].mean()) / 2
+    score.backward()
+    return score.item(), pose.grad.numpy().copy()
+
+
 def denominator_image(query_img, keys_sampled):
     """pose_refine.py:56."""
     return torch.logsumexp(query_img @ keys_sampled.T, dim=-1, keepdim=True)
