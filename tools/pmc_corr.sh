@@ -22,7 +22,7 @@ for f in glob.glob(out + "/*/*/*counter_collection.csv"):
         k = r["Kernel_Name"]
         if "corr_" not in k: continue
         if "finalize" in k: k = "corr_finalize"
-        elif "direct" in k: k = "corr_bf16_direct_kernel"
+        elif "direct" in k: k = "corr_bf16_direct_kernel<log2>" if "false>" in k else "corr_bf16_direct_kernel<natural>"
         elif "corr_bf16_kernel" in k: k = "corr_bf16_kernel(fallback, log2)" if ("true" in k or "Lb1" in k) else "corr_bf16_kernel"
         else: k = k.split("(")[0][-40:]
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -31,5 +31,16 @@ with open(out + "/summary.txt", "w") as g:
         g.write(f"== {k}\n")
         for c, v in sorted(d.items()):
             g.write(f"  {c:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
+        if "direct" in k and "SQ_INSTS_VALU" in d and "SQ_WAVES" in d:
+            # per 32x32 tile: a wave owns 64 queries = 2 query blocks x ceil(N/32) key tiles
+            import os
+            N = int(os.environ.get("PMC_N", "20000"))
+            tiles = (sum(d["SQ_WAVES"]) / len(d["SQ_WAVES"])) * 2 * ((N + 31) // 32)
+            m = lambda c: sum(d[c]) / len(d[c])
+            g.write(f"  -- per 32x32 tile: VALU+MFMA instructions {m('SQ_INSTS_VALU') / tiles:.1f} (MFMA {m('SQ_INSTS_MFMA') / tiles:.2f}, "
+                    f"transcendental {m('SQ_INSTS_VALU_TRANS_F32') / tiles:.1f}), SALU {m('SQ_INSTS_SALU') / tiles:.2f}, LDS {m('SQ_INSTS_LDS') / tiles:.2f}\n")
+            if "SQ_BUSY_CU_CYCLES" in d:
+                g.write(f"  -- VALU active {m('SQ_ACTIVE_INST_VALU') / m('SQ_BUSY_CU_CYCLES'):.3f} (SQ_ACTIVE_INST_VALU / SQ_BUSY_CU_CYCLES), MFMA busy "
+                        f"{m('SQ_VALU_MFMA_BUSY_CYCLES') / m('SQ_BUSY_CU_CYCLES') / 4:.3f} (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES), LDS bank conflicts {m('SQ_LDS_BANK_CONFLICT'):.0f}\n")
 print(open(out + "/summary.txt").read())
 PY
