@@ -284,7 +284,7 @@ __global__ void best_kernel(const int32_t* __restrict__ n_inl, const uint8_t* __
   best_dev += b;
   if (status_dev) status_dev += b;
   if (pose_dev) pose_dev += (size_t)b * 12;
-  if (gn_state && threadIdx.x == 0) gn_state[4 * b] = 0;
+  if (gn_state && threadIdx.x == 0) { gn_state[4 * b] = 0; gn_state[4 * b + 1] = 0; }
   int bc = -1, bh = -1;
   for (int h = threadIdx.x; h < H; h += 256) {
     if (ok[h] && n_inl[h] > bc) { bc = n_inl[h]; bh = h; }  // ascending h per thread: lowest kept
@@ -321,7 +321,7 @@ __global__ void refined_proj_kernel(const double* __restrict__ pose, ImgBatch ib
     const int r = e / 4, c = e % 4;
     Pm[12 * (size_t)b + e] = (float)fma(cam.k[3 * r + 2], T[8 + c], fma(cam.k[3 * r + 1], T[4 + c], cam.k[3 * r] * T[c]));
   }
-  if (e == 0) gn_state[4 * b] = 0;
+  if (e == 0) { gn_state[4 * b] = 0; gn_state[4 * b + 1] = 0; }
 }
 
 __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
@@ -350,80 +350,13 @@ constexpr int kRefThreads = 256;
 constexpr int kRefBlocks = 64;
 constexpr int kNAcc = 28;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2)
 
-__global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
-    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev, int M_cap,
-    const uint32_t* __restrict__ mask, int mask_words, ImgBatch ib, const double* __restrict__ Rt,
-    const int32_t* __restrict__ status_dev, const int32_t* __restrict__ state,
-    double* __restrict__ partial) {
-  __shared__ double red[kRefThreads / 64][kNAcc];
-  const int img = blockIdx.z;
-  const Cam& cam = ib.cam[img];
-  p3d += (size_t)img * M_cap * 3; p2d += (size_t)img * M_cap * 2;
-  if (mask) mask += (size_t)img * mask_words;
-  Rt += (size_t)img * 12; state += 4 * img; partial += (size_t)img * kRefBlocks * kNAcc;
-  if (state[0]) return;  // converged (block-uniform)
-  double acc[kNAcc];
-#pragma unroll
-  for (int i = 0; i < kNAcc; ++i) acc[i] = 0.0;
-  const int M = M_dev[img];
-  const bool live = (status_dev == nullptr) || (status_dev[img] != 0);
-  if (live) {
-    double T[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) T[i] = Rt[i];
-    for (int m = blockIdx.x * kRefThreads + threadIdx.x; m < M; m += kRefBlocks * kRefThreads) {
-      if (mask && !((mask[m >> 5] >> (m & 31)) & 1u)) continue;
-      const double X = p3d[3 * (size_t)m], Y = p3d[3 * (size_t)m + 1], Z = p3d[3 * (size_t)m + 2];
-      const double xc = T[0] * X + T[1] * Y + T[2] * Z + T[3];
-      const double yc = T[4] * X + T[5] * Y + T[6] * Z + T[7];
-      const double zc = T[8] * X + T[9] * Y + T[10] * Z + T[11];
-      const double px = cam.k[0] * xc + cam.k[1] * yc + cam.k[2] * zc;
-      const double py = cam.k[3] * xc + cam.k[4] * yc + cam.k[5] * zc;
-      const double pz = cam.k[6] * xc + cam.k[7] * yc + cam.k[8] * zc;
-      const double ipz = 1.0 / pz;
-      const double u = px * ipz, v = py * ipz;
-      const double ru = u - (double)p2d[2 * (size_t)m], rv = v - (double)p2d[2 * (size_t)m + 1];
-      // d(u,v)/dXc = (K_row - (u,v) K_row2) / pz
-      const double a0 = (cam.k[0] - u * cam.k[6]) * ipz, a1 = (cam.k[1] - u * cam.k[7]) * ipz, a2 = (cam.k[2] - u * cam.k[8]) * ipz;
-      const double b0 = (cam.k[3] - v * cam.k[6]) * ipz, b1 = (cam.k[4] - v * cam.k[7]) * ipz, b2 = (cam.k[5] - v * cam.k[8]) * ipz;
-      // Xc' = Xc + w x Xc + dt  ->  dXc/dw = -[Xc]x, dXc/dt = I
-      const double Ju[6] = {a2 * yc - a1 * zc, a0 * zc - a2 * xc, a1 * xc - a0 * yc, a0, a1, a2};
-      const double Jv[6] = {b2 * yc - b1 * zc, b0 * zc - b2 * xc, b1 * xc - b0 * yc, b0, b1, b2};
-      int k = 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) acc[k++] += Ju[i] * Ju[j] + Jv[i] * Jv[j];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) acc[21 + i] += Ju[i] * ru + Jv[i] * rv;
-      acc[27] += ru * ru + rv * rv;
-    }
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-#pragma unroll
-  for (int i = 0; i < kNAcc; ++i) {
-    double s = acc[i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) red[wave][i] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNAcc)
-    partial[(size_t)blockIdx.x * kNAcc + threadIdx.x] =
-        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-}
-
 // One block: 28 lanes sum the block partials in order (fixed order: reproducible), lane 0 solves
 // the 6x6 normal equations by Cholesky and retracts:  R <- Q(w) R,  t <- Q(w) t + dt  with Q(w) the
 // rotation of the unit quaternion (1, w/2)/|.| (sqrt only: no sin/cos, so the step is plain IEEE
 // arithmetic).  state[0] = 1 once the step is below 1e-12: later launches return at once.
-__global__ void gn_solve_kernel(const double* __restrict__ partial, double* __restrict__ Rt,
-                                const int32_t* __restrict__ status_dev, int32_t* __restrict__ state) {
+// (Runs in the LAST workgroup of gn_accumulate_kernel to deliver its partial sums: one launch per iteration.)
+__device__ void gn_solve(const double* __restrict__ partial, double* __restrict__ Rt, int32_t* __restrict__ state) {
   __shared__ double s[kNAcc];
-  const int img = blockIdx.z;
-  partial += (size_t)img * kRefBlocks * kNAcc; Rt += (size_t)img * 12; state += 4 * img;
-  if (status_dev && status_dev[img] == 0) return;
-  if (state[0]) return;
   if (threadIdx.x < kNAcc) {
     double a = 0.0;
     for (int b = 0; b < kRefBlocks; ++b) a += partial[(size_t)b * kNAcc + threadIdx.x];
@@ -484,6 +417,81 @@ __global__ void gn_solve_kernel(const double* __restrict__ partial, double* __re
   const double dt = x[3] * x[3] + x[4] * x[4] + x[5] * x[5];
   const double tt = O[3] * O[3] + O[7] * O[7] + O[11] * O[11];
   if (dw < 1e-24 && dt < 1e-20 * (tt + 1.0)) state[0] = 1;
+}
+
+
+__global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
+    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev, int M_cap,
+    const uint32_t* __restrict__ mask, int mask_words, ImgBatch ib, const double* __restrict__ Rt,
+    const int32_t* __restrict__ status_dev, int32_t* __restrict__ state,
+    double* __restrict__ partial) {
+  __shared__ double red[kRefThreads / 64][kNAcc];
+  __shared__ int last;
+  const int img = blockIdx.z;
+  const Cam& cam = ib.cam[img];
+  p3d += (size_t)img * M_cap * 3; p2d += (size_t)img * M_cap * 2;
+  if (mask) mask += (size_t)img * mask_words;
+  Rt += (size_t)img * 12; state += 4 * img; partial += (size_t)img * kRefBlocks * kNAcc;
+  if (state[0]) return;  // converged (block-uniform)
+  if (status_dev && status_dev[img] == 0) return;   // no pose: nothing to refit (block-uniform)
+  double acc[kNAcc];
+#pragma unroll
+  for (int i = 0; i < kNAcc; ++i) acc[i] = 0.0;
+  const int M = M_dev[img];
+  const bool live = (status_dev == nullptr) || (status_dev[img] != 0);
+  if (live) {
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = Rt[i];
+    for (int m = blockIdx.x * kRefThreads + threadIdx.x; m < M; m += kRefBlocks * kRefThreads) {
+      if (mask && !((mask[m >> 5] >> (m & 31)) & 1u)) continue;
+      const double X = p3d[3 * (size_t)m], Y = p3d[3 * (size_t)m + 1], Z = p3d[3 * (size_t)m + 2];
+      const double xc = T[0] * X + T[1] * Y + T[2] * Z + T[3];
+      const double yc = T[4] * X + T[5] * Y + T[6] * Z + T[7];
+      const double zc = T[8] * X + T[9] * Y + T[10] * Z + T[11];
+      const double px = cam.k[0] * xc + cam.k[1] * yc + cam.k[2] * zc;
+      const double py = cam.k[3] * xc + cam.k[4] * yc + cam.k[5] * zc;
+      const double pz = cam.k[6] * xc + cam.k[7] * yc + cam.k[8] * zc;
+      const double ipz = 1.0 / pz;
+      const double u = px * ipz, v = py * ipz;
+      const double ru = u - (double)p2d[2 * (size_t)m], rv = v - (double)p2d[2 * (size_t)m + 1];
+      // d(u,v)/dXc = (K_row - (u,v) K_row2) / pz
+      const double a0 = (cam.k[0] - u * cam.k[6]) * ipz, a1 = (cam.k[1] - u * cam.k[7]) * ipz, a2 = (cam.k[2] - u * cam.k[8]) * ipz;
+      const double b0 = (cam.k[3] - v * cam.k[6]) * ipz, b1 = (cam.k[4] - v * cam.k[7]) * ipz, b2 = (cam.k[5] - v * cam.k[8]) * ipz;
+      // Xc' = Xc + w x Xc + dt  ->  dXc/dw = -[Xc]x, dXc/dt = I
+      const double Ju[6] = {a2 * yc - a1 * zc, a0 * zc - a2 * xc, a1 * xc - a0 * yc, a0, a1, a2};
+      const double Jv[6] = {b2 * yc - b1 * zc, b0 * zc - b2 * xc, b1 * xc - b0 * yc, b0, b1, b2};
+      int k = 0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = i; j < 6; ++j) acc[k++] += Ju[i] * Ju[j] + Jv[i] * Jv[j];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc[21 + i] += Ju[i] * ru + Jv[i] * rv;
+      acc[27] += ru * ru + rv * rv;
+    }
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < kNAcc; ++i) {
+    double s = acc[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) red[wave][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNAcc)
+    partial[(size_t)blockIdx.x * kNAcc + threadIdx.x] =
+        ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+  // the last workgroup to deliver its sums (agent-scope fences order them before the ticket) solves
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(&state[1], 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (threadIdx.x == 0) state[1] = 0;
+  gn_solve(partial, const_cast<double*>(Rt), state);
 }
 
 // ------------------------------------------------------------------------------ compaction
@@ -696,7 +704,6 @@ static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev,
   for (int it = 0; it < iters; ++it) {
     gn_accumulate_kernel<<<dim3(kRefBlocks, 1, B), kRefThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, mask, mask_words_of(M_cap),
                                                                              ib, Rt_io, status_dev, state, partial);
-    gn_solve_kernel<<<dim3(1, 1, B), 64, 0, stream>>>(partial, Rt_io, status_dev, state);
   }
   ISR_CHECK_LAUNCH("pnp refine kernels");
   return ISR_OK;
