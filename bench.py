@@ -62,12 +62,14 @@ def parse_args():
     ap.add_argument("--itr", type=int, default=500)
     ap.add_argument("--cad", type=int, default=5000)
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the images are pipelined over")
-    ap.add_argument("--group", type=int, default=16, help="images per K1 launch (1 = one launch per image)")
+    ap.add_argument("--group", type=int, default=32, help="images per K1 launch (1 = one launch per image)")
     ap.add_argument("--refine-iters", type=int, default=6, help="Gauss-Newton refit iterations after RANSAC")
     ap.add_argument("--k1", choices=("log2", "natural"), default="log2",
                     help="log2: descriptors multiplied by log2(e) before their one rounding to bf16 "
                          "(ISR_DTYPE_BF16_LOG2, the direct-sum kernel); natural: plain bf16 (ISR_DTYPE_BF16)")
     ap.add_argument("--tau", type=float, default=5.0, help="descriptor norm |k| (softmax sharpness), see make_model")
+    ap.add_argument("--depth", type=int, default=1,
+                    help="how many batches the registration may run ahead of the verification (step overlap)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish a step's ICP + final Chamfer before the next step's registration starts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -362,15 +364,17 @@ def main():
             for s in range(first, first + count):
                 last = verify(*register(s))
             return last
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
-        pending = None
-        with ThreadPoolExecutor(max_workers=1) as pool:
+        pending = deque()
+        with ThreadPoolExecutor(max_workers=1) as pool:      # one worker: the collectives keep their order
             for s in range(first, first + count):
                 r = register(s)
-                if pending is not None:
-                    last = pending.result()
-                pending = pool.submit(verify, *r)
-            last = pending.result()
+                while len(pending) >= max(args.depth, 1):
+                    last = pending.popleft().result()
+                pending.append(pool.submit(verify, *r))
+            while pending:
+                last = pending.popleft().result()
         return last
 
     def barrier():

@@ -6,7 +6,7 @@ set -u
 out=${1:-gpurun_out/pmc_r2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$out"
-for tag in "k1_1 tools/time_corr.py 307200 20000 64" "k1_16 tools/time_corr.py 4915200 20000 64" "nn tools/time_nn_brute.py 20000 32"; do
+for tag in "k1_1 tools/time_corr.py 307200 20000 64" "k1_16 tools/time_corr.py 4915200 20000 64" "k1_32 tools/time_corr.py 9830400 20000 64" "nn tools/time_nn_brute.py 20000 32"; do
   set -- $tag; name=$1; shift
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$out/$name/fetch" -- python3 "$@" > "$out/$name.fetch.log" 2>&1
   rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d "$out/$name/write" -- python3 "$@" > "$out/$name.write.log" 2>&1

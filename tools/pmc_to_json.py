@@ -32,7 +32,7 @@ k1 = {"kernel": "corr_bf16_direct_kernel<4,2,false> (K1, ISR_DTYPE_BF16_LOG2) + 
       "per_launch": {}}
 K1_KERNELS = ["corr_bf16_direct_kernel", "corr_finalize_kernel", "corr_bf16_kernel", "corr_recheck_kernel", "corr_keynorm_kernel",
               "corr_recheck_merge_kernel"]
-for g, P in (("1", 307200), ("16", 4915200)):
+for g, P in (("1", 307200), ("16", 4915200), ("32", 9830400)):
     c, n = counters(f"k1_{g}", K1_KERNELS)
     parts = {k: hbm(c, k) for k in K1_KERNELS}
     total = sum(p["hbm_bytes"] for p in parts.values())
