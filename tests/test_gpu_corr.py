@@ -293,3 +293,37 @@ def test_corr_result_is_independent_of_the_launch(cuda0, log2, P, N, D):
     mixed[1::2] = (Q[1:512:2].float() * 40.0).bfloat16()
     im, lm = ops.corr_argmax(mixed, Kb, log2_prescaled=log2)
     assert torch.equal(im[0::2], idx[0:512:2]) and torch.equal(lm[0::2], logp[0:512:2])
+
+
+def test_corr_randomised_shapes_distributions_and_scales(cuda0, oracle_lib):
+    """A slice of tools/stress_corr.py (60 cases there): random P, N, D, logit scale, descriptor distribution
+    (Gaussian, planted, duplicate keys, sparse) and path (bf16 / bf16-log2).  Indices equal the oracle's exactly,
+    logp to 5e-5 of the logit scale, and a random sub-launch reproduces its rows bit for bit."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(2)
+    for c in range(14):
+        D = int(rng.choice([16, 32, 64, 128]))
+        P, N = int(rng.integers(1, 2500)), int(rng.integers(1, 25000))
+        scale = float(rng.choice([0.05, 0.5, 1.0, 3.0, 8.0, 25.0]))
+        kind = rng.choice(["gauss", "planted", "dups", "sparse"])
+        K = rng.normal(0, 1, (N, D)).astype(np.float32)
+        if kind == "sparse":
+            K *= rng.uniform(size=(N, D)) < 0.2
+        if kind == "dups" and N > 4:
+            K[N // 2:] = K[: N - N // 2]
+        Q = rng.normal(0, 1, (P, D)).astype(np.float32)
+        if kind == "planted":
+            Q = K[rng.integers(N, size=P)] + 0.3 * Q
+        Q *= scale / np.sqrt(D) * (1 + 3 * (rng.uniform(size=(P, 1)) < 0.05))
+        log2 = bool(rng.integers(2))
+        qb = ops.prescale_queries_log2(torch.from_numpy(Q)) if log2 else torch.from_numpy(Q).bfloat16()
+        kb = torch.from_numpy(K).bfloat16()
+        idx, logp = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0), log2_prescaled=log2)
+        o = oracle_lib.corr_argmax_bf16(_bits(qb), _bits(kb), logit_scale=np.log(2.0) if log2 else 1.0)
+        assert np.array_equal(idx.cpu().numpy(), o["idx"]), (c, kind, P, N, D, scale, log2)
+        err = np.abs(logp.cpu().numpy() - (o["maxlogit"] - o["lse"])) / np.maximum(1.0, np.abs(o["maxlogit"]) * 1e-1)
+        assert err.max() < 5e-5, (c, kind, float(err.max()))
+        a = int(rng.integers(0, P))
+        b = int(rng.integers(a + 1, P + 1))
+        i2, l2 = ops.corr_argmax(qb[a:b].contiguous().to(cuda0), kb.to(cuda0), log2_prescaled=log2)
+        assert torch.equal(i2, idx[a:b]) and torch.equal(l2, logp[a:b]), (c, kind, a, b)
