@@ -879,7 +879,7 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     const uint16_t* k = static_cast<const uint16_t*>(K);
     const bool log2 = dtype == ISR_DTYPE_BF16_LOG2;
     const dim3 cgrid(p.qblocks, p.nchunks);       // fallback: one canonical chunk per workgroup
-    const dim3 rgrid(256, p.rsplit);
+    const dim3 rgrid(128, p.rsplit);      // groups of 256 listed queries stride over 128 workgroups per key range
     const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
     corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, ws);
 #define ISR_LAUNCH_BF16(DKv)                                                                                  \
