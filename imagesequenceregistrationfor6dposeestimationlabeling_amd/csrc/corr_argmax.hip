@@ -13,7 +13,7 @@
 // lane-local — no cross-lane traffic until one 2-lane merge per chunk.
 //
 // A query's result is a function of (query, keys) ONLY — not of the launch it travels in:
-//   * the log-sum-exp is accumulated over CANONICAL CHUNKS of kChunk keys (a constant): per chunk a
+//   * the log-sum-exp is accumulated over CANONICAL CHUNKS of kChunk = 4096 keys (a constant): per chunk a
 //     partial (reference R_c, l_c = sum 2^(s log2e - R_c)) whose arithmetic order is fixed, written
 //     to the workspace; corr_finalize_kernel adds the chunks in ascending order in f64.  Which
 //     workgroup computed a chunk (the plan splits the key range by occupancy) never matters.
@@ -42,14 +42,14 @@ constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kQB = 2;                       // 32-query blocks per wave
 constexpr int kTK = 128;                     // keys per LDS stage
-constexpr int kChunkStages = 16;             // stages per canonical chunk
+constexpr int kChunkStages = 32;             // stages per canonical chunk
 constexpr int kChunk = kTK * kChunkStages;   // keys per canonical chunk of the log-sum-exp (a CONSTANT)
 constexpr float kLog2e = 1.4426950408889634f;
 // M2 of a lane that has seen no valid key yet: finite, so a fully masked tile gives
 // exp2(fma(-inf, log2e, 1e30)) = 0 instead of NaN, and the first real key rescales l by 2^-huge = 0.
 constexpr float kNoM2 = -1.0e30f;
 constexpr int kKnBlocks = 64;                // blocks of the key-norm pass
-constexpr int kRSplitMax = 16;               // key ranges of the recheck pass (latency, not arithmetic)
+constexpr int kRSplitMax = 4;                // key ranges of the recheck pass (latency, not arithmetic; sizes rval / ridx)
 
 // Workspace of one isr_corr_argmax call.
 struct CorrWs {

@@ -11,7 +11,7 @@
 // query's sums are made of depends on the query and the keys only, never on its wave-mates or on
 // the launch (round 1 anchored the reference on the wave's first tile: results then moved by ~1e-5
 // with the launch shape, enough to flip the strict `>` of the top-80 % cut, inference.py:282-290).
-// Canonical order of the sum: keys are cut into CHUNKS of kChunk = 2048 (a constant); inside a
+// Canonical order of the sum: keys are cut into CHUNKS of kChunk = 4096 (a constant); inside a
 // chunk each of the query's two lanes adds its 16 rows per 32-key tile in register order, tile
 // after tile, in f32; the two lane sums are added; the chunk sums go to memory and
 // corr_finalize_kernel adds them in ascending order in f64.  A workgroup may own any number of
