@@ -298,7 +298,7 @@ int isr_refine_objective(const float* X, const float* keys, int N, int e, const 
                          const float* denom_img, int res, const double* Kcrop, const double* Rt,
                          double* out4, void* ws, size_t ws_bytes, isr_stream_t stream);
 
- /* The same objective with the rotation live (the evidently intended variant): out13 (device, 13 f64)
+/* The same objective with the rotation live (the evidently intended variant): out13 (device, 13 f64)
  * = { score, d score / d t (3), d score / d R (9, row-major) }; the caller chains d/dR with the Rodrigues Jacobian.
  * ws >= 64*14*8 + 256 bytes (also enough for isr_refine_objective). */
 int isr_refine_objective_full(const float* X, const float* keys, int N, int e, const float* query_img,
