@@ -79,6 +79,24 @@ def register_crop(model: SequenceModel, feat: torch.Tensor, mask: torch.Tensor, 
     return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp), n_dev
 
 
+def register_frame(model: SequenceModel, rgb, mask, camparams, encoder, n_feat: int = 12, down_sample: int = 3,
+                   itr: int = 500, reperr: float = 2.0, seed: int = 0, refine_iters: int = 10, confidence: float = 0.99,
+                   useMask: bool = True):
+    """One iteration of the reference's per-image loop, inference.py:196-293, from the raw frame to the pose with
+    everything but the descriptor network in this package: the crop front end on the device
+    (registration.crop_inputs: mask box, crop affine + camera matrix, warp of image and mask, useMask blanking,
+    normalize), `encoder` — the caller's network, `encoder_rgb` of inference.py:237: (1, 3, 224, 224) f32 ->
+    (1, C, 224, 224) with the descriptor in channels [0, n_feat) — and then register_crop (sub-sampling, masking,
+    getCors, top-80 % filter, pnp).  Returns (ImageResult, n_dev, camMat (3, 3))."""
+    from . import registration
+    inputIM, cropMask, cam, _ = registration.crop_inputs(rgb, mask, camparams, useMask=useMask, down_sample=down_sample)
+    with torch.no_grad():
+        imfeatsfull = torch.movedim(encoder(inputIM), 1, 3)                       # inference.py:236-237
+    res, n_dev = register_crop(model, imfeatsfull, cropMask[0], cam[0], n_feat=n_feat, down_sample=down_sample, itr=itr,
+                               reperr=reperr, seed=seed, refine_iters=refine_iters, confidence=confidence)
+    return res, n_dev, cam[0]
+
+
 def _publish(results: list[ImageResult], consumer: torch.cuda.Stream) -> None:
     """The tensors of `results` were allocated on side streams and are about to be read on `consumer`
     (which has been made to wait for those streams).  Tell the caching allocator: without
