@@ -61,6 +61,7 @@ struct CorrWs {
   float* pmc;       // (nchunks, P) chunk maxima (fallback / f32: the chunk reference is ceil of it)
   float* qn2;       // (P) |q|^2, then (finalize) the recheck threshold
   int32_t* flags;   // (nsplit, qblocks) workgroup holds a bad query
+  int32_t* blist;   // the set flags as a list of (range * qblocks + query block); its length is rcount[1]
   float* kn2;       // (kKnBlocks) per-block max |k|^2
   int32_t* rcount;  // recheck list length
   long long* clk;   // diagnostics: {shader-clock ticks, 100 MHz reference ticks} over the life of workgroup (0, 0)
@@ -227,24 +228,29 @@ __device__ __forceinline__ void update_max_l2(f32x16& acc, L2State& st, f32x16& 
   }
 }
 
-// The per-query-reference kernel: ONE canonical chunk per workgroup (grid.y = chunk), so every
-// chunk starts from a clean state (C = 0 for the first tile) whatever else the launch holds.  It
-// runs behind corr_bf16_direct_kernel and only for the queries that kernel marked bad; it leaves
-// (chunk maximum, l_c relative to R_c = ceil(chunk maximum [* log2 e])) — the index of a bad query is
-// always decided by the exact recheck, so no arg-max is kept here.
+// The per-query-reference kernel: ONE canonical chunk per work item, so every chunk starts from a
+// clean state (C = 0 for the first tile) whatever else the launch holds.  It runs behind
+// corr_bf16_direct_kernel and only for the query blocks that kernel LISTED as holding a bad query
+// (ws.blist; a fixed grid strides over list x chunks — with nothing listed the launch costs a few
+// microseconds, where a (query blocks x chunks) grid of early exits cost 130 us per 32-image launch);
+// it leaves (chunk maximum, l_c relative to R_c = ceil(chunk maximum [* log2 e])) — the index of a
+// bad query is always decided by the exact recheck, so no arg-max is kept here.
+constexpr int kFallbackGrid = 1024;
 template <int DK, bool LOG2>
 __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
-    int range_chunks, CorrWs ws) {
-  const int chunk = blockIdx.y;
-  const int range = chunk / range_chunks;
-  if (ws.flags[range * gridDim.x + blockIdx.x] == 0) return;
+    int range_chunks, int qblocks, int nchunks, CorrWs ws) {
   using KS = KeyStage<DK>;
   __shared__ uint4 lds[2][KS::CHUNKS];
-
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int q0 = (blockIdx.x * kWaves + wave) * (kQB * 32);
+  const int nlisted = ws.rcount[1];
+  for (int item = blockIdx.x; item < nlisted * range_chunks; item += gridDim.x) {   // block-uniform
+  const int ent = ws.blist[item / range_chunks];
+  const int range = ent / qblocks, bx = ent - range * qblocks;
+  const int chunk = range * range_chunks + item % range_chunks;
+  if (chunk >= nchunks) continue;                   // the last key range may hold fewer chunks
+  const int q0 = (bx * kWaves + wave) * (kQB * 32);
 
   bf16x8 bq[kQB][DK];
 #pragma unroll
@@ -322,6 +328,7 @@ __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
       ws.plc[(size_t)chunk * P + q] = lc;
     }
   }
+  }  // work items
 }
 
 // ------------------------------------------------------------------------------------- f32
@@ -468,7 +475,7 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
   __syncthreads();
   if (threadIdx.x == 0) {
     ws.kn2[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    if (blockIdx.x == 0) *ws.rcount = 0;
+    if (blockIdx.x == 0) { ws.rcount[0] = 0; ws.rcount[1] = 0; }
   }
 }
 
@@ -535,12 +542,15 @@ __global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, int ns
                                                             float* __restrict__ logp, float* __restrict__ lse) {
   // bf16, ONE key range: the direct kernel finished its good queries itself; only workgroups that hold a bad
   // query (the same 256-query blocks there and here) have anything left to do
+  // (there the grid is a fixed one striding over the direct kernel's list of such blocks: nothing listed, nothing done)
   const bool finished_in_kernel = MODE != 0 && nsplit == 1;
-  if (finished_in_kernel && ws.flags[blockIdx.x] == 0) return;
+  const int nblocks = finished_in_kernel ? ws.rcount[1] : (int)gridDim.x;
   const float kn2 = MODE != 0 ? kn2_max(ws) : 0.f;
-  const int q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= P) return;
-  if (finished_in_kernel && !ws.pbad[q]) return;
+  for (int e = blockIdx.x; e < nblocks; e += gridDim.x) {
+  const int qblock = finished_in_kernel ? ws.blist[e] : e;
+  const int q = qblock * blockDim.x + threadIdx.x;
+  if (q >= P) continue;
+  if (finished_in_kernel && !ws.pbad[q]) continue;
   float G1 = -__builtin_inff(), G2 = -__builtin_inff();
   int bi = 0;
   bool anybad = false;
@@ -568,6 +578,7 @@ __global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, int ns
     else L += l * exp2((double)R - Rf);
   }
   corr_finish<MODE>(q, G1, G2, bi, anybad, L, Rf, D, MODE != 0 ? ws.qn2[q] : 0.f, kn2, ws, idx, logp, lse);
+  }  // query blocks
 }
 
 // ------------------------------------------------------------------------------ exact recheck
@@ -790,6 +801,7 @@ size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   o->pbad = bf16 ? w.take<int32_t>((size_t)ns * P) : nullptr;
   o->qn2 = bf16 ? w.take<float>(P) : nullptr;
   o->flags = bf16 ? w.take<int32_t>((size_t)ns * qblocks) : nullptr;
+  o->blist = bf16 ? w.take<int32_t>((size_t)ns * qblocks) : nullptr;
   o->kn2 = bf16 ? w.take<float>(kKnBlocks) : nullptr;
   o->rcount = bf16 ? w.take<int32_t>(4) : nullptr;
   o->clk = bf16 ? w.take<long long>(2) : nullptr;
@@ -866,6 +878,7 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
   carve(w, P, N, dtype, &ws);
   const dim3 grid(p.qblocks, p.nsplit);
   const int fin_blocks = (P + 255) / 256;
+  const int fin_bf16 = (p.nsplit == 1 && fin_blocks > kFallbackGrid) ? kFallbackGrid : fin_blocks;   // one key range: list-driven
 
   if (dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2) {
     ISR_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128,
@@ -878,7 +891,7 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     const uint16_t* q = static_cast<const uint16_t*>(Q);
     const uint16_t* k = static_cast<const uint16_t*>(K);
     const bool log2 = dtype == ISR_DTYPE_BF16_LOG2;
-    const dim3 cgrid(p.qblocks, p.nchunks);       // fallback: one canonical chunk per workgroup
+    const int cgrid = (int)(((long)p.qblocks * p.nchunks < kFallbackGrid) ? (long)p.qblocks * p.nchunks : kFallbackGrid);   // fallback: strides over listed blocks x chunks
     const dim3 rgrid(128, p.rsplit);      // groups of 256 listed queries stride over 128 workgroups per key range
     const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
     corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, ws);
@@ -887,14 +900,16 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     if (log2) {                                                                                               \
       corr_bf16_direct_kernel<DKv, kQB, false><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,          \
                                                                               p.range_chunks, ws, idx, logp, lse); \
-      corr_bf16_kernel<DKv, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws);  \
-      corr_finalize_kernel<1><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
+      corr_bf16_kernel<DKv, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,      \
+                                                                  p.nchunks, ws);  \
+      corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
     } else {                                                                                                  \
       corr_bf16_direct_kernel<DKv, kQB, true><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,           \
                                                                              p.range_chunks, ws, idx, logp, lse); \
-      corr_bf16_kernel<DKv, false><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws); \
-      corr_finalize_kernel<2><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
+      corr_bf16_kernel<DKv, false><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,     \
+                                                                   p.nchunks, ws); \
+      corr_finalize_kernel<2><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
     }                                                                                                         \
     corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, ws);      \

@@ -328,7 +328,11 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     any_bad_lane |= bad_q && q < P;
   }
   const int any_bad = __syncthreads_or(any_bad_lane ? 1 : 0);
-  if (tid == 0) ws.flags[blockIdx.y * gridDim.x + blockIdx.x] = any_bad;
+  if (tid == 0) {
+    const int ent = blockIdx.y * gridDim.x + blockIdx.x;
+    ws.flags[ent] = any_bad;
+    if (any_bad) ws.blist[atomicAdd(&ws.rcount[1], 1)] = ent;      // the fallback kernel's work list
+  }
   if (probe && tid == 0) {
     ws.clk[0] = (long long)__builtin_amdgcn_s_memtime() - t_sclk0;
     ws.clk[1] = (long long)__builtin_amdgcn_s_memrealtime() - t_ref0;
