@@ -166,6 +166,140 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
   }
 }
 
+// ------------------------------------------------------------------ warm-started search (ICP passes 1..)
+// From the second ICP pass on every source point knows last pass's neighbour; its distance under the new T is
+// an upper bound that is almost always the answer.  With the running minimum that tight, the search can run on
+// the 3-FMA form  s = |t|^2 - 2 q.t  (= d2 - |q|^2 up to rounding: half the VALU work of the difference form)
+// as a FILTER: a group of 8 targets is looked at in the difference form — the arithmetic that defines the
+// result — only when some lane's smallest s could belong to a target that beats or ties its best:
+//   s <= best - |q|^2 + E,   E >= |s + |q|^2 - d2|.
+// With u = 2^-24: the three fmas of s and the three of |t|^2 err by <= 6u (|q| + |t|)^2, |q|^2 by 3u |q|^2, d2 by
+// 5u d2 <= 5u (|q| + |t|)^2 — together <= 14u (|q| + |t|)^2 <= 28u (|q|^2 + |t|^2); E = 64u (|q|^2 + max |t|^2 of
+// the tile) + 8u best also covers the roundings of the threshold itself.  The winner is the lexicographic
+// minimum of (d2, index) — what the cold kernel's strict '<' in ascending index order produces — so the loop's
+// results do not depend on which kernel ran a pass.  (Cold, the filter loses: with 64 queries per wave some lane
+// sets a new record in ~45 % of the groups of a 3 300-target split and the verification costs more than the
+// cheap form saves; tools/time_icp.py.)
+template <int RQ>
+__global__ __launch_bounds__(kThreads) void nn_search_warm_kernel(
+    const float* __restrict__ qry, int Nq, const float* __restrict__ tgt, int Nt, const double* __restrict__ Tq,
+    const double* __restrict__ Tt, int split_len, const int32_t* __restrict__ warm_idx,
+    unsigned long long* __restrict__ packed, const int32_t* __restrict__ skip) {
+  __shared__ __attribute__((aligned(16))) float lds[2][4][kTile];   // -2x, -2y, -2z, |t|^2 of the staged targets
+  __shared__ float tile_t2[2][kThreads / 64];                       // largest |t|^2 of a tile, per staging wave
+  if (skip && *skip) return;
+  const int tid = threadIdx.x;
+  const int split = blockIdx.y;
+
+  float qx[RQ], qy[RQ], qz[RQ], q2[RQ], best[RQ], thr[RQ];
+  int bidx[RQ];
+#pragma unroll
+  for (int r = 0; r < RQ; ++r) {
+    int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+    qi = qi < Nq ? qi : Nq - 1;  // clamp: out-of-range lanes compute a valid query, never store
+    double x, y, z;
+    xform64(Tq, qry[3 * (size_t)qi], qry[3 * (size_t)qi + 1], qry[3 * (size_t)qi + 2], x, y, z);
+    qx[r] = (float)x; qy[r] = (float)y; qz[r] = (float)z;
+    q2[r] = __builtin_fmaf(qz[r], qz[r], __builtin_fmaf(qy[r], qy[r], qx[r] * qx[r]));
+    best[r] = __builtin_inff();
+    bidx[r] = -1;
+    const int w = warm_idx[qi];
+    if (w >= 0 && w < Nt) {
+      double tx, ty, tz;
+      xform64(Tt, tgt[3 * (size_t)w], tgt[3 * (size_t)w + 1], tgt[3 * (size_t)w + 2], tx, ty, tz);
+      const float dx = qx[r] - (float)tx, dy = qy[r] - (float)ty, dz = qz[r] - (float)tz;
+      best[r] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      bidx[r] = w;
+    }
+  }
+
+  const int t0 = split * split_len;
+  const int t1 = min(Nt, t0 + split_len);
+  const int ntiles = (t1 - t0 + kTile - 1) / kTile;
+  constexpr float kU = 5.9604645e-8f;    // 2^-24
+
+  auto stage = [&](int tile, int buf) {
+    const int j = t0 + tile * kTile + tid;
+    float x = 0.f, y = 0.f, z = 0.f, t2 = 3.0e38f, t2m = 0.f;  // padding: score 3e38, above every threshold
+    if (j < t1) {
+      double dx, dy, dz;
+      xform64(Tt, tgt[3 * (size_t)j], tgt[3 * (size_t)j + 1], tgt[3 * (size_t)j + 2], dx, dy, dz);
+      x = (float)dx; y = (float)dy; z = (float)dz;
+      t2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+      t2m = t2;
+    }
+    lds[buf][0][tid] = -2.f * x;
+    lds[buf][1][tid] = -2.f * y;
+    lds[buf][2][tid] = -2.f * z;
+    lds[buf][3][tid] = t2;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t2m = fmaxf(t2m, __shfl_xor(t2m, o, 64));
+    if ((tid & 63) == 0) tile_t2[buf][tid >> 6] = t2m;
+  };
+  auto threshold = [&](int r, float t2max) {
+    return __builtin_fmaf(64.f * kU, q2[r] + t2max, __builtin_fmaf(best[r], 1.f + 8.f * kU, -q2[r]));
+  };
+
+  if (ntiles > 0) stage(0, 0);
+  __syncthreads();
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int buf = tile & 1;
+    if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
+    const int jbase = t0 + tile * kTile;
+    const float t2max = fmaxf(fmaxf(tile_t2[buf][0], tile_t2[buf][1]), fmaxf(tile_t2[buf][2], tile_t2[buf][3]));
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) thr[r] = threshold(r, t2max);
+#pragma unroll 2
+    for (int g = 0; g < kTile; g += kGroup) {
+      float tx[kGroup], ty[kGroup], tz[kGroup], tw[kGroup];
+#pragma unroll
+      for (int v = 0; v < kGroup; v += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(&lds[buf][0][g + v]);
+        const float4 c = *reinterpret_cast<const float4*>(&lds[buf][1][g + v]);
+        const float4 e = *reinterpret_cast<const float4*>(&lds[buf][2][g + v]);
+        const float4 w = *reinterpret_cast<const float4*>(&lds[buf][3][g + v]);
+        tx[v] = a.x; tx[v + 1] = a.y; tx[v + 2] = a.z; tx[v + 3] = a.w;
+        ty[v] = c.x; ty[v + 1] = c.y; ty[v + 2] = c.z; ty[v + 3] = c.w;
+        tz[v] = e.x; tz[v + 1] = e.y; tz[v + 2] = e.z; tz[v + 3] = e.w;
+        tw[v] = w.x; tw[v + 1] = w.y; tw[v + 2] = w.z; tw[v + 3] = w.w;
+      }
+#pragma unroll
+      for (int r = 0; r < RQ; ++r) {
+        float sc[kGroup];
+#pragma unroll
+        for (int v = 0; v < kGroup; ++v)
+          sc[v] = __builtin_fmaf(qx[r], tx[v], __builtin_fmaf(qy[r], ty[v], __builtin_fmaf(qz[r], tz[v], tw[v])));
+        const float m = fminf(fminf(fminf(sc[3], sc[4]), sc[5]),
+                              fminf(fminf(sc[6], sc[7]), fminf(fminf(sc[0], sc[1]), sc[2])));
+        if (__any(m <= thr[r])) {  // wave-uniform, rare: the bound is last pass's neighbour
+          const float th = thr[r];   // the group's candidates against ONE threshold: a lowered best only prunes more
+#pragma unroll
+          for (int v = 0; v < kGroup; ++v) {
+            if (__any(sc[v] <= th)) {           // wave-uniform per entry: typically one or two of the eight
+              // -0.5 * (-2 t) = t exactly: the differences are the cold kernel's
+              const float dx = qx[r] + 0.5f * tx[v], dy = qy[r] + 0.5f * ty[v], dz = qz[r] + 0.5f * tz[v];
+              const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+              const int j = jbase + g + v;
+              const bool up = (sc[v] <= th) & (sc[v] < 2.9e38f) & ((d2 < best[r]) | ((d2 == best[r]) & (j < bidx[r])));   // 3e38: padding
+              best[r] = up ? d2 : best[r];
+              bidx[r] = up ? j : bidx[r];
+            }
+          }
+          thr[r] = threshold(r, t2max);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < RQ; ++r) {
+    const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+    if (qi < Nq && bidx[r] >= 0)
+      atomicMin(&packed[qi], ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned int)bidx[r]);
+  }
+}
+
+
 #include "nn_grid.hpp"   // the two exact grid searches, their build kernels and workspace helpers
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -437,8 +571,8 @@ __global__ __launch_bounds__(kThreads) void icp_update_kernel(const double* __re
 // runs the update.  Two launches per ICP iteration, no partial arrays.
 __global__ __launch_bounds__(kThreads) void icp_finalize_update_kernel(
     const float* __restrict__ src, int Ns, const float* __restrict__ tgt, double radius,
-    unsigned long long* __restrict__ packed, double* __restrict__ part_sums, int max_iter, double rel_fitness,
-    double rel_rmse, double* __restrict__ T, IcpState* __restrict__ st, double* __restrict__ result) {
+    unsigned long long* __restrict__ packed, int32_t* __restrict__ prev_idx, double* __restrict__ part_sums, int max_iter,
+    double rel_fitness, double rel_rmse, double* __restrict__ T, IcpState* __restrict__ st, double* __restrict__ result) {
   __shared__ double red[kThreads / 64][kNV];
   __shared__ int last;
   if (st->done) return;
@@ -450,6 +584,7 @@ __global__ __launch_bounds__(kThreads) void icp_finalize_update_kernel(
   if (qi < Ns) {
     const unsigned long long pk = packed[qi];
     packed[qi] = ~0ull;
+    prev_idx[qi] = pk != ~0ull ? (int)(unsigned int)pk : -1;     // the next pass starts from this neighbour
     if (pk != ~0ull) {
       const int bi = (int)(unsigned int)pk;
       double q0, q1, q2;
@@ -663,7 +798,7 @@ extern "C" int isr_add_metric(const float* verts, int V, const double* Ta, const
 extern "C" size_t isr_icp_workspace_bytes(int Ns, int Nt) {
   if (Ns <= 0 || Nt <= 0) return 0;
   // includes the grid when the plan uses one; + the packed minima of the brute-force loop
-  return isr_nn_batched_workspace_bytes(Ns, Nt, 1) + isr::align_up((size_t)Ns * 8, 256) + 1024;
+  return isr_nn_batched_workspace_bytes(Ns, Nt, 1) + isr::align_up((size_t)Ns * 8, 256) + isr::align_up((size_t)Ns * 4, 256) + 1024;
 }
 
 extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt, int Nt, double threshold,
@@ -684,6 +819,9 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
   IcpState* st = w.take<IcpState>(1);
   const bool brute = !p.grid && !p.tile;
   unsigned long long* packed = brute ? w.take<unsigned long long>(Ns) : nullptr;
+  int32_t* prev_idx = brute ? w.take<int32_t>(Ns) : nullptr;
+  const char* warm_env = getenv("ISR_ICP_WARM");                   // tuning hook: 0 keeps every pass on the cold kernel
+  const bool warm = !(warm_env && warm_env[0] == '0');
   icp_init_kernel<<<brute ? (Ns + kThreads - 1) / kThreads : 1, kThreads, 0, stream>>>(st, T_io, packed, Ns);
   GridWs gw{};
   TileWs tw{};
@@ -701,14 +839,22 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
     if (brute) {
       // two launches per pass: search with one packed atomic min per (point, target split), then the
       // finalize whose last workgroup runs the update
-      if (p.rq == 4)
+      // (from the second pass on: the warm-started filter search, bounded by the previous pass's neighbour)
+      if (it > 0 && warm) {
+        if (p.rq == 4)
+          nn_search_warm_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, prev_idx,
+                                                                  packed, &st->done);
+        else
+          nn_search_warm_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, prev_idx,
+                                                                  packed, &st->done);
+      } else if (p.rq == 4)
         nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
                                                            nullptr, nullptr, &st->done, nullptr, packed);
       else
         nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
                                                            nullptr, nullptr, &st->done, nullptr, packed);
-      icp_finalize_update_kernel<<<p.fblocks, kThreads, 0, stream>>>(src, Ns, tgt, threshold, packed, part_sums, max_iter,
-                                                                     rel_fitness, rel_rmse, T_io, st, result);
+      icp_finalize_update_kernel<<<p.fblocks, kThreads, 0, stream>>>(src, Ns, tgt, threshold, packed, prev_idx, part_sums,
+                                                                     max_iter, rel_fitness, rel_rmse, T_io, st, result);
       continue;
     }
     if (p.tile) {
