@@ -46,15 +46,34 @@ __device__ __forceinline__ void xform64(const double* __restrict__ T, float x, f
 
 constexpr int kUnresolved = -2;   // part_idx of a query the grid search handed to the brute-force pass
 
+// FILTER = false: the plain loop — per pair the difference form d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)) (6 VALU ops), a min3
+// tree per group of 8 targets, the (value, index) update in a wave-uniform slow path.
+// FILTER = true: the search runs on the 3-FMA form  s = |t|^2 - 2 q.t  (= d2 - |q|^2 up to rounding: half the VALU work of the
+// difference form) as a FILTER; the difference form d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)) — the arithmetic that
+// defines the result — is evaluated only for targets whose s could beat or tie the lane's best:
+//   s <= best - |q|^2 + E,   E >= |s + |q|^2 - d2|.
+// With u = 2^-24: the three fmas of s and the three of |t|^2 err by <= 6u (|q| + |t|)^2, |q|^2 by 3u |q|^2, d2 by
+// 5u d2 <= 5u (|q| + |t|)^2 — together <= 14u (|q| + |t|)^2 <= 28u (|q|^2 + |t|^2); E = 64u (|q|^2 + max |t|^2 of
+// the tile) + 8u best also covers the roundings of the threshold itself.  A group of 8 targets costs 24 fma + a
+// min3 tree; when some lane's smallest s passes its threshold (wave-uniform), each of the 8 entries that passes on
+// some lane (wave-uniform again: typically one or two) is evaluated exactly.  The winner is the lexicographic
+// minimum of (d2, index), i.e. strict '<' in ascending index order: both loops return the same winners.  The
+// filter pays when a lane's running minimum has settled — target ranges of several tiles (batches: 7.2 vs 6.0
+// Tpairs/s on 32 x 20 000^2), or a warm start; on a one-tile range (one batch item split 79 ways) the minima are
+// young, most groups pass the filter, and the plain loop is 25 % faster (tools/time_nn.py).
+// warm != nullptr (ICP passes after the first): the lane starts from last pass's neighbour — its distance under
+// the new T is an upper bound that is almost always the answer, so almost nothing passes the filter.
 // unresolved != nullptr: second pass behind nn_grid_search_kernel (nsplit must be 1) — only blocks
 // that hold a query marked kUnresolved run, and only those queries are stored.
-template <int RQ>
+template <int RQ, bool FILTER>
 __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     const float* __restrict__ qry, int Nq, const float* __restrict__ tgt, int Nt,
     const double* __restrict__ Tq, const double* __restrict__ Tt, int split_len, int nsplit,
     float* __restrict__ part_d2, int32_t* __restrict__ part_idx, const int32_t* __restrict__ skip,
-    const int32_t* __restrict__ unresolved, unsigned long long* __restrict__ packed = nullptr) {
-  __shared__ __attribute__((aligned(16))) float lds[2][3][kTile];
+    const int32_t* __restrict__ unresolved, unsigned long long* __restrict__ packed = nullptr,
+    const int32_t* __restrict__ warm = nullptr) {
+  __shared__ __attribute__((aligned(16))) float lds[2][FILTER ? 4 : 3][kTile];   // FILTER: -2x, -2y, -2z, |t|^2; else x, y, z
+  __shared__ float tile_t2[2][kThreads / 64];                       // largest |t|^2 of a tile, per staging wave
   if (skip && *skip) return;  // device-side ICP loop: converged, later iterations are no-ops
   if (unresolved && *unresolved == 0) return;
 
@@ -73,7 +92,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
   const double* tq = Tq ? Tq + 12 * (size_t)b : nullptr;
   const double* tt = Tt ? Tt + 12 * (size_t)b : nullptr;
 
-  float qx[RQ], qy[RQ], qz[RQ], best[RQ];
+  float qx[RQ], qy[RQ], qz[RQ], q2[RQ], best[RQ], thr[RQ];
   int bidx[RQ];
 #pragma unroll
   for (int r = 0; r < RQ; ++r) {
@@ -82,25 +101,56 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     double x, y, z;
     xform64(tq, qry[3 * (size_t)qi], qry[3 * (size_t)qi + 1], qry[3 * (size_t)qi + 2], x, y, z);
     qx[r] = (float)x; qy[r] = (float)y; qz[r] = (float)z;
+    q2[r] = __builtin_fmaf(qz[r], qz[r], __builtin_fmaf(qy[r], qy[r], qx[r] * qx[r]));
     best[r] = __builtin_inff();
     bidx[r] = -1;
+    const int w = warm ? warm[(size_t)b * Nq + qi] : -1;
+    if (w >= 0 && w < Nt) {
+      double tx, ty, tz;
+      xform64(tt, tgt[3 * (size_t)w], tgt[3 * (size_t)w + 1], tgt[3 * (size_t)w + 2], tx, ty, tz);
+      const float dx = qx[r] - (float)tx, dy = qy[r] - (float)ty, dz = qz[r] - (float)tz;
+      best[r] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+      bidx[r] = w;
+    }
   }
 
   const int t0 = split * split_len;
   const int t1 = min(Nt, t0 + split_len);
   const int ntiles = (t1 - t0 + kTile - 1) / kTile;
+  constexpr float kU = 5.9604645e-8f;    // 2^-24
 
   auto stage = [&](int tile, int buf) {
     const int j = t0 + tile * kTile + tid;
-    float x = 3.0e38f, y = 3.0e38f, z = 3.0e38f;  // padding: d2 = +inf, never wins
+    if (!FILTER) {
+      float x = 3.0e38f, y = 3.0e38f, z = 3.0e38f;  // padding: d2 = +inf, never wins
+      if (j < t1) {
+        double dx, dy, dz;
+        xform64(tt, tgt[3 * (size_t)j], tgt[3 * (size_t)j + 1], tgt[3 * (size_t)j + 2], dx, dy, dz);
+        x = (float)dx; y = (float)dy; z = (float)dz;
+      }
+      lds[buf][0][tid] = x;
+      lds[buf][1][tid] = y;
+      lds[buf][2][tid] = z;
+      return;
+    }
+    float x = 0.f, y = 0.f, z = 0.f, t2 = 3.0e38f, t2m = 0.f;  // padding: score 3e38, never evaluated
     if (j < t1) {
       double dx, dy, dz;
       xform64(tt, tgt[3 * (size_t)j], tgt[3 * (size_t)j + 1], tgt[3 * (size_t)j + 2], dx, dy, dz);
       x = (float)dx; y = (float)dy; z = (float)dz;
+      t2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
+      t2m = t2;
     }
-    lds[buf][0][tid] = x;
-    lds[buf][1][tid] = y;
-    lds[buf][2][tid] = z;
+    lds[buf][0][tid] = -2.f * x;
+    lds[buf][1][tid] = -2.f * y;
+    lds[buf][2][tid] = -2.f * z;
+    lds[buf][FILTER ? 3 : 0][tid] = t2;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) t2m = fmaxf(t2m, __shfl_xor(t2m, o, 64));
+    if ((tid & 63) == 0) tile_t2[buf][tid >> 6] = t2m;
+  };
+  auto threshold = [&](int r, float t2max) {
+    return __builtin_fmaf(64.f * kU, q2[r] + t2max, __builtin_fmaf(best[r], 1.f + 8.f * kU, -q2[r]));
   };
 
   if (ntiles > 0) stage(0, 0);
@@ -109,36 +159,85 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     const int buf = tile & 1;
     if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
     const int jbase = t0 + tile * kTile;
+    if (!FILTER) {
+#pragma unroll 2
+      for (int g = 0; g < kTile; g += kGroup) {
+        float tx[kGroup], ty[kGroup], tz[kGroup];
+#pragma unroll
+        for (int v = 0; v < kGroup; v += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(&lds[buf][0][g + v]);
+          const float4 c = *reinterpret_cast<const float4*>(&lds[buf][1][g + v]);
+          const float4 e = *reinterpret_cast<const float4*>(&lds[buf][2][g + v]);
+          tx[v] = a.x; tx[v + 1] = a.y; tx[v + 2] = a.z; tx[v + 3] = a.w;
+          ty[v] = c.x; ty[v + 1] = c.y; ty[v + 2] = c.z; ty[v + 3] = c.w;
+          tz[v] = e.x; tz[v + 1] = e.y; tz[v + 2] = e.z; tz[v + 3] = e.w;
+        }
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {
+          float d[kGroup];
+#pragma unroll
+          for (int v = 0; v < kGroup; ++v) {
+            const float dx = qx[r] - tx[v], dy = qy[r] - ty[v], dz = qz[r] - tz[v];
+            d[v] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          }
+          // three v_min3 + one v_min (min-type ops issue at 0.6x the add rate: keep them few)
+          const float m = fminf(fminf(fminf(d[3], d[4]), d[5]),
+                                fminf(fminf(d[6], d[7]), fminf(fminf(d[0], d[1]), d[2])));
+          if (__any(m < best[r])) {  // wave-uniform
+#pragma unroll
+            for (int v = 0; v < kGroup; ++v) {
+              const bool up = d[v] < best[r];
+              best[r] = up ? d[v] : best[r];
+              bidx[r] = up ? (jbase + g + v) : bidx[r];
+            }
+          }
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    const float t2max = fmaxf(fmaxf(tile_t2[buf][0], tile_t2[buf][1]), fmaxf(tile_t2[buf][2], tile_t2[buf][3]));
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) thr[r] = threshold(r, t2max);
 #pragma unroll 2
     for (int g = 0; g < kTile; g += kGroup) {
-      float tx[kGroup], ty[kGroup], tz[kGroup];
+      float tx[kGroup], ty[kGroup], tz[kGroup], tw[kGroup];
 #pragma unroll
       for (int v = 0; v < kGroup; v += 4) {
         const float4 a = *reinterpret_cast<const float4*>(&lds[buf][0][g + v]);
         const float4 c = *reinterpret_cast<const float4*>(&lds[buf][1][g + v]);
         const float4 e = *reinterpret_cast<const float4*>(&lds[buf][2][g + v]);
+        const float4 w = *reinterpret_cast<const float4*>(&lds[buf][FILTER ? 3 : 0][g + v]);
         tx[v] = a.x; tx[v + 1] = a.y; tx[v + 2] = a.z; tx[v + 3] = a.w;
         ty[v] = c.x; ty[v + 1] = c.y; ty[v + 2] = c.z; ty[v + 3] = c.w;
         tz[v] = e.x; tz[v + 1] = e.y; tz[v + 2] = e.z; tz[v + 3] = e.w;
+        tw[v] = w.x; tw[v + 1] = w.y; tw[v + 2] = w.z; tw[v + 3] = w.w;
       }
 #pragma unroll
       for (int r = 0; r < RQ; ++r) {
-        float d[kGroup];
+        float sc[kGroup];
 #pragma unroll
-        for (int v = 0; v < kGroup; ++v) {
-          const float dx = qx[r] - tx[v], dy = qy[r] - ty[v], dz = qz[r] - tz[v];
-          d[v] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        }
+        for (int v = 0; v < kGroup; ++v)
+          sc[v] = __builtin_fmaf(qx[r], tx[v], __builtin_fmaf(qy[r], ty[v], __builtin_fmaf(qz[r], tz[v], tw[v])));
         // three v_min3 + one v_min (min-type ops issue at 0.6x the add rate: keep them few)
-        const float m = fminf(fminf(fminf(d[3], d[4]), d[5]),
-                              fminf(fminf(d[6], d[7]), fminf(fminf(d[0], d[1]), d[2])));
-        if (__any(m < best[r])) {  // wave-uniform: rare after the first few tiles
+        const float m = fminf(fminf(fminf(sc[3], sc[4]), sc[5]),
+                              fminf(fminf(sc[6], sc[7]), fminf(fminf(sc[0], sc[1]), sc[2])));
+        if (__any(m <= thr[r])) {  // wave-uniform
+          const float th = thr[r];   // the group's candidates against ONE threshold: a lowered best only prunes more
 #pragma unroll
           for (int v = 0; v < kGroup; ++v) {
-            const bool up = d[v] < best[r];
-            best[r] = up ? d[v] : best[r];
-            bidx[r] = up ? (jbase + g + v) : bidx[r];
+            if (__any(sc[v] <= th)) {           // wave-uniform per entry: typically one or two of the eight
+              // -0.5 * (-2 t) = t exactly: the same differences as dx = qx - tx
+              const float dx = qx[r] + 0.5f * tx[v], dy = qy[r] + 0.5f * ty[v], dz = qz[r] + 0.5f * tz[v];
+              const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+              const int j = jbase + g + v;
+              const bool up = (sc[v] <= th) & (sc[v] < 2.9e38f) &            // 3e38: padding
+                              ((d2 < best[r]) | ((d2 == best[r]) & (j < bidx[r])));
+              best[r] = up ? d2 : best[r];
+              bidx[r] = up ? j : bidx[r];
+            }
           }
+          thr[r] = threshold(r, t2max);
         }
       }
     }
@@ -165,140 +264,6 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     }
   }
 }
-
-// ------------------------------------------------------------------ warm-started search (ICP passes 1..)
-// From the second ICP pass on every source point knows last pass's neighbour; its distance under the new T is
-// an upper bound that is almost always the answer.  With the running minimum that tight, the search can run on
-// the 3-FMA form  s = |t|^2 - 2 q.t  (= d2 - |q|^2 up to rounding: half the VALU work of the difference form)
-// as a FILTER: a group of 8 targets is looked at in the difference form — the arithmetic that defines the
-// result — only when some lane's smallest s could belong to a target that beats or ties its best:
-//   s <= best - |q|^2 + E,   E >= |s + |q|^2 - d2|.
-// With u = 2^-24: the three fmas of s and the three of |t|^2 err by <= 6u (|q| + |t|)^2, |q|^2 by 3u |q|^2, d2 by
-// 5u d2 <= 5u (|q| + |t|)^2 — together <= 14u (|q| + |t|)^2 <= 28u (|q|^2 + |t|^2); E = 64u (|q|^2 + max |t|^2 of
-// the tile) + 8u best also covers the roundings of the threshold itself.  The winner is the lexicographic
-// minimum of (d2, index) — what the cold kernel's strict '<' in ascending index order produces — so the loop's
-// results do not depend on which kernel ran a pass.  (Cold, the filter loses: with 64 queries per wave some lane
-// sets a new record in ~45 % of the groups of a 3 300-target split and the verification costs more than the
-// cheap form saves; tools/time_icp.py.)
-template <int RQ>
-__global__ __launch_bounds__(kThreads) void nn_search_warm_kernel(
-    const float* __restrict__ qry, int Nq, const float* __restrict__ tgt, int Nt, const double* __restrict__ Tq,
-    const double* __restrict__ Tt, int split_len, const int32_t* __restrict__ warm_idx,
-    unsigned long long* __restrict__ packed, const int32_t* __restrict__ skip) {
-  __shared__ __attribute__((aligned(16))) float lds[2][4][kTile];   // -2x, -2y, -2z, |t|^2 of the staged targets
-  __shared__ float tile_t2[2][kThreads / 64];                       // largest |t|^2 of a tile, per staging wave
-  if (skip && *skip) return;
-  const int tid = threadIdx.x;
-  const int split = blockIdx.y;
-
-  float qx[RQ], qy[RQ], qz[RQ], q2[RQ], best[RQ], thr[RQ];
-  int bidx[RQ];
-#pragma unroll
-  for (int r = 0; r < RQ; ++r) {
-    int qi = (blockIdx.x * RQ + r) * kThreads + tid;
-    qi = qi < Nq ? qi : Nq - 1;  // clamp: out-of-range lanes compute a valid query, never store
-    double x, y, z;
-    xform64(Tq, qry[3 * (size_t)qi], qry[3 * (size_t)qi + 1], qry[3 * (size_t)qi + 2], x, y, z);
-    qx[r] = (float)x; qy[r] = (float)y; qz[r] = (float)z;
-    q2[r] = __builtin_fmaf(qz[r], qz[r], __builtin_fmaf(qy[r], qy[r], qx[r] * qx[r]));
-    best[r] = __builtin_inff();
-    bidx[r] = -1;
-    const int w = warm_idx[qi];
-    if (w >= 0 && w < Nt) {
-      double tx, ty, tz;
-      xform64(Tt, tgt[3 * (size_t)w], tgt[3 * (size_t)w + 1], tgt[3 * (size_t)w + 2], tx, ty, tz);
-      const float dx = qx[r] - (float)tx, dy = qy[r] - (float)ty, dz = qz[r] - (float)tz;
-      best[r] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-      bidx[r] = w;
-    }
-  }
-
-  const int t0 = split * split_len;
-  const int t1 = min(Nt, t0 + split_len);
-  const int ntiles = (t1 - t0 + kTile - 1) / kTile;
-  constexpr float kU = 5.9604645e-8f;    // 2^-24
-
-  auto stage = [&](int tile, int buf) {
-    const int j = t0 + tile * kTile + tid;
-    float x = 0.f, y = 0.f, z = 0.f, t2 = 3.0e38f, t2m = 0.f;  // padding: score 3e38, above every threshold
-    if (j < t1) {
-      double dx, dy, dz;
-      xform64(Tt, tgt[3 * (size_t)j], tgt[3 * (size_t)j + 1], tgt[3 * (size_t)j + 2], dx, dy, dz);
-      x = (float)dx; y = (float)dy; z = (float)dz;
-      t2 = __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x));
-      t2m = t2;
-    }
-    lds[buf][0][tid] = -2.f * x;
-    lds[buf][1][tid] = -2.f * y;
-    lds[buf][2][tid] = -2.f * z;
-    lds[buf][3][tid] = t2;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) t2m = fmaxf(t2m, __shfl_xor(t2m, o, 64));
-    if ((tid & 63) == 0) tile_t2[buf][tid >> 6] = t2m;
-  };
-  auto threshold = [&](int r, float t2max) {
-    return __builtin_fmaf(64.f * kU, q2[r] + t2max, __builtin_fmaf(best[r], 1.f + 8.f * kU, -q2[r]));
-  };
-
-  if (ntiles > 0) stage(0, 0);
-  __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int buf = tile & 1;
-    if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
-    const int jbase = t0 + tile * kTile;
-    const float t2max = fmaxf(fmaxf(tile_t2[buf][0], tile_t2[buf][1]), fmaxf(tile_t2[buf][2], tile_t2[buf][3]));
-#pragma unroll
-    for (int r = 0; r < RQ; ++r) thr[r] = threshold(r, t2max);
-#pragma unroll 2
-    for (int g = 0; g < kTile; g += kGroup) {
-      float tx[kGroup], ty[kGroup], tz[kGroup], tw[kGroup];
-#pragma unroll
-      for (int v = 0; v < kGroup; v += 4) {
-        const float4 a = *reinterpret_cast<const float4*>(&lds[buf][0][g + v]);
-        const float4 c = *reinterpret_cast<const float4*>(&lds[buf][1][g + v]);
-        const float4 e = *reinterpret_cast<const float4*>(&lds[buf][2][g + v]);
-        const float4 w = *reinterpret_cast<const float4*>(&lds[buf][3][g + v]);
-        tx[v] = a.x; tx[v + 1] = a.y; tx[v + 2] = a.z; tx[v + 3] = a.w;
-        ty[v] = c.x; ty[v + 1] = c.y; ty[v + 2] = c.z; ty[v + 3] = c.w;
-        tz[v] = e.x; tz[v + 1] = e.y; tz[v + 2] = e.z; tz[v + 3] = e.w;
-        tw[v] = w.x; tw[v + 1] = w.y; tw[v + 2] = w.z; tw[v + 3] = w.w;
-      }
-#pragma unroll
-      for (int r = 0; r < RQ; ++r) {
-        float sc[kGroup];
-#pragma unroll
-        for (int v = 0; v < kGroup; ++v)
-          sc[v] = __builtin_fmaf(qx[r], tx[v], __builtin_fmaf(qy[r], ty[v], __builtin_fmaf(qz[r], tz[v], tw[v])));
-        const float m = fminf(fminf(fminf(sc[3], sc[4]), sc[5]),
-                              fminf(fminf(sc[6], sc[7]), fminf(fminf(sc[0], sc[1]), sc[2])));
-        if (__any(m <= thr[r])) {  // wave-uniform, rare: the bound is last pass's neighbour
-          const float th = thr[r];   // the group's candidates against ONE threshold: a lowered best only prunes more
-#pragma unroll
-          for (int v = 0; v < kGroup; ++v) {
-            if (__any(sc[v] <= th)) {           // wave-uniform per entry: typically one or two of the eight
-              // -0.5 * (-2 t) = t exactly: the differences are the cold kernel's
-              const float dx = qx[r] + 0.5f * tx[v], dy = qy[r] + 0.5f * ty[v], dz = qz[r] + 0.5f * tz[v];
-              const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-              const int j = jbase + g + v;
-              const bool up = (sc[v] <= th) & (sc[v] < 2.9e38f) & ((d2 < best[r]) | ((d2 == best[r]) & (j < bidx[r])));   // 3e38: padding
-              best[r] = up ? d2 : best[r];
-              bidx[r] = up ? j : bidx[r];
-            }
-          }
-          thr[r] = threshold(r, t2max);
-        }
-      }
-    }
-    __syncthreads();
-  }
-#pragma unroll
-  for (int r = 0; r < RQ; ++r) {
-    const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
-    if (qi < Nq && bidx[r] >= 0)
-      atomicMin(&packed[qi], ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned int)bidx[r]);
-  }
-}
-
 
 #include "nn_grid.hpp"   // the two exact grid searches, their build kernels and workspace helpers
 
@@ -696,6 +661,24 @@ NNPlan make_plan(int Nq, int Nt, int B) {
   return p;
 }
 
+// the brute-force search of a plan: plain loop or filter loop (nn_search_kernel) — the filter needs settled minima,
+// i.e. a warm start or a target range of several tiles per workgroup
+constexpr int kFilterMinTiles = 4;
+void launch_search(const NNPlan& p, const dim3& grid, hipStream_t stream, const float* qry, int Nq, const float* tgt, int Nt,
+                   const double* tq, const double* tt, float* part_d2, int32_t* part_idx, const int32_t* skip,
+                   const int32_t* unresolved, unsigned long long* packed, const int32_t* warm) {
+  bool filter = warm != nullptr || p.split_len >= kFilterMinTiles * kTile;
+  // tuning hook (experiments only) for cold searches; a warm start always takes the filter loop (its tie rule —
+  // equal distance, lower index — is what makes a warm-started lane return the cold winner)
+  if (const char* e = getenv("ISR_NN_FILTER")) { if (e[0] && !warm) filter = e[0] == '1'; }
+#define ISR_SEARCH(RQv, Fv)                                                                                              \
+  nn_search_kernel<RQv, Fv><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len, p.nsplit, part_d2, part_idx, \
+                                                           skip, unresolved, packed, warm)
+  if (p.rq == 4) { if (filter) ISR_SEARCH(4, true); else ISR_SEARCH(4, false); }
+  else { if (filter) ISR_SEARCH(1, true); else ISR_SEARCH(1, false); }
+#undef ISR_SEARCH
+}
+
 }  // namespace
 
 extern "C" size_t isr_nn_batched_workspace_bytes(int Nq, int Nt, int B) {
@@ -759,12 +742,8 @@ extern "C" int isr_nn_batched(const float* qry, int Nq, const float* tgt, int Nt
     }
     if (p.tile)
       launch_tile_search(tw, Nq, Nt, tq, tt, nb, stop_radius, part_d2, part_idx, nullptr, stream);
-    else if (p.rq == 4)
-      nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len,
-                                                         p.nsplit, part_d2, part_idx, nullptr, unres);
     else
-      nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len,
-                                                         p.nsplit, part_d2, part_idx, nullptr, unres);
+      launch_search(p, grid, stream, qry, Nq, tgt, Nt, tq, tt, part_d2, part_idx, nullptr, unres, nullptr, nullptr);
     ISR_CHECK_LAUNCH("nn_search_kernel");
     const dim3 fgrid(p.fblocks, nb);
     if (cov)
@@ -840,19 +819,8 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
       // two launches per pass: search with one packed atomic min per (point, target split), then the
       // finalize whose last workgroup runs the update
       // (from the second pass on: the warm-started filter search, bounded by the previous pass's neighbour)
-      if (it > 0 && warm) {
-        if (p.rq == 4)
-          nn_search_warm_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, prev_idx,
-                                                                  packed, &st->done);
-        else
-          nn_search_warm_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, prev_idx,
-                                                                  packed, &st->done);
-      } else if (p.rq == 4)
-        nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
-                                                           nullptr, nullptr, &st->done, nullptr, packed);
-      else
-        nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
-                                                           nullptr, nullptr, &st->done, nullptr, packed);
+      const int32_t* w_idx = (it > 0 && warm) ? prev_idx : nullptr;
+      launch_search(p, grid, stream, src, Ns, tgt, Nt, T_io, nullptr, nullptr, nullptr, &st->done, nullptr, packed, w_idx);
       icp_finalize_update_kernel<<<p.fblocks, kThreads, 0, stream>>>(src, Ns, tgt, threshold, packed, prev_idx, part_sums,
                                                                      max_iter, rel_fitness, rel_rmse, T_io, st, result);
       continue;
@@ -865,12 +833,8 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
       nn_grid_search_kernel<<<dim3(p.fblocks, 1), kThreads, 0, stream>>>(src, Ns, gw.desc, gw.start, gw.sorted, T_io,
                                                                          nullptr, stop_radius, part_d2, part_idx,
                                                                          gw.unresolved, &st->done);
-      if (p.rq == 4)
-        nn_search_kernel<4><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
-                                                           part_d2, part_idx, &st->done, gw.unresolved);
-      else
-        nn_search_kernel<1><<<grid, kThreads, 0, stream>>>(src, Ns, tgt, Nt, T_io, nullptr, p.split_len, p.nsplit,
-                                                           part_d2, part_idx, &st->done, gw.unresolved);
+      launch_search(p, grid, stream, src, Ns, tgt, Nt, T_io, nullptr, part_d2, part_idx, &st->done, gw.unresolved, nullptr,
+                    nullptr);
     }
     nn_finalize_kernel<true><<<fgrid, kThreads, 0, stream>>>(src, Ns, tgt, T_io, nullptr, p.nsplit, threshold, part_d2,
                                                              part_idx, 0, nullptr, nullptr, part_sums, &st->done);
