@@ -339,6 +339,25 @@ __global__ __launch_bounds__(TB, 8) void nn_tile_search_kernel(
     // stream the candidates listed in run_start / run_pref (n_runs runs, C points) against the lanes
     auto scan_runs = [&](int n_runs, int C) {
       constexpr int CPT = kTile / TB;                        // candidates staged per thread and tile
+      // the NEXT tile's candidates are fetched (run lookup + one global load each) before the current tile is
+      // scanned and transformed after it: their latency hides behind the scan instead of in front of it
+      float4 raw[CPT];
+      auto issue = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+          const int p = t0 + tid + u * TB;
+          raw[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p < C) {
+            int lo = 0, hi = n_runs;                         // last run with run_pref[r] <= p
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              if (run_pref[mid] <= p) lo = mid; else hi = mid;
+            }
+            raw[u] = sorted[run_start[lo] + (p - run_pref[lo])];
+          }
+        }
+      };
+      issue(0);
       for (int t0 = 0; t0 < C; t0 += kTile) {
         float cx[CPT], cy[CPT], cz[CPT];
         int ci[CPT];
@@ -348,16 +367,10 @@ __global__ __launch_bounds__(TB, 8) void nn_tile_search_kernel(
           cx[u] = big; cy[u] = big; cz[u] = big;             // padding: d2 = +inf
           ci[u] = 0x7fffffff;
           if (p < C) {
-            int lo = 0, hi = n_runs;                         // last run with run_pref[r] <= p
-            while (hi - lo > 1) {
-              const int mid = (lo + hi) >> 1;
-              if (run_pref[mid] <= p) lo = mid; else hi = mid;
-            }
-            const float4 c = sorted[run_start[lo] + (p - run_pref[lo])];
             double tx, ty, tz;
-            xform64(tt, c.x, c.y, c.z, tx, ty, tz);
+            xform64(tt, raw[u].x, raw[u].y, raw[u].z, tx, ty, tz);
             cx[u] = (float)tx; cy[u] = (float)ty; cz[u] = (float)tz;
-            ci[u] = __float_as_int(c.w);
+            ci[u] = __float_as_int(raw[u].w);
           }
         }
         __syncthreads();                                     // previous tile fully consumed
@@ -367,6 +380,7 @@ __global__ __launch_bounds__(TB, 8) void nn_tile_search_kernel(
           tile[0][q] = cx[u]; tile[1][q] = cy[u]; tile[2][q] = cz[u]; tidx[q] = ci[u];
         }
         __syncthreads();
+        if (t0 + kTile < C) issue(t0 + kTile);
         const int nvalid = min(kTile, C - t0);
         for (int g0 = 0; g0 < nvalid; g0 += kGroup) {
           float tx[kGroup], ty[kGroup], tz[kGroup];
