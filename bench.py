@@ -199,7 +199,7 @@ def cpu_baseline(args, keys_bf16, pts, Q0, pix0, Kcam, upper, lower, cad, R_gt, 
 
 
 def measure_nn(pts, dev, pairs=32):
-    """K3 brute force (nn_search_kernel, ISR_NN_GRID=0) on `pairs` Chamfer-pair items of N x N points with
+    """K3 brute force (nn_search_kernel, ISR_TUNE_NN_PATH = 0) on `pairs` Chamfer-pair items of N x N points with
     unrelated orientations, timed with HIP events on the launch stream.  Three figures:
     the VALU fraction under the 8-FLOP/pair convention, the algorithmic bytes against HBM, and — from
     the committed PMC run, when there is one for this shape — the counter HBM bytes."""
@@ -209,9 +209,7 @@ def measure_nn(pts, dev, pairs=32):
     Rb, tb = synth.random_poses(rng, pairs)
     Tq = torch.from_numpy(np.concatenate([Ra, np.zeros((pairs, 3, 1))], 2)).to(dev)
     Tt = torch.from_numpy(np.concatenate([Rb, np.zeros((pairs, 3, 1))], 2)).to(dev)
-    old = os.environ.get("ISR_NN_GRID")
-    os.environ["ISR_NN_GRID"] = "0"
-    try:
+    with ops.tuning(nn_path=0):          # explicit knob, no environment access (no other thread is running here)
         ops.nn_batched(pts, pts, Tq, Tt)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
@@ -220,11 +218,6 @@ def measure_nn(pts, dev, pairs=32):
             ops.nn_batched(pts, pts, Tq, Tt)
         e1.record()
         torch.cuda.synchronize()
-    finally:
-        if old is None:
-            os.environ.pop("ISR_NN_GRID", None)
-        else:
-            os.environ["ISR_NN_GRID"] = old
     sec = e0.elapsed_time(e1) * 1e-3 / 3
     n_pairs = float(pairs) * N * N
     alg_bytes = 12.0 * N + 12.0 * N + 96.0 * pairs + 8.0 * N * pairs

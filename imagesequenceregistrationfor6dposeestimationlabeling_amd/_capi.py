@@ -18,9 +18,13 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ISR_HIP_LIB"]) if os.environ.get("ISR_HIP_LIB") else _PKG / "libisr_hip.so"
 
 ISR_OK = 0
+ABI_VERSION = 3
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
 DTYPE_BF16_LOG2 = 2
+# ISR_TUNE_* knobs of include/isr_hip.h
+TUNE = {"nn_path": 0, "nn_filter": 1, "icp_warm": 2, "nn_plan_rq": 3, "nn_plan_blocks": 4,
+        "nn_tile_st": 5, "nn_tile_sq": 6, "nn_tile_tb": 7}
 
 
 class IsrError(RuntimeError):
@@ -42,6 +46,8 @@ SIGNATURES = {
     "isr_abi_version": (_i, []),
     "isr_last_error": (C.c_char_p, []),
     "isr_device_count": (_i, []),
+    "isr_tuning_set": (_i, [_i, _i]),
+    "isr_tuning_get": (_i, [_i]),
     "isr_corr_argmax_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "isr_corr_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_corr_argmax_recheck_count": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
@@ -56,7 +62,7 @@ SIGNATURES = {
     "isr_select_top_batch": (_i, [_vp, _i, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "isr_pnp_ransac_batch_workspace_bytes": (_sz, [_i, _i, _i]),
-    "isr_pnp_ransac_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_pnp_ransac_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_prep_queries_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_prep_queries": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
@@ -65,7 +71,7 @@ SIGNATURES = {
     "isr_p3p_hypotheses": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp]),
     "isr_ransac_score": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_pnp_refine": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
-    "isr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _f, _d, _i, _vp, _vp, _vp, _vp, _vp,
+    "isr_pnp_ransac": (_i, [_vp, _vp, _vp, _i, _vp, _i, _u64, _f, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp,
                             _sz, _vp]),
     "isr_nn_batched_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_nn_batched": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -109,8 +115,8 @@ def lib() -> C.CDLL:
             raise IsrError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if L.isr_abi_version() != 2:
-        raise IsrError(f"ABI version {L.isr_abi_version()} != 2")
+    if L.isr_abi_version() != ABI_VERSION:
+        raise IsrError(f"ABI version {L.isr_abi_version()} != {ABI_VERSION}")
     _lib = L
     return L
 

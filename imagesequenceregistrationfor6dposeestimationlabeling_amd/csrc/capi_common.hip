@@ -1,6 +1,8 @@
 // capi_common.hip — error text, version, device probe, and the relative-pose table kernel.
 #include "isr_common.hpp"
 
+#include <atomic>
+#include <cstdlib>
 #include <cstring>
 
 namespace isr {
@@ -17,7 +19,58 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+namespace {
+
+struct Tuning {
+  std::atomic<int> v[ISR_TUNE_COUNT];
+  Tuning() {
+    const int defaults[ISR_TUNE_COUNT] = {-1, -1, 1, 0, 0, 0, 0, 0};
+    for (int i = 0; i < ISR_TUNE_COUNT; ++i) v[i].store(defaults[i], std::memory_order_relaxed);
+    // the environment is consulted here and nowhere else: once, before any entry point can run
+    if (const char* e = getenv("ISR_NN_GRID")) { if (e[0] >= '0' && e[0] <= '2') v[ISR_TUNE_NN_PATH] = e[0] - '0'; }
+    if (const char* e = getenv("ISR_NN_FILTER")) { if (e[0] == '0' || e[0] == '1') v[ISR_TUNE_NN_FILTER] = e[0] - '0'; }
+    if (const char* e = getenv("ISR_ICP_WARM")) { if (e[0] == '0') v[ISR_TUNE_ICP_WARM] = 0; }
+    if (const char* e = getenv("ISR_NN_PLAN")) {
+      int rq = 0; long want = 0;
+      if (sscanf(e, "%d,%ld", &rq, &want) >= 1) {
+        if (rq == 1 || rq == 4) v[ISR_TUNE_NN_PLAN_RQ] = rq;
+        if (want > 0) v[ISR_TUNE_NN_PLAN_BLOCKS] = (int)want;
+      }
+    }
+    if (const char* e = getenv("ISR_NN_TILE")) {
+      double st = 0, sq = 0; int tb = 0;
+      (void)sscanf(e, "%lf,%lf,%d", &st, &sq, &tb);
+      if (st > 0) v[ISR_TUNE_NN_TILE_ST] = (int)(st * 1000.0 + 0.5);
+      if (sq > 0) v[ISR_TUNE_NN_TILE_SQ] = (int)(sq * 1000.0 + 0.5);
+      if (tb > 0) v[ISR_TUNE_NN_TILE_TB] = tb;
+    }
+  }
+};
+
+Tuning& tuning_state() {
+  static Tuning t;      // constructed once (thread-safe), at the first knob access
+  return t;
+}
+
+// touch the state when the library is loaded, so the environment is read before any thread can change it
+const int tuning_loaded = (tuning_state(), 0);
+
+}  // namespace
+
+int tuning(int knob) { return tuning_state().v[knob].load(std::memory_order_relaxed); }
+
 }  // namespace isr
+
+extern "C" int isr_tuning_set(int knob, int value) {
+  ISR_REQUIRE(knob >= 0 && knob < ISR_TUNE_COUNT, "isr_tuning_set: unknown knob %d", knob);
+  isr::tuning_state().v[knob].store(value, std::memory_order_relaxed);
+  return ISR_OK;
+}
+
+extern "C" int isr_tuning_get(int knob) {
+  if (knob < 0 || knob >= ISR_TUNE_COUNT) return 0;
+  return isr::tuning(knob);
+}
 
 extern "C" int isr_abi_version(void) { return ISR_ABI_VERSION; }
 

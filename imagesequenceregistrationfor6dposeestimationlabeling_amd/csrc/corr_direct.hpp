@@ -345,7 +345,12 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + qb * 32 + r;
     if (h != 0 || q >= P) continue;
-    if (any_bad) ws.pbad[q] = over[qb] ? 1 : 0;
+    if (any_bad) {
+      ws.pbad[q] = over[qb] ? 1 : 0;
+      // corr_finalize_kernel finishes the bad queries of this block and reads |q|^2 for the margin test from the
+      // workspace (this launch stored it nowhere else: the split == 0 store above is the key-split route's)
+      if (over[qb]) ws.qn2[q] = qn2[qb];
+    }
     if (!over[qb])
       corr_finish<NAT ? 2 : 1>(q, st[qb].m, st[qb].m2, st[qb].tb, false, st[qb].L, 0.0, 16 * DK, qn2[qb], kn2, ws, idx_out,
                                logp_out, lse_out);

@@ -14,6 +14,9 @@ namespace isr {
 char* last_error_buf();
 void set_error(const char* fmt, ...);
 
+// Value of a tuning knob (ISR_TUNE_*): a relaxed atomic load, no environment access.
+int tuning(int knob);
+
 inline hipStream_t as_stream(isr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Launch check: hipGetLastError after a kernel launch, no synchronisation.

@@ -612,10 +612,10 @@ constexpr size_t kPartBudget = size_t(192) << 20;  // bytes of per-query partial
 NNPlan make_plan(int Nq, int Nt, int B) {
   NNPlan p;
   p.rq = (Nq >= 4 * kThreads) ? 4 : 1;
-  // tuning hook (experiments only): ISR_NN_PLAN="rq,want_blocks"
-  static const char* env = getenv("ISR_NN_PLAN");
-  long want_env = 0;
-  if (env) { int rq = 0; if (sscanf(env, "%d,%ld", &rq, &want_env) >= 1 && (rq == 1 || rq == 4)) p.rq = rq; }
+  // tuning knobs (experiments only): ISR_TUNE_NN_PLAN_RQ / _BLOCKS
+  const int rq_knob = isr::tuning(ISR_TUNE_NN_PLAN_RQ);
+  const long want_env = isr::tuning(ISR_TUNE_NN_PLAN_BLOCKS);
+  if (rq_knob == 1 || rq_knob == 4) p.rq = rq_knob;
   p.qblocks = (Nq + p.rq * kThreads - 1) / (p.rq * kThreads);
   // 256 CUs x 8 workgroups are resident at once; aim for two such rounds.  More key-range splits
   // would even out the last round, but every split restarts its running minimum, and while a
@@ -645,9 +645,7 @@ NNPlan make_plan(int Nq, int Nt, int B) {
   //    force once neighbours are more than a cell or two away.
   p.grid = false;
   p.tile = B >= 4 && Nq >= 1024 && Nt >= 4096 && (long)Nq * B >= (1L << 17);
-  if (const char* ge = getenv("ISR_NN_GRID")) {
-    if (ge[0]) { p.grid = ge[0] == '1'; p.tile = ge[0] == '2'; }   // empty = unset
-  }
+  if (const int path = isr::tuning(ISR_TUNE_NN_PATH); path >= 0) { p.grid = path == 1; p.tile = path == 2; }
   if (p.grid || p.tile) {
     p.nsplit = 1;
     p.split_len = max_split * kTile;
@@ -670,7 +668,7 @@ void launch_search(const NNPlan& p, const dim3& grid, hipStream_t stream, const 
   bool filter = warm != nullptr || p.split_len >= kFilterMinTiles * kTile;
   // tuning hook (experiments only) for cold searches; a warm start always takes the filter loop (its tie rule —
   // equal distance, lower index — is what makes a warm-started lane return the cold winner)
-  if (const char* e = getenv("ISR_NN_FILTER")) { if (e[0] && !warm) filter = e[0] == '1'; }
+  if (const int f = isr::tuning(ISR_TUNE_NN_FILTER); f >= 0 && !warm) filter = f == 1;
 #define ISR_SEARCH(RQv, Fv)                                                                                              \
   nn_search_kernel<RQv, Fv><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len, p.nsplit, part_d2, part_idx, \
                                                            skip, unresolved, packed, warm)
@@ -799,8 +797,7 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
   const bool brute = !p.grid && !p.tile;
   unsigned long long* packed = brute ? w.take<unsigned long long>(Ns) : nullptr;
   int32_t* prev_idx = brute ? w.take<int32_t>(Ns) : nullptr;
-  const char* warm_env = getenv("ISR_ICP_WARM");                   // tuning hook: 0 keeps every pass on the cold kernel
-  const bool warm = !(warm_env && warm_env[0] == '0');
+  const bool warm = isr::tuning(ISR_TUNE_ICP_WARM) != 0;          // tuning knob: 0 keeps every pass on the cold kernel
   icp_init_kernel<<<brute ? (Ns + kThreads - 1) / kThreads : 1, kThreads, 0, stream>>>(st, T_io, packed, Ns);
   GridWs gw{};
   TileWs tw{};

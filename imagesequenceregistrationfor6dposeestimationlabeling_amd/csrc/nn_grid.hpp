@@ -582,7 +582,9 @@ struct TileCfg {
 
 TileCfg tile_cfg() {
   TileCfg c{kCellScaleTgt, kCellScaleQry, kTileTB};
-  if (const char* e = getenv("ISR_NN_TILE")) (void)sscanf(e, "%lf,%lf,%d", &c.st, &c.sq, &c.tb);
+  if (const int v = isr::tuning(ISR_TUNE_NN_TILE_ST); v > 0) c.st = v * 1e-3;
+  if (const int v = isr::tuning(ISR_TUNE_NN_TILE_SQ); v > 0) c.sq = v * 1e-3;
+  if (const int v = isr::tuning(ISR_TUNE_NN_TILE_TB); v > 0) c.tb = v;
   if (c.tb != 64 && c.tb != 128 && c.tb != 256) c.tb = kTileTB;
   return c;
 }

@@ -30,7 +30,10 @@
 //                   local optimisation: the inlier mask is recomputed under the refitted pose (same
 //                   f32 test) and the refit repeated on it — a hypothesis from 4 noisy points captures
 //                   only part of the consensus set, and with the adaptive termination the loop may
-//                   stop after 32 of them; the reported inliers are those of the refitted pose.
+//                   stop after 32 of them.  The reported inliers are those of the RETURNED pose (the mask is
+//                   evaluated once more under the final refit; cv2 reports the RANSAC model's consensus set
+//                   instead, as far as is known — a documented deviation, like the confidence rule).  A refit
+//                   over fewer than 4 correspondences is skipped (the pose it started from is kept).
 //   5. compaction   inlier mask -> ascending int32 indices.
 // Every step reads M and the status from device memory: the whole chain is enqueued without a
 // host round trip.
@@ -274,20 +277,42 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
 
 // One block per image: best = arg-max n_inl over ok hypotheses (lowest h on ties); status = count >= 4.
 // Also clears the image's Gauss-Newton convergence flag (no memset launch).
+// n_eval_dev (nullable): how many hypotheses the staged loop scored for this image — the stage rule replayed
+// on the final counts (a stage that did not run left its counts at 0, and the replay stops before it).
 __global__ void best_kernel(const int32_t* __restrict__ n_inl, const uint8_t* __restrict__ ok, int H,
                             int32_t* __restrict__ best_dev, int32_t* __restrict__ status_dev,
                             const double* __restrict__ Rt, double* __restrict__ pose_dev,
-                            int32_t* __restrict__ gn_state) {
+                            int32_t* __restrict__ gn_state, const int32_t* __restrict__ M_dev,
+                            double one_minus_conf, int32_t* __restrict__ n_eval_dev) {
   __shared__ int32_t sc[256], sh[256];
+  __shared__ int32_t smax[16];        // best count inside stage s = [32 (2^s - 1), 32 (2^(s+1) - 1))
   const int b = blockIdx.z;
   n_inl += (size_t)b * H; ok += (size_t)b * H; Rt += (size_t)b * H * 12;
   best_dev += b;
   if (status_dev) status_dev += b;
   if (pose_dev) pose_dev += (size_t)b * 12;
   if (gn_state && threadIdx.x == 0) { gn_state[4 * b] = 0; gn_state[4 * b + 1] = 0; }
+  if (threadIdx.x < 16) smax[threadIdx.x] = 0;
+  if (n_eval_dev) __syncthreads();
   int bc = -1, bh = -1;
   for (int h = threadIdx.x; h < H; h += 256) {
     if (ok[h] && n_inl[h] > bc) { bc = n_inl[h]; bh = h; }  // ascending h per thread: lowest kept
+    if (n_eval_dev && ok[h] && n_inl[h] > 0) atomicMax(&smax[31 - __clz(h / kStage0 + 1)], n_inl[h]);
+  }
+  if (n_eval_dev) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int n_eval = H, c = 0;
+      if (one_minus_conf > 0.0) {
+        for (int st = 0; st < 16; ++st) {
+          c = max(c, smax[st]);
+          const int bound = kStage0 * ((2 << st) - 1);     // upper boundary of stage st
+          if (bound >= H) break;
+          if (ransac_stop(c, M_dev[b], bound, one_minus_conf)) { n_eval = bound; break; }
+        }
+      }
+      n_eval_dev[b] = n_eval;
+    }
   }
   sc[threadIdx.x] = bc; sh[threadIdx.x] = bh;
   __syncthreads();
@@ -348,7 +373,7 @@ __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __r
 // ---------------------------------------------------------------------------------- refit
 constexpr int kRefThreads = 256;
 constexpr int kRefBlocks = 64;
-constexpr int kNAcc = 28;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2)
+constexpr int kNAcc = 29;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2) + 1 (number of correspondences used)
 
 // One block: 28 lanes sum the block partials in order (fixed order: reproducible), lane 0 solves
 // the 6x6 normal equations by Cholesky and retracts:  R <- Q(w) R,  t <- Q(w) t + dt  with Q(w) the
@@ -364,6 +389,9 @@ __device__ void gn_solve(const double* __restrict__ partial, double* __restrict_
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
+  // fewer than 4 correspondences (a local-optimisation mask that collapsed): the system is rank deficient or
+  // nearly so — keep the pose this refit started from (oracle/pnp_oracle.py:refine does the same)
+  if (s[28] < 4.0) { state[0] = 1; return; }
   double A[6][6], g[6];
   int k = 0;
   for (int i = 0; i < 6; ++i)
@@ -469,6 +497,7 @@ __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
 #pragma unroll
       for (int i = 0; i < 6; ++i) acc[21 + i] += Ju[i] * ru + Jv[i] * rv;
       acc[27] += ru * ru + rv * rv;
+      acc[28] += 1.0;
     }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -661,7 +690,7 @@ extern "C" int isr_p3p_all_roots(const double* X, const double* uv, const double
 static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgBatch& ib,
                       const double* Rt, const uint8_t* ok, int H, double confidence, float reperr, float* Pm,
                       int32_t* n_inl, int32_t* best_dev, uint32_t* best_mask, int32_t* status_dev, double* pose_dev,
-                      int32_t* gn_state, hipStream_t stream) {
+                      int32_t* gn_state, int32_t* n_eval_dev, hipStream_t stream) {
   proj_matrix_kernel<<<dim3((H * 12 + 255) / 256, 1, B), 256, 0, stream>>>(Rt, ib, H, Pm, n_inl);
   const int nblk = (M_cap + kScoreThreads * kCPL - 1) / (kScoreThreads * kCPL);
   const double omc = (confidence >= 1.0) ? 0.0 : 1.0 - confidence;
@@ -672,7 +701,8 @@ static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, 
         p3d, p2d, M_dev, M_cap, Pm, ok, H, lo, hi, omc, reperr, n_inl);
     if (hi == H) break;
   }
-  best_kernel<<<dim3(1, 1, B), 256, 0, stream>>>(n_inl, ok, H, best_dev, status_dev, Rt, pose_dev, gn_state);
+  best_kernel<<<dim3(1, 1, B), 256, 0, stream>>>(n_inl, ok, H, best_dev, status_dev, Rt, pose_dev, gn_state, M_dev, omc,
+                                                 n_eval_dev);
   if (best_mask)
     best_mask_kernel<<<dim3((M_cap + 255) / 256, 1, B), 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, H, Pm, best_dev, reperr,
                                                                           best_mask, mask_words_of(M_cap));
@@ -695,7 +725,7 @@ extern "C" int isr_ransac_score(const float* p3d, const float* p2d, const int32_
   isr::Workspace w(ws, ws_bytes);
   float* Pm = w.take<float>((size_t)H * 12);
   return score_impl(p3d, p2d, M_dev, M_cap, 1, ib, Rt, ok, H, 1.0, reperr, Pm, n_inl, best_dev, best_mask,
-                    nullptr, nullptr, nullptr, isr::as_stream(stream_));
+                    nullptr, nullptr, nullptr, nullptr, isr::as_stream(stream_));
 }
 
 static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const uint32_t* mask,
@@ -731,11 +761,11 @@ extern "C" int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t*
 // the chain for B <= kMaxBatch images: hypotheses, scoring, best + mask, refit, compaction
 static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgBatch& ib,
                         int H, double confidence, float reperr, int refine_iters, double* pose_dev, int32_t* inl_idx,
-                        int32_t* n_inl_dev, int32_t* status_dev, const RansacWs& b, hipStream_t stream) {
+                        int32_t* n_inl_dev, int32_t* status_dev, int32_t* n_eval_dev, const RansacWs& b, hipStream_t stream) {
   p3p_kernel<<<dim3((H + 63) / 64, 1, B), 64, 0, stream>>>(p3d, p2d, M_dev, M_cap, ib, H, b.Rt, b.ok, nullptr);
   ISR_CHECK_LAUNCH("p3p_kernel");
   int rc = score_impl(p3d, p2d, M_dev, M_cap, B, ib, b.Rt, b.ok, H, confidence, reperr, b.Pm, b.n_inl, b.best, b.mask,
-                      status_dev, pose_dev, b.state, stream);
+                      status_dev, pose_dev, b.state, n_eval_dev, stream);
   if (rc != ISR_OK) return rc;
   rc = refine_impl(p3d, p2d, M_dev, M_cap, B, b.mask, ib, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
   if (rc != ISR_OK) return rc;
@@ -745,6 +775,10 @@ static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev
                                                                           b.mask, mask_words_of(M_cap));
     rc = refine_impl(p3d, p2d, M_dev, M_cap, B, b.mask, ib, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
     if (rc != ISR_OK) return rc;
+    // the reported inliers are those of the RETURNED pose: the mask once more, under the final refit
+    refined_proj_kernel<<<B, 64, 0, stream>>>(pose_dev, ib, b.Pm, b.state);
+    best_mask_kernel<<<dim3((M_cap + 255) / 256, 1, B), 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, 1, b.Pm, nullptr, reperr,
+                                                                          b.mask, mask_words_of(M_cap));
   }
   const int cb = comp_blocks_of(M_cap), mw = mask_words_of(M_cap);
   mask_count_kernel<<<dim3(cb, 1, B), kCompBlock, 0, stream>>>(b.mask, mw, M_dev, status_dev, b.cblocks);
@@ -757,7 +791,7 @@ static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev
 extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
                               const double* Kcam, int H, uint64_t seed, float reperr, double confidence,
                               int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
-                              int32_t* status_dev, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+                              int32_t* status_dev, int32_t* n_eval_dev, void* ws, size_t ws_bytes, isr_stream_t stream_) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && pose_dev && inl_idx && n_inl_dev && status_dev,
               "isr_pnp_ransac: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH, "isr_pnp_ransac: M_cap=%d H=%d (H <= %d)", M_cap, H, kMaxH);
@@ -772,13 +806,14 @@ extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t*
   carve(w, M_cap, H, 1, &b);
   ISR_REQUIRE(confidence > 0.0, "isr_pnp_ransac: confidence=%g must be > 0 (>= 1: score every hypothesis)", confidence);
   return ransac_chain(p3d, p2d, M_dev, M_cap, 1, ib, H, confidence, reperr, refine_iters, pose_dev, inl_idx, n_inl_dev,
-                      status_dev, b, isr::as_stream(stream_));
+                      status_dev, n_eval_dev, b, isr::as_stream(stream_));
 }
 
 extern "C" int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B,
                                     const double* Kcams, int H, const uint64_t* seeds, float reperr, double confidence,
                                     int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
-                                    int32_t* status_dev, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+                                    int32_t* status_dev, int32_t* n_eval_dev, void* ws, size_t ws_bytes,
+                                    isr_stream_t stream_) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcams && seeds && pose_dev && inl_idx && n_inl_dev && status_dev,
               "isr_pnp_ransac_batch: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH && B > 0, "isr_pnp_ransac_batch: M_cap=%d H=%d (H <= %d) B=%d", M_cap, H, kMaxH, B);
@@ -797,7 +832,7 @@ extern "C" int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const in
     carve(w, M_cap, H, nb, &wsb);
     const int rc = ransac_chain(p3d + (size_t)b0 * M_cap * 3, p2d + (size_t)b0 * M_cap * 2, M_dev + b0, M_cap, nb, ib, H,
                                 confidence, reperr, refine_iters, pose_dev + (size_t)b0 * 12, inl_idx + (size_t)b0 * M_cap,
-                                n_inl_dev + b0, status_dev + b0, wsb, stream);
+                                n_inl_dev + b0, status_dev + b0, n_eval_dev ? n_eval_dev + b0 : nullptr, wsb, stream);
     if (rc != ISR_OK) return rc;
   }
   return ISR_OK;

@@ -53,6 +53,45 @@ class _timed:
         return False
 
 
+class tuning:
+    """Context manager over the library's tuning knobs (isr_tuning_set; experiments and tests only):
+        with ops.tuning(nn_path=0): ...      # brute-force NN inside the block
+    Knobs: nn_path (-1 auto, 0 brute, 1 per-lane grid, 2 block-cooperative grid), nn_filter (-1 auto, 0, 1),
+    icp_warm (1, 0), nn_plan_rq, nn_plan_blocks, nn_tile_st / nn_tile_sq (x 1000), nn_tile_tb.  Process-wide:
+    do not flip a knob while another thread is inside an entry point that reads it."""
+
+    def __init__(self, **knobs):
+        self.knobs = {_capi.TUNE[k]: int(v) for k, v in knobs.items()}
+
+    def __enter__(self):
+        L = lib()
+        self.old = {k: L.isr_tuning_get(k) for k in self.knobs}
+        for k, v in self.knobs.items():
+            check(L.isr_tuning_set(k, v), "isr_tuning_set")
+        return self
+
+    def __exit__(self, *exc):
+        L = lib()
+        for k, v in self.old.items():
+            L.isr_tuning_set(k, v)
+        return False
+
+
+def set_tuning(**knobs) -> None:
+    """Set tuning knobs for the rest of the process (tools/ sweeps); see `tuning`."""
+    for k, v in knobs.items():
+        check(lib().isr_tuning_set(_capi.TUNE[k], int(v)), "isr_tuning_set")
+
+
+def set_tile_plan(plan: str | None) -> None:
+    """'st,sq,tb' (the old ISR_NN_TILE syntax) or None for the defaults."""
+    if plan is None:
+        set_tuning(nn_tile_st=0, nn_tile_sq=0, nn_tile_tb=0)
+    else:
+        st, sq, tb = plan.split(",")
+        set_tuning(nn_tile_st=round(float(st) * 1000), nn_tile_sq=round(float(sq) * 1000), nn_tile_tb=int(tb))
+
+
 def workspace(device: torch.device, nbytes: int, tag: str = "default") -> torch.Tensor:
     """A cached, grow-only scratch buffer per (device, stream, tag).
     While the current stream is being captured into a HIP graph nothing is cached: a buffer allocated during
@@ -435,6 +474,7 @@ class PnPResult:
     inl_idx: torch.Tensor   # (cap,) i32 device, first n_inl valid
     n_inl: torch.Tensor     # (1,) i32 device
     status: torch.Tensor    # (1,) i32 device
+    n_eval: torch.Tensor | None = None   # (1,) i32 device: hypotheses the staged loop scored
 
 
 def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
@@ -450,15 +490,16 @@ def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
     inl = torch.empty(cap, dtype=torch.int32, device=dev)
     n_inl = torch.zeros(1, dtype=torch.int32, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
+    n_eval = torch.zeros(1, dtype=torch.int32, device=dev)
     L = lib()
     ws = workspace(dev, L.isr_pnp_ransac_workspace_bytes(cap, H), "ransac")
     k = _kcam(Kcam)
     with torch.cuda.device(dev), _timed("pnp_ransac", 30.0 * H * cap):
         rc = L.isr_pnp_ransac(ptr(p3d), ptr(p2d), ptr(M_dev), cap, ctypes.cast(k, ctypes.c_void_p), int(H),
                               seed & 0xFFFFFFFFFFFFFFFF, float(reperr), float(confidence), int(refine_iters), ptr(pose),
-                              ptr(inl), ptr(n_inl), ptr(status), ptr(ws), ws.numel(), current_stream(dev))
+                              ptr(inl), ptr(n_inl), ptr(status), ptr(n_eval), ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_pnp_ransac")
-    return PnPResult(pose, inl, n_inl, status)
+    return PnPResult(pose, inl, n_inl, status, n_eval)
 
 
 # ------------------------------------------------------------------ the per-group (batched) chain
@@ -503,6 +544,7 @@ class PnPBatchResult:
     inl_idx: torch.Tensor   # (B,cap) i32 device, first n_inl[b] valid
     n_inl: torch.Tensor     # (B,) i32 device
     status: torch.Tensor    # (B,) i32 device
+    n_eval: torch.Tensor | None = None   # (B,) i32 device: hypotheses the staged loop scored per image
 
 
 def pnp_ransac_batch(p3d, p2d, Kcams, M_dev, H: int = 500, reperr: float = 2.0, seeds=None,
@@ -524,15 +566,16 @@ def pnp_ransac_batch(p3d, p2d, Kcams, M_dev, H: int = 500, reperr: float = 2.0, 
     inl = torch.empty((B, cap), dtype=torch.int32, device=dev)
     n_inl = torch.empty(B, dtype=torch.int32, device=dev)
     status = torch.empty(B, dtype=torch.int32, device=dev)
+    n_eval = torch.empty(B, dtype=torch.int32, device=dev)
     L = lib()
     ws = workspace(dev, L.isr_pnp_ransac_batch_workspace_bytes(cap, H, B), "ransac")
     with torch.cuda.device(dev), _timed("pnp_ransac", 30.0 * H * cap * B):
         rc = L.isr_pnp_ransac_batch(ptr(p3d), ptr(p2d), ptr(M_dev), cap, B, K.ctypes.data_as(ctypes.c_void_p), int(H),
                                     sd.ctypes.data_as(ctypes.c_void_p), float(reperr), float(confidence),
                                     int(refine_iters), ptr(pose),
-                                    ptr(inl), ptr(n_inl), ptr(status), ptr(ws), ws.numel(), current_stream(dev))
+                                    ptr(inl), ptr(n_inl), ptr(status), ptr(n_eval), ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_pnp_ransac_batch")
-    return PnPBatchResult(pose, inl, n_inl, status)
+    return PnPBatchResult(pose, inl, n_inl, status, n_eval)
 
 
 def add_metric(verts: torch.Tensor, Ta: torch.Tensor | None, Tb: torch.Tensor | None) -> torch.Tensor:

@@ -33,6 +33,7 @@ class ImageResult:
     M: torch.Tensor        # (1,) i32 device
     idx: torch.Tensor      # (P,) i32 device: idx1 of inference.py:273
     logp: torch.Tensor     # (P,) f32 device: in1[:,0]
+    n_eval: torch.Tensor | None = None   # (1,) i32 device: hypotheses the staged RANSAC loop scored
 
 
 def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Tensor, cam,
@@ -51,7 +52,7 @@ def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
     p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix_xy)
     r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M,
                        confidence=confidence)
-    return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp)
+    return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp, r.n_eval)
 
 
 def register_crop(model: SequenceModel, feat: torch.Tensor, mask: torch.Tensor, cam, c0: int = 0,
@@ -76,7 +77,7 @@ def register_crop(model: SequenceModel, feat: torch.Tensor, mask: torch.Tensor, 
     p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix)
     r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M,
                        confidence=confidence)
-    return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp), n_dev
+    return ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp, r.n_eval), n_dev
 
 
 def register_frame(model: SequenceModel, rgb, mask, camparams, encoder, n_feat: int = 12, down_sample: int = 3,
@@ -103,8 +104,9 @@ def _publish(results: list[ImageResult], consumer: torch.cuda.Stream) -> None:
     record_stream a dropped result's block goes back to its side stream's pool at once, and the next
     step's allocations there may overwrite it while `consumer` is still reading."""
     for r in results:
-        for t in (r.pose, r.status, r.n_inl, r.inl_idx, r.keep, r.M, r.idx, r.logp):
-            t.record_stream(consumer)
+        for t in (r.pose, r.status, r.n_inl, r.inl_idx, r.keep, r.M, r.idx, r.logp, r.n_eval):
+            if t is not None:
+                t.record_stream(consumer)
 
 
 _streams: dict[tuple, list] = {}
@@ -157,7 +159,7 @@ def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: f
             p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix)
             r = ops.pnp_ransac(p3d, p2d, cam_of(j), H=itr, reperr=reperr, seed=seed0 + j,
                                refine_iters=refine_iters, M_dev=M, confidence=confidence)
-        out.append(ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp))
+        out.append(ImageResult(r.pose, r.status, r.n_inl, r.inl_idx, keep, M, idx, logp, r.n_eval))
     for s in pool:
         cur.wait_stream(s)
     _publish(out, cur)
@@ -176,7 +178,8 @@ def register_group(model: SequenceModel, idx_g: torch.Tensor, logp_g: torch.Tens
     p3d, p2d = ops.gather_corr_batch(idx_g, keep, M, model.pts, pix_xy)
     r = ops.pnp_ransac_batch(p3d, p2d, cams, M, H=itr, reperr=reperr, seeds=seeds, refine_iters=refine_iters,
                              confidence=confidence)
-    return [ImageResult(r.pose[b], r.status[b:b + 1], r.n_inl[b:b + 1], r.inl_idx[b], keep[b], M[b:b + 1], idx_g[b], logp_g[b])
+    return [ImageResult(r.pose[b], r.status[b:b + 1], r.n_inl[b:b + 1], r.inl_idx[b], keep[b], M[b:b + 1], idx_g[b], logp_g[b],
+                        r.n_eval[b:b + 1])
             for b in range(B)]
 
 
@@ -235,12 +238,20 @@ def _orthonormal(R, tol=1e-9) -> bool:
 
 def pick_by_chamfer(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.ndarray, t_gt_all: np.ndarray,
                     n_total: int) -> tuple[int, float]:
-    """verfication.py:61-108 sharded: this rank evaluates the consecutive pairs it owns, then one
-    packed all-reduce(MIN) picks the global first minimum.  poses_all (n,12) predicted poses of ALL
-    images (after the all-gather), R_gt_all/t_gt_all the GT poses from scene_gt.json."""
+    """verfication.py:61-108 sharded: this rank evaluates the consecutive pairs it owns, then ONE
+    all-reduce(MIN) over the (n - 1)-entry f64 table (shard.allreduce_min_table) hands every rank the whole
+    `chamferdis` list, and min / list.index(min) — the first minimum, in f64 — is taken on every rank
+    identically.  poses_all (n,12) predicted poses of ALL images (after the all-gather), R_gt_all/t_gt_all
+    the GT poses from scene_gt.json.  Returns (index, value)."""
+    idx, val, _ = pick_by_chamfer_table(pc1, poses_all, R_gt_all, t_gt_all, n_total)
+    return idx, val
+
+
+def pick_by_chamfer_table(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.ndarray, t_gt_all: np.ndarray,
+                          n_total: int) -> tuple[int, float, np.ndarray]:
+    """pick_by_chamfer, also returning the full chamferdis table (n - 1,) f64 as a NumPy array."""
     rank, size = shard.world()
     lo, hi = shard.owned_pairs(n_total, rank, size)
-    best = (None, 0)
     if hi > lo:
         Rp = poses_all.reshape(-1, 3, 4)[lo:hi + 1, :, :3].cpu().numpy()
         # rotation block of [R2|T2] inv([R1|T1]) (verfication.py:9-19) for every owned pair at once
@@ -249,10 +260,11 @@ def pick_by_chamfer(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.nda
             [registration.calculate_relative_pose(R_gt_all[i], t_gt_all[i], R_gt_all[i + 1], t_gt_all[i + 1])[0]
              for i in range(lo, hi)])
         ch = registration.chamfer_pairs(pc1, Rp, Rrel)
-        i, v = registration.choose_best(ch)
-        best = (float(np.float32(v)), lo + i)
-    val, idx = shard.allreduce_min_pair(best[0], best[1])
-    return idx, val
+    else:
+        ch = torch.empty(0, dtype=torch.float64, device=pc1.device)
+    table = shard.allreduce_min_table(ch, lo, n_total - 1).cpu().numpy()
+    idx, val = shard.first_min(table)
+    return idx, val, table
 
 
 def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, top: int = 50):

@@ -5,15 +5,15 @@ The path partitions by image: rank r registers the contiguous block block_range(
 data-path collective.  Verification needs two tiny exchanges:
   * all-gather of the predicted poses (n x 12 f64, <= 123 KB) so the pair (i, i+1) that straddles
     a block boundary can be evaluated by the rank that owns i;
-  * one all-reduce(MIN) of a packed int64 (f32 bits of the Chamfer distance << 32 | pair index):
-    distances are >= 0 so the IEEE bit pattern is order preserving, and the lower index wins ties,
-    which is list.index(min) — verfication.py:105-106.
+  * one all-reduce(MIN) over the (n - 1)-entry table of pair Chamfer distances held as the int64 image of
+    their f64 values (distances are >= 0, so the IEEE bit pattern is order preserving; entries a rank does
+    not own are +inf): every rank ends up with the reference's whole `chamferdis` list, exact in f64, and
+    takes min / list.index(min) itself — verfication.py:105-106.
 Both are latency-bound; the per-link xGMI bandwidth never matters here.
 """
 from __future__ import annotations
 
 import os
-import struct
 
 import torch
 import torch.distributed as dist
@@ -38,31 +38,44 @@ def owned_pairs(n: int, rank: int, size: int) -> tuple[int, int]:
     return lo, min(hi, n - 1)
 
 
-def pack_min(val: float, idx: int) -> int:
-    """(non-negative f32 value, index) -> int64 whose integer order is (value, index) order."""
-    if not (val >= 0.0):
-        raise ValueError(f"pack_min needs a non-negative finite value, got {val}")
-    bits = struct.unpack("<I", struct.pack("<f", val))[0]
-    return (bits << 32) | (idx & 0xFFFFFFFF)
+INF_BITS = 0x7FF0000000000000     # +inf as f64 bits: the identity of the MIN reduction below
 
 
-def unpack_min(packed: int) -> tuple[float, int]:
-    bits = (packed >> 32) & 0xFFFFFFFF
-    return struct.unpack("<f", struct.pack("<I", bits))[0], packed & 0xFFFFFFFF
-
-
-EMPTY = (0x7F800000 << 32) | 0xFFFFFFFF   # +inf, max index: the identity of the MIN reduction
-
-
-def allreduce_min_pair(val: float | None, idx: int, device=None) -> tuple[float, int]:
-    """Global (min value, its index) over ranks; val None = this rank owns nothing."""
-    packed = EMPTY if val is None else pack_min(val, idx)
+def allreduce_min_table(local: torch.Tensor, lo: int, n_items: int) -> torch.Tensor:
+    """Every rank contributes the f64 values of the items [lo, lo + len(local)) it owns; ONE all-reduce(MIN)
+    gives every rank the whole (n_items,) table — the reference's `chamferdis` list (verfication.py:61-102) —
+    bit for bit.  The reduction runs on the int64 image of the doubles: values are >= 0, so the IEEE bit
+    pattern is order preserving, an item nobody owns stays +inf, and an owned item passes through unchanged
+    (min(x, +inf) = x), i.e. the table is EXACT in f64, not rounded to f32 as round 2's packed (f32, index)
+    word was.  n_items * 8 B per rank (4 KB at 512 images): latency-bound on xGMI like the 8-byte word.
+    A NaN entry (a failed image's pose) has a bit pattern above +inf and comes out as +inf: it cannot win.
+    No host synchronisation here; first_min() validates the table it reads back."""
     rank, size = world()
+    local = local.to(torch.float64).reshape(-1)
     if size == 1 and not _forced():
-        return unpack_min(packed)
-    t = torch.tensor([packed], dtype=torch.int64, device=device or _coll_device())
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return unpack_min(int(t.item()))
+        if lo != 0 or local.numel() != n_items:
+            raise ValueError("a single rank owns every item")
+        return local
+    dev = _coll_device()
+    table = torch.full((n_items,), INF_BITS, dtype=torch.int64, device=dev)
+    if local.numel():
+        table[lo:lo + local.numel()] = local.to(dev).view(torch.int64)
+    dist.all_reduce(table, op=dist.ReduceOp.MIN)
+    return table.view(torch.float64)
+
+
+def first_min(table) -> tuple[int, float]:
+    """verfication.py:105-106: `min(chamferdis)` and `chamferdis.index(min)` — the FIRST minimum, in f64."""
+    import numpy as np
+    c = table.cpu().numpy() if isinstance(table, torch.Tensor) else np.asarray(table, np.float64)
+    if c.size == 0:
+        raise ValueError("first_min of an empty table (a sequence needs at least two images)")
+    if np.isnan(c).any():
+        c = np.where(np.isnan(c), np.inf, c)
+    if (c < 0).any():
+        raise ValueError("first_min: negative distance in the table")
+    i = int(np.argmin(c))          # np.argmin returns the first occurrence of the minimum
+    return i, float(c[i])
 
 
 def _forced() -> bool:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ISR_ABI_VERSION 2
+#define ISR_ABI_VERSION 3
 
 #define ISR_OK 0
 #define ISR_ERR_ARG (-1)         /* bad shape / null pointer / unsupported value */
@@ -47,6 +47,23 @@ int isr_abi_version(void);
 const char* isr_last_error(void);
 /* Number of HIP devices visible to the library's runtime (0 on a CPU-only host, no error). */
 int isr_device_count(void);
+
+/* Tuning knobs (experiments and tests only; every knob at its default selects the shipped plan).  Process-wide
+ * atomics, read by the entry points when they plan a launch: no environment look-ups on the call path.  The
+ * initial values are read ONCE, when the library is loaded, from the ISR_* environment variables named below.
+ * isr_tuning_set returns ISR_OK (ISR_ERR_ARG for an unknown knob), isr_tuning_get the value (0 for an unknown
+ * knob); all choices give bit-identical results (the NN paths are interchangeable by construction and tested to be). */
+#define ISR_TUNE_NN_PATH 0       /* -1 auto | 0 brute force | 1 per-lane grid | 2 block-cooperative grid   ISR_NN_GRID */
+#define ISR_TUNE_NN_FILTER 1     /* -1 auto | 0 plain loop | 1 filter loop (cold searches)                  ISR_NN_FILTER */
+#define ISR_TUNE_ICP_WARM 2      /* 1 warm-started ICP passes (default) | 0 every pass cold                 ISR_ICP_WARM */
+#define ISR_TUNE_NN_PLAN_RQ 3    /* 0 auto | 1 | 4 queries per lane                                         ISR_NN_PLAN="rq,blocks" */
+#define ISR_TUNE_NN_PLAN_BLOCKS 4 /* 0 auto | wanted workgroups per launch */
+#define ISR_TUNE_NN_TILE_ST 5    /* 0 default | target cell scale x 1000                                    ISR_NN_TILE="st,sq,tb" */
+#define ISR_TUNE_NN_TILE_SQ 6    /* 0 default | query cell scale x 1000 */
+#define ISR_TUNE_NN_TILE_TB 7    /* 0 default | 64 | 128 | 256 threads per workgroup */
+#define ISR_TUNE_COUNT 8
+int isr_tuning_set(int knob, int value);
+int isr_tuning_get(int knob);
 
 /* ------------------------------------------------------------------------------------------
  * K1  feature correlation: getCors(queries, feats, leaves=1)
@@ -176,7 +193,9 @@ int isr_gather_corr_batch(const int32_t* idx, const int32_t* keep, const int32_t
  *   (1 - (c/M)^4)^b > 1 - confidence for the best count c after the b hypotheses before it;
  *   confidence >= 1 scores all H (isr_ransac_score always does).
  *   pose_dev: 12 f64 [R|t];  inl_idx: capacity M_cap;  n_inl_dev: i32;  status_dev: i32
- *   (1 = pose found, 0 = failed: the Python mirror then returns the reference's (1,1,1)).
+ *   (1 = pose found, 0 = failed: the Python mirror then returns the reference's (1,1,1));
+ *   n_eval_dev (nullable): i32, how many of the H hypotheses the staged loop scored.
+ *   The inliers reported are those of the RETURNED pose (after the refit and its local-optimisation round).
  * Kcam: host pointer, 9 doubles row-major.
  */
 /* Diagnostics: EVERY root of the device P3P solver for S independent 3-point problems (the production
@@ -197,7 +216,7 @@ int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t* M_dev, int
 int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
                    const double* Kcam, int H, uint64_t seed, float reperr, double confidence,
                    int refine_iters, double* pose_dev, int32_t* inl_idx, int32_t* n_inl_dev,
-                   int32_t* status_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
+                   int32_t* status_dev, int32_t* n_eval_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* isr_pnp_ransac for a GROUP of B images as one chain of launches (image = blockIdx.z of every kernel):
  * p3d (B, M_cap, 3), p2d (B, M_cap, 2), M_dev (B); Kcams HOST (B, 9) f64, seeds HOST (B) u64;
@@ -207,8 +226,8 @@ size_t isr_pnp_ransac_batch_workspace_bytes(int M_cap, int H, int B);
 int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B,
                          const double* Kcams, int H, const uint64_t* seeds, float reperr,
                          double confidence, int refine_iters, double* pose_dev, int32_t* inl_idx,
-                         int32_t* n_inl_dev, int32_t* status_dev, void* ws, size_t ws_bytes,
-                         isr_stream_t stream);
+                         int32_t* n_inl_dev, int32_t* status_dev, int32_t* n_eval_dev /* (B), nullable */,
+                         void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3 / K4  batched brute-force nearest neighbour with fused reductions

@@ -180,6 +180,8 @@ def refine(p3d, p2d, K, Rt, sel, iters=10):
     X = p3d[sel].astype(np.float64)
     uv = p2d[sel].astype(np.float64)
     R, t = Rt[:, :3].copy(), Rt[:, 3].copy()
+    if len(X) < 4:          # csrc/ransac.hip:gn_solve keeps the pose when fewer than 4 correspondences remain
+        return np.array(Rt, np.float64, copy=True)
     for _ in range(iters):
         Xc = X @ R.T + t
         p = Xc @ K.T
@@ -260,5 +262,8 @@ def pnp_ransac(p3d, p2d, K, H=500, reperr=2.0, seed=0, refine_iters=10, confiden
         lo = cbind.ransac_score(p3d, p2d, K, pose.reshape(1, 12), np.ones(1, np.uint8), reperr)
         inl = unpack_mask(lo["best_mask"], len(p3d))
         pose = refine(p3d, p2d, K, pose, inl, refine_iters)
+        # the reported inliers belong to the returned pose
+        fin = cbind.ransac_score(p3d, p2d, K, pose.reshape(1, 12), np.ones(1, np.uint8), reperr)
+        inl = unpack_mask(fin["best_mask"], len(p3d))
     return dict(status=status, Rt=pose, inliers=np.nonzero(inl)[0].astype(np.int32) if status else
                 np.zeros(0, np.int32), n_inl=sc["n_inl"], best=best, n_eval=n_eval, Rt_all=Rt, ok=ok, samples=S)

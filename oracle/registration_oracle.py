@@ -104,7 +104,7 @@ def vote(modelVerts, surfacePointsScaled, gt_rel, pred_rel, diameter):
 
 def nn_dist(a, b):
     """open3d PointCloud(a).compute_point_cloud_distance(PointCloud(b)): exact 1-NN distances."""
-    return cKDTree(np.asarray(b, np.float64)).query(np.asarray(a, np.float64), k=1)[0]
+    return cKDTree(np.asarray(b, np.float64)).query(np.asarray(a, np.float64), k=1, workers=-1)[0]
 
 
 def chamfer(a, b):
@@ -125,7 +125,7 @@ def chamfer_pairs(pc1, R_pred, R_rel_gt):
 def evaluate_registration(source, target, threshold, T):
     """icp.py:97-99: (fitness, inlier_rmse, correspondences)."""
     src = np.asarray(source, np.float64) @ T[:3, :3].T + T[:3, 3]
-    d, j = cKDTree(np.asarray(target, np.float64)).query(src, k=1)
+    d, j = cKDTree(np.asarray(target, np.float64)).query(src, k=1, workers=-1)
     m = d <= threshold
     n = int(m.sum())
     return n / len(src), (float(np.sqrt((d[m] ** 2).mean())) if n else 0.0), src[m], np.asarray(target, np.float64)[j[m]]

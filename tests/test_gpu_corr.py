@@ -213,6 +213,31 @@ def test_corr_bf16_fallback_list_at_large_P(cuda0, oracle_lib, log2):
     _check_log2(ops, oracle_lib, cuda0, Q, K, atol=4e-4, log2=log2)    # logits up to +-1000 log2 units: f32 ulp 1e-4
 
 
+@pytest.mark.parametrize("fill", ["ff", "neg", "zero"])
+@pytest.mark.parametrize("log2", [True, False])
+def test_corr_single_range_does_not_read_workspace_history(cuda0, oracle_lib, log2, fill):
+    """One key range (N <= 4096) with out-of-range queries: corr_finalize_kernel finishes them and takes |q|^2
+    for the margin test from the workspace.  The cached grow-only 'corr' workspace is filled with NaN bit
+    patterns / negative floats / zeros before the call: the result must not depend on what an earlier call left
+    there (round-2 advisor finding: the direct kernel stored |q|^2 only on the key-split route)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(29)
+    P, N, D = 3000, 1500, 32
+    Q, K, gt = _planted(rng, P, N, D, tau=4.0)
+    hot = rng.choice(P, size=400, replace=False)
+    Q[hot[:200]] *= 60.0
+    Q[hot[200:]] = -Q[hot[200:]] * 30.0 - 8.0 * np.sign(K).mean(0)
+    K[900:1400] = K[:500]                                   # exact ties too: bad queries that need the recheck
+    ws = ops.workspace(cuda0, 64 << 20, "corr")
+    if fill == "ff":
+        ws.fill_(0xFF)
+    elif fill == "neg":
+        ws.view(torch.float32).fill_(-3.0e30)
+    else:
+        ws.zero_()
+    _check_log2(ops, oracle_lib, cuda0, Q, K, atol=4e-4, log2=log2)
+
+
 @pytest.mark.parametrize("log2", [True, False])
 def test_corr_bf16_log2_ties_lowest_key(cuda0, oracle_lib, log2):
     """Duplicate keys: every query has an exact tie — the margin test sends all of them to the exact

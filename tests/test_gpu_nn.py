@@ -80,16 +80,13 @@ def test_nn_large_batch_vote_shape(cuda0, oracle_lib):
 
 
 def _both_paths(cuda0, q, t, Tq, Tt, radius):
-    """The same call through both grid searches and through brute force (ISR_NN_GRID forces the
-    path): everything must agree bit for bit."""
-    import os
+    """The same call through both grid searches and through brute force (the ISR_TUNE_NN_PATH knob
+    forces the path): everything must agree bit for bit."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
     out = {}
-    try:
-        for flag in ("2", "1", "0"):       # block-cooperative grid, per-query grid, brute force
-            os.environ["ISR_NN_GRID"] = flag
+    for flag in ("2", "1", "0"):       # block-cooperative grid, per-query grid, brute force
+        with ops.tuning(nn_path=int(flag)):
             out[flag] = _run(cuda0, q, t, Tq, Tt, radius)
-    finally:
-        os.environ.pop("ISR_NN_GRID", None)
     b = out["0"]
     for flag in ("2", "1"):
         for k in ("nn_idx", "nn_d", "n_in", "sum_d", "sum_d2", "cov"):
@@ -168,10 +165,10 @@ def test_icp_loop_is_identical_on_every_nn_path(cuda0, monkeypatch):
     src = (upper.astype(np.float64) @ R[0].T + t[0]).astype(np.float32)
     init = np.linalg.inv(np.vstack([np.hstack([Rp, tp[:, None]]), [0, 0, 0, 1]]))
     out = {}
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
     for mode in ("0", "1", "2"):
-        monkeypatch.setenv("ISR_NN_GRID", mode)
-        out[mode] = registration.icp_point_to_point(src, lower, 20, init)
-    monkeypatch.delenv("ISR_NN_GRID")
+        with ops.tuning(nn_path=int(mode)):
+            out[mode] = registration.icp_point_to_point(src, lower, 20, init)
     T0, f0, r0 = out["0"]
     assert 0.5 < f0 <= 1.0 and r0 > 1.0          # far from a trivial all-matched case
     for mode in ("1", "2"):

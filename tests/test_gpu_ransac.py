@@ -145,6 +145,7 @@ def test_pnp_ransac_pipeline(cuda0, M, H, kind, seed, confidence):
     o = po.pnp_ransac(p3d, p2d, K, H=H, reperr=2.0, seed=seed, refine_iters=10, confidence=confidence) if M <= 20000 else None
     if o is not None:
         assert o["n_eval"] == H or confidence < 1.0
+        assert int(r.n_eval.item()) == o["n_eval"]
         if o["best"] == int(np.argmax(o["n_inl"])):
             # same winning hypothesis -> same inlier set (bit-exact scoring) -> same refit optimum
             assert np.array_equal(idx, o["inliers"])
@@ -180,6 +181,7 @@ def test_adaptive_termination_follows_the_stopping_rule(cuda0):
         n = int(r.n_inl.item())
         assert int(r.status.item()) == o["status"] == 1
         assert np.array_equal(r.inl_idx[:n].cpu().numpy(), o["inliers"]), (seed, frac, o["n_eval"])
+        assert int(r.n_eval.item()) == o["n_eval"]            # the device reports how many hypotheses it scored
         stops.add(o["n_eval"])
         differs += int(o["best"] != full["best"])
     assert len(stops) >= 3 and differs >= 1, (stops, differs)      # the cases do discriminate

@@ -1,8 +1,7 @@
-"""N > 1 path on CPU: world_size-2 gloo processes exercise the block partition, the pose
-all-gather and the packed (min, idx) all-reduce exactly as the GPU ranks use them."""
+"""N > 1 path on CPU: gloo processes (world size 2, and 8 = BASELINE configs[2]) exercise the block partition,
+the pose all-gather and the exact f64 min-table all-reduce exactly as the GPU ranks use them."""
 import os
 import socket
-import struct
 
 import numpy as np
 import pytest
@@ -24,22 +23,39 @@ def test_block_range_partitions():
             assert covered == list(range(n - 1))
 
 
-def test_pack_min_orders_like_value_then_index():
-    rng = np.random.default_rng(0)
-    vals = np.abs(rng.normal(size=200)).astype(np.float32)
-    vals[10] = vals[3]                       # a tie: the lower index must win
-    packed = [shard.pack_min(float(v), i) for i, v in enumerate(vals)]
-    v, i = shard.unpack_min(min(packed))
-    assert i == int(np.argmin(vals)) and v == vals.min()
-    assert shard.unpack_min(shard.EMPTY)[0] == float("inf")
+def test_first_min_is_the_first_f64_minimum():
+    """verfication.py:105-106: min() / list.index(min) over f64.  Two values that agree to f32 precision must be
+    told apart (round 2 packed f32 bits and picked the lower index), equal f64 values resolve to the lower index."""
+    a = 1.2345678
+    c = np.array([3.0, a + 3e-9, 2.5, a, 9.0, a])             # c[1] and c[3] round to the same f32
+    assert np.float32(c[1]) == np.float32(c[3]) and c[1] != c[3]
+    assert shard.first_min(c) == (3, a)                        # not 1 (f32 tie -> lower index), not 5 (later equal)
+    assert shard.first_min(torch.tensor([np.nan, 2.0, 2.0])) == (1, 2.0)     # a failed image cannot win
     with pytest.raises(ValueError):
-        shard.pack_min(-1.0, 0)
+        shard.first_min(np.array([1.0, -1.0]))
+    with pytest.raises(ValueError):
+        shard.first_min(np.zeros(0))
+    # single process: the table passes through untouched
+    t = torch.tensor(c)
+    assert shard.allreduce_min_table(t, 0, 6) is not None and torch.equal(shard.allreduce_min_table(t, 0, 6), t)
 
 
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _chamfer_table(n):
+    """A fixed (n - 1,) f64 'chamferdis' with (i) a global tie between two ranks' pairs and (ii) an entry that
+    differs from the minimum by less than one f32 ulp and sits at a LOWER index on another rank."""
+    ch = 1.0 + np.abs(np.sin(np.arange(n - 1) * 1.7))
+    lo = ch.min() * 0.5
+    if n - 1 >= 8:
+        ch[n - 3] = lo                       # the f64 minimum, late in the sequence
+        ch[n - 2] = lo                       # equal f64 value after it: the earlier one wins
+        ch[2] = lo * (1.0 + 2.0 ** -30)      # same f32, larger f64, lower index: must NOT win
+    return ch
 
 
 def _worker(rank, size, port, n, ret):
@@ -50,28 +66,35 @@ def _worker(rank, size, port, n, ret):
         full = torch.arange(n * 12, dtype=torch.float64).reshape(n, 12)
         got = shard.allgather_rows(full[lo:hi].clone(), n)
         assert torch.equal(got, full)
-        # every rank proposes the minimum of its own pairs of a fixed vector
-        ch = np.abs(np.sin(np.arange(n - 1) * 1.7)).astype(np.float32)
-        ch[5] = ch[n - 3] = ch.min()          # global tie across ranks: first index wins
+        # every rank contributes its own pairs of a fixed vector (a pair straddling a block boundary belongs to
+        # the lower rank; with n - 1 < size some ranks own nothing)
+        ch = _chamfer_table(n)
         plo, phi = shard.owned_pairs(n, rank, size)
-        loc = (None, 0) if phi <= plo else (float(ch[plo:phi].min()), plo + int(np.argmin(ch[plo:phi])))
-        v, i = shard.allreduce_min_pair(loc[0], loc[1])
-        ret[rank] = (v, i)
+        table = shard.allreduce_min_table(torch.from_numpy(ch[plo:max(phi, plo)].copy()), plo, n - 1)
+        i, v = shard.first_min(table)
+        ret[rank] = (v, i, table.numpy().tobytes(), phi - plo)
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [9, 64])
-def test_world2_gather_and_min_reduce(n):
-    size, port = 2, _free_port()
+@pytest.mark.parametrize("size,n", [(2, 9), (2, 64), (8, 512), (8, 513), (8, 5)])
+def test_gather_and_exact_min_table(size, n):
+    """configs[2] rehearsal: 8 ranks, 512 (and 513: uneven blocks) images; n = 5 leaves ranks without a pair."""
+    port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_worker, args=(size, port, n, ret), nprocs=size, join=True)
-        ch = np.abs(np.sin(np.arange(n - 1) * 1.7)).astype(np.float32)
-        ch[5] = ch[n - 3] = ch.min()
+        ch = _chamfer_table(n)
+        owned = [ret[r][3] for r in range(size)]
+        assert sum(max(o, 0) for o in owned) == n - 1
+        if n == 5:
+            assert min(owned) <= 0                       # at least one rank owned no pair
         for r in range(size):
-            v, i = ret[r]
+            v, i, raw, _ = ret[r]
+            assert raw == ch.tobytes()                   # the reference's whole chamferdis list, bit for bit
             assert i == int(np.argmin(ch)) and v == float(ch.min())
+        if n - 1 >= 8:
+            assert ret[0][1] == n - 3                    # f64 minimum, not the f32-equal entry at index 2
 
 
 def _vote_worker(rank, size, port, n, ret):
@@ -88,8 +111,9 @@ def _vote_worker(rank, size, port, n, ret):
         dist.destroy_process_group()
 
 
-def test_world2_vote_row_sums():
-    size, port, n = 2, _free_port(), 11
+@pytest.mark.parametrize("size,n", [(2, 11), (8, 513)])
+def test_vote_row_sums(size, n):
+    port = _free_port()
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_vote_worker, args=(size, port, n, ret), nprocs=size, join=True)
@@ -97,7 +121,7 @@ def test_world2_vote_row_sums():
         sums = err.sum(1)
         for r in range(size):
             assert ret[r][2] == sums.tolist() and ret[r][0] == int(np.argmax(sums))
-        assert ret[0] == ret[1]
+        assert all(ret[r] == ret[0] for r in range(size))
 
 
 def _pipelined_worker(rank, size, port, n, steps, ret):
@@ -114,10 +138,9 @@ def _pipelined_worker(rank, size, port, n, steps, ret):
 
         def verify(s, poses):
             allp = shard.allgather_rows(poses, n)
-            ch = np.abs(np.sin((allp[:-1, 0].numpy() + s) * 1.3)).astype(np.float32)
+            ch = np.abs(np.sin((allp[:-1, 0].numpy() + s) * 1.3))
             plo, phi = shard.owned_pairs(n, rank, size)
-            loc = (None, 0) if phi <= plo else (float(ch[plo:phi].min()), plo + int(np.argmin(ch[plo:phi])))
-            v, i = shard.allreduce_min_pair(loc[0], loc[1])
+            i, v = shard.first_min(shard.allreduce_min_table(torch.from_numpy(ch[plo:max(phi, plo)].copy()), plo, n - 1))
             return (s, float(allp.sum()), v, i)
 
         out, pending = [], None
@@ -134,13 +157,14 @@ def _pipelined_worker(rank, size, port, n, steps, ret):
         dist.destroy_process_group()
 
 
-def test_world2_pipelined_verification_in_worker_threads():
-    size, port, n, steps = 2, _free_port(), 10, 6
+@pytest.mark.parametrize("size,n", [(2, 10), (8, 67)])
+def test_pipelined_verification_in_worker_threads(size, n):
+    port, steps = _free_port(), 6
     with mp.Manager() as mgr:
         ret = mgr.dict()
         mp.spawn(_pipelined_worker, args=(size, port, n, steps, ret), nprocs=size, join=True)
-        assert ret[0] == ret[1] and [o[0] for o in ret[0]] == list(range(steps))
+        assert all(ret[r] == ret[0] for r in range(size)) and [o[0] for o in ret[0]] == list(range(steps))
         for s, total, v, i in ret[0]:
             allp0 = np.arange(n, dtype=np.float64) + s
-            ch = np.abs(np.sin((allp0[:-1] + s) * 1.3)).astype(np.float32)
+            ch = np.abs(np.sin((allp0[:-1] + s) * 1.3))
             assert total == float((allp0 * 12).sum()) and i == int(np.argmin(ch)) and v == float(ch.min())

@@ -11,7 +11,7 @@ for N in (20000, 50000):
     cloud = torch.from_numpy(synth.tless_like(rng, N)).to(dev)
     Tq, Tt = poses(63), poses(63)
     for plan in ("4,8192", "4,1024", "4,2520", "4,4096", "1,4096", "1,8192", "1,16384"):
-        os.environ["ISR_NN_PLAN"] = plan
+        ops.set_tuning(nn_plan_rq=int(plan.split(",")[0]), nn_plan_blocks=int(plan.split(",")[1]))
         ops.nn_batched(cloud, cloud, Tq, Tt); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -18,16 +18,16 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 cloud = torch.from_numpy(np.ascontiguousarray(synth.tless_like(rng, N))).to(dev)
 Ta = poses(63)
 cases = {"near3deg": poses(63, Ta, 3.0), "mid15deg": poses(63, Ta, 15.0), "random": poses(63)}
-os.environ["ISR_NN_GRID"] = "0"
+ops.set_tuning(nn_path=0)
 for name, Tb in cases.items():
     Tq, Tt = torch.from_numpy(Ta).to(dev), torch.from_numpy(Tb).to(dev)
     ops.nn_batched(cloud, cloud, Tq, Tt); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); [ops.nn_batched(cloud, cloud, Tq, Tt) for _ in range(3)]; e1.record(); torch.cuda.synchronize()
     print(f"N={N} {name:9s} brute {e0.elapsed_time(e1)/3:7.3f} ms", flush=True)
-os.environ["ISR_NN_GRID"] = "2"
+ops.set_tuning(nn_path=2)
 for plan in ("6,16,256", "6,11,64", "6,16,64", "8,11,64", "6,13,64", "5,11,64", "6,16,128", "8,16,64", "6,22,64"):
-    os.environ["ISR_NN_TILE"] = plan
+    ops.set_tile_plan(plan)
     out = []
     for name, Tb in cases.items():
         Tq, Tt = torch.from_numpy(Ta).to(dev), torch.from_numpy(Tb).to(dev)

@@ -3,7 +3,7 @@ three exact NN searches: python tools/time_icp.py.  Also one ICP evaluation pass
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration, synth
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, registration, synth
 rng = np.random.default_rng(20240)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 cloud = synth.tless_like(rng, 4 * N)
@@ -18,9 +18,9 @@ s, l, c = (torch.from_numpy(x).to(dev) for x in (src, lower, cad))
 ref = None
 for mode in ("0", "1", "2", ""):
     if mode:
-        os.environ["ISR_NN_GRID"] = mode
+        ops.set_tuning(nn_path=int(mode))
     else:
-        os.environ.pop("ISR_NN_GRID", None)
+        ops.set_tuning(nn_path=-1)
     T, fit, rmse = registration.icp_point_to_point(s, l, 20, init)
     ch = registration.final_chamfer(s, l, T, c)
     torch.cuda.synchronize()

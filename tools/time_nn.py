@@ -23,7 +23,7 @@ for name, Nq, Nt, B in (("chamfer pairs", 20000, 20000, 63), ("icp step", 20000,
         Tq, Tt = torch.from_numpy(Ta).to(dev), torch.from_numpy(Tb).to(dev)
         res = {}
         for path in ("2", "1", "0"):
-            os.environ["ISR_NN_GRID"] = path
+            ops.set_tuning(nn_path=int(path))
             r = ops.nn_batched(q, t, Tq, Tt); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -33,4 +33,4 @@ for name, Nq, Nt, B in (("chamfer pairs", 20000, 20000, 63), ("icp step", 20000,
         assert np.array_equal(res["1"][1], res["0"][1]) and np.array_equal(res["2"][1], res["0"][1])
         print(f"{name:14s} {kind:6s} Nq={Nq} Nt={Nt} B={B}: tile-grid {res['2'][0]:8.3f} ms | lane-grid {res['1'][0]:8.3f} ms | "
               f"brute {res['0'][0]:8.3f} ms ({Nq*Nt*B/res['0'][0]*1e-9:.2f} Tpairs/s)  brute/tile {res['0'][0]/res['2'][0]:.1f}x")
-os.environ.pop("ISR_NN_GRID", None)
+ops.set_tuning(nn_path=-1)
