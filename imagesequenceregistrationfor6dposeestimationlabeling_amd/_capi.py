@@ -65,6 +65,8 @@ SIGNATURES = {
     "isr_pnp_ransac_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_prep_queries_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_prep_queries": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_prep_queries_batch_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "isr_prep_queries_batch": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr": (_i, [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "isr_p3p_all_roots": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "isr_pnp_ransac_workspace_bytes": (_sz, [_i, _i]),

@@ -328,6 +328,40 @@ def prep_queries(feat: torch.Tensor, mask: torch.Tensor, c0: int = 0, D: int | N
     return Q, pix, n_dev
 
 
+def prep_queries_batch(feat: torch.Tensor, mask: torch.Tensor, c0: int = 0, D: int | None = None, step: int = 3,
+                       dtype: str = "bf16_log2"):
+    """isr_prep_queries_batch: a GROUP of crops in three launches.  feat (B, H, W, C) f32 channels-last; mask
+    (B, H, W) or (B, H, W, k) uint8 (channel 0 is used).  Returns Q (B, S, Dpad) with zero rows past each image's
+    count, pix_xy (B, S, 2) f32, n_dev (B,) i32 — S = ceil(H/step) * ceil(W/step)."""
+    dev = require_cuda(feat, mask)
+    if feat.ndim != 4:
+        raise ValueError(f"prep_queries_batch: feat {tuple(feat.shape)} must be (B, H, W, C)")
+    feat = _f32c(feat)
+    B, H, W, C = feat.shape
+    D = C - c0 if D is None else D
+    if mask.dtype != torch.uint8:
+        mask = (mask != 0).to(torch.uint8)
+    mask = mask.contiguous()
+    stride = 1 if mask.ndim == 3 else mask.shape[3]
+    if tuple(mask.shape[:3]) != (B, H, W):
+        raise ValueError(f"mask {tuple(mask.shape)} does not match the feature maps {(B, H, W)}")
+    code = {"bf16": _capi.DTYPE_BF16, "bf16_log2": _capi.DTYPE_BF16_LOG2, "f32": _capi.DTYPE_F32}[dtype]
+    Dpad = D if dtype == "f32" else (16 if D <= 16 else 32 if D <= 32 else 64 if D <= 64 else 128)
+    if D > 128 or (dtype == "f32" and D > 64):
+        raise ValueError(f"D={D} not supported by K1")
+    S = ((H + step - 1) // step) * ((W + step - 1) // step)
+    Q = torch.empty((B, S, Dpad), dtype=torch.float32 if dtype == "f32" else torch.bfloat16, device=dev)
+    pix = torch.zeros((B, S, 2), dtype=torch.float32, device=dev)
+    n_dev = torch.empty(B, dtype=torch.int32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_prep_queries_batch_workspace_bytes(H, W, step, B), "prep")
+    with torch.cuda.device(dev):
+        rc = L.isr_prep_queries_batch(ptr(feat), B, H, W, C, int(c0), int(D), ptr(mask), int(stride), int(step), code, Dpad,
+                                      ptr(Q), ptr(pix), ptr(n_dev), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_prep_queries_batch")
+    return Q, pix, n_dev
+
+
 IMAGENET_MEAN = (0.485, 0.456, 0.406)      # normalize(), inference.py:135-141
 IMAGENET_STD = (0.229, 0.224, 0.225)
 

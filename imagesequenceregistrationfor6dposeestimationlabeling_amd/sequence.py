@@ -98,6 +98,82 @@ def register_frame(model: SequenceModel, rgb, mask, camparams, encoder, n_feat: 
     return res, n_dev, cam[0]
 
 
+def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tensor, cams, c0: int = 0,
+                   n_feat: int | None = None, down_sample: int = 3, itr: int = 500, reperr: float = 2.0,
+                   seeds=None, refine_iters: int = 10, confidence: float = 0.99, group: int = 64,
+                   n_streams: int = 3) -> tuple[list[ImageResult], torch.Tensor]:
+    """The reference's per-image loop (inference.py:163, 248-293) from the network output on, BATCHED: `feats`
+    (n, H, W, C) channels-last on the device, `masks` (n, H, W[, 3]) uint8 on the device, `cams` (n, 3, 3) the
+    cropped, down-sampled camera matrices (formats.crop_camera).  Per `group` images: ONE isr_prep_queries_batch
+    (three launches), ONE K1 launch on group * S capacity rows (S = ceil(H/ds) * ceil(W/ds); rows past an image's
+    count are zero queries whose results nobody reads), ONE filter / assembly / RANSAC chain (register_group with
+    the ragged counts).  At the reference's shape (75 x 75 crop, D = 12, N = 80 000) a single image is bound by
+    ~45 dependent launches of a few microseconds of work each; a group shares them.  K1 of group g+1 runs on its
+    own stream beside the chain of group g.  Every image's outputs are bit-identical to register_crop's.
+    Returns (results, n_dev (n,) i32 on the device)."""
+    dev = model.keys.device
+    n = feats.shape[0]
+    D = model.keys.shape[1] if n_feat is None else n_feat
+    if model.keys.dtype == torch.bfloat16:
+        dtype = "bf16_log2" if model.log2_queries else "bf16"
+    else:
+        dtype = "f32"
+    cams = np.asarray(cams, np.float64)
+    cams = np.broadcast_to(cams, (n, 3, 3)) if cams.ndim == 2 else cams
+    seeds = list(range(n)) if seeds is None else list(seeds)
+    cur = torch.cuda.current_stream(dev)
+    pool = _stream_pool(dev, max(n_streams, 2))
+    for s in pool:
+        s.wait_stream(cur)
+    k1_stream, side = pool[0], pool[1:]
+    out, counts, keys = [], [], None
+    for gi, g0 in enumerate(range(0, n, group)):
+        g1 = min(n, g0 + group)
+        B = g1 - g0
+        with torch.cuda.stream(k1_stream):
+            Q, pix, n_dev = ops.prep_queries_batch(feats[g0:g1], masks[g0:g1], c0=c0, D=D, step=down_sample, dtype=dtype)
+            if keys is None:
+                keys = model.keys if model.keys.shape[1] == Q.shape[2] else ops._pad_cols(model.keys, Q.shape[2])
+            S = Q.shape[1]
+            idx_g, logp_g = ops.corr_argmax(Q.view(B * S, -1), keys, log2_prescaled=model.log2_queries)
+            done = torch.cuda.Event()
+            done.record(k1_stream)
+        s = side[gi % len(side)]
+        s.wait_event(done)
+        for t in (idx_g, logp_g, pix, n_dev):
+            t.record_stream(s)
+        with torch.cuda.stream(s):
+            keep, M, _ = ops.select_top_batch(logp_g.view(B, S), n_dev=n_dev)
+            p3d, p2d = ops.gather_corr_batch(idx_g.view(B, S), keep, M, model.pts, pix)
+            r = ops.pnp_ransac_batch(p3d, p2d, cams[g0:g1], M, H=itr, reperr=reperr, seeds=seeds[g0:g1],
+                                     refine_iters=refine_iters, confidence=confidence)
+        iv, lv = idx_g.view(B, S), logp_g.view(B, S)
+        out += [ImageResult(r.pose[b], r.status[b:b + 1], r.n_inl[b:b + 1], r.inl_idx[b], keep[b], M[b:b + 1], iv[b], lv[b],
+                            r.n_eval[b:b + 1]) for b in range(B)]
+        counts.append(n_dev)
+    for s in pool:
+        cur.wait_stream(s)
+    _publish(out, cur)
+    n_all = torch.cat(counts)
+    n_all.record_stream(cur)
+    return out, n_all
+
+
+def register_frames(model: SequenceModel, rgbs, masks, camparams, encoder, n_feat: int = 12, down_sample: int = 3,
+                    itr: int = 500, reperr: float = 2.0, seeds=None, refine_iters: int = 10, confidence: float = 0.99,
+                    useMask: bool = True, group: int = 64):
+    """The reference's per-image loop, inference.py:163-293, for a block of frames: the crop front end of every
+    frame on the device in two launches (registration.crop_inputs: mask boxes, crop affines + camera matrices,
+    warps, useMask blanking, normalize), ONE call of `encoder` on the (n, 3, 224, 224) batch (the caller's network,
+    `encoder_rgb` of inference.py:237), then register_crops.  Returns (results, n_dev (n,), camMat (n, 3, 3))."""
+    inputIM, cropMask, cam, _ = registration.crop_inputs(rgbs, masks, camparams, useMask=useMask, down_sample=down_sample)
+    with torch.no_grad():
+        imfeatsfull = torch.movedim(encoder(inputIM), 1, 3)                       # inference.py:236-237
+    res, n_dev = register_crops(model, imfeatsfull, cropMask, cam, n_feat=n_feat, down_sample=down_sample, itr=itr,
+                                reperr=reperr, seeds=seeds, refine_iters=refine_iters, confidence=confidence, group=group)
+    return res, n_dev, cam
+
+
 def _publish(results: list[ImageResult], consumer: torch.cuda.Stream) -> None:
     """The tensors of `results` were allocated on side streams and are about to be read on `consumer`
     (which has been made to wait for those streams).  Tell the caching allocator: without

@@ -118,6 +118,17 @@ int isr_prep_queries(const float* feat, int H, int W, int C, int c0, int D, cons
                      int mask_pix_stride, int step, int dtype, int ldq, void* Q, float* pix_xy,
                      int32_t* n_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
 
+/* The same for a GROUP of B crops as one chain of three launches (image = blockIdx.z): the per-image loop of
+ * inference.py:163, 248-279 batched.  feat (B, H, W, C), mask (B, H, W) x mask_pix_stride bytes per pixel;
+ * Q (B, S, ldq), pix_xy (B, S, 2), n_dev (B).  Rows past n_dev[b] of image b are zero queries: K1 runs ONCE
+ * over the B * S capacity rows (a query's result does not depend on the launch it rides in), and
+ * isr_select_top_batch / isr_gather_corr_batch / isr_pnp_ransac_batch take the ragged counts from n_dev.
+ * Same kernels as isr_prep_queries: image b's rows are bit-identical to the single-image call. */
+size_t isr_prep_queries_batch_workspace_bytes(int H, int W, int step, int B);
+int isr_prep_queries_batch(const float* feat, int B, int H, int W, int C, int c0, int D, const uint8_t* mask,
+                           int mask_pix_stride, int step, int dtype, int ldq, void* Q, float* pix_xy,
+                           int32_t* n_dev, void* ws, size_t ws_bytes, isr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * image front end of the per-image loop, image = blockIdx.z: a group costs two launches
  * isr_mask_bbox       x, y, w, h = cv2.boundingRect(mask[:, :, 0])         inference.py:202

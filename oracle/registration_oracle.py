@@ -122,10 +122,21 @@ def chamfer_pairs(pc1, R_pred, R_rel_gt):
     return np.array(out)
 
 
-def evaluate_registration(source, target, threshold, T):
-    """icp.py:97-99: (fitness, inlier_rmse, correspondences)."""
+def evaluate_registration(source, target, threshold, T, search="f64"):
+    """icp.py:97-99: (fitness, inlier_rmse, correspondences).
+    search = "f64": exact nearest neighbours on doubles (cKDTree; what Open3D's KD-tree does, from memory).
+    search = "f32": the DEVICE's definition of the neighbour — transformed source rounded to f32, squared distances
+    in f32, lowest index on ties (oracle/isr_oracle.c:orc_nn_batched) — distances and sums still in f64.  The two
+    differ only for source points with two targets equidistant to f32 rounding (a relative gap below ~1e-7)."""
     src = np.asarray(source, np.float64) @ T[:3, :3].T + T[:3, 3]
-    d, j = cKDTree(np.asarray(target, np.float64)).query(src, k=1, workers=-1)
+    if search == "f32":
+        from . import cbind
+        o = cbind.nn_batched(np.asarray(source, np.float32), np.asarray(target, np.float32), Tq=np.asarray(T, np.float64)[:3, :],
+                             radius=-1.0, want_cov=False)
+        j = o["nn_idx"][0]
+        d = np.linalg.norm(src - np.asarray(target, np.float64)[j], axis=1)
+    else:
+        d, j = cKDTree(np.asarray(target, np.float64)).query(src, k=1, workers=-1)
     m = d <= threshold
     n = int(m.sum())
     return n / len(src), (float(np.sqrt((d[m] ** 2).mean())) if n else 0.0), src[m], np.asarray(target, np.float64)[j[m]]
@@ -144,17 +155,18 @@ def kabsch(P, Q):
     return T
 
 
-def icp_point_to_point(source, target, threshold, init, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6):
-    """icp.py:101-103 [Open3D defaults from memory].  Returns (T, fitness, rmse, trajectory)."""
+def icp_point_to_point(source, target, threshold, init, max_iter=30, rel_fitness=1e-6, rel_rmse=1e-6, search="f64"):
+    """icp.py:101-103 [Open3D defaults from memory].  Returns (T, fitness, rmse, trajectory).  `search`: see
+    evaluate_registration."""
     T = np.asarray(init, np.float64).copy()
-    fit, rmse, P, Q = evaluate_registration(source, target, threshold, T)
+    fit, rmse, P, Q = evaluate_registration(source, target, threshold, T, search)
     traj = [(T.copy(), fit, rmse)]
     for _ in range(max_iter):
         if len(P) < 3:
             break
         T = kabsch(P, Q) @ T
         pf, pr = fit, rmse
-        fit, rmse, P, Q = evaluate_registration(source, target, threshold, T)
+        fit, rmse, P, Q = evaluate_registration(source, target, threshold, T, search)
         traj.append((T.copy(), fit, rmse))
         if abs(pf - fit) < rel_fitness and abs(pr - rmse) < rel_rmse:
             break

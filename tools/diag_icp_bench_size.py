@@ -1,0 +1,37 @@
+"""ICP at the bench's size (20 000-point halves of the T-LESS-like solid): device loop vs the oracle with the device's
+neighbour definition (f32 search) and vs the oracle with exact f64 neighbours (cKDTree), per iteration count."""
+import sys
+import numpy as np, torch
+sys.path.insert(0, ".")
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration as reg, synth
+from oracle import registration_oracle as ro
+rng = np.random.default_rng(20240)
+N = 20000
+synth.tless_like(rng, N)
+cloud = synth.tless_like(rng, 4 * N)
+upper, lower = synth.split_halves(rng, cloud, N)
+Rg, tg = synth.random_poses(np.random.default_rng(99), 2)
+for k, (rot_deg, trans) in enumerate([(0.012, 0.05), (2.0, 2.0)]):
+    Rp, tp = synth.perturb_pose(np.random.default_rng(7 + k), Rg[k], tg[k], rot_deg, trans)
+    src = (upper.astype(np.float64) @ Rg[k].T + tg[k]).astype(np.float32)
+    init = np.linalg.inv(np.vstack([np.hstack([Rp, tp[:, None]]), [0, 0, 0, 1]]))
+    T64, f64_, r64, traj64 = ro.icp_point_to_point(src, lower, 20, init, search="f64")
+    T32, f32_, r32, traj32 = ro.icp_point_to_point(src, lower, 20, init, search="f32")
+    # neighbours that differ between the two definitions in the first pass
+    s0 = src.astype(np.float64) @ init[:3, :3].T + init[:3, 3]
+    from scipy.spatial import cKDTree
+    d64, j64 = cKDTree(lower.astype(np.float64)).query(s0, k=2, workers=-1)
+    from oracle import cbind
+    j32 = cbind.nn_batched(src, lower, Tq=init[:3, :], want_cov=False)["nn_idx"][0]
+    diff = np.nonzero(j32 != j64[:, 0])[0]
+    gap = (d64[diff, 1] - d64[diff, 0]) / np.maximum(d64[diff, 0], 1e-30)
+    print(f"case {k}: init {rot_deg} deg / {trans} mm; oracle iterations f64 {len(traj64) - 1}, f32 {len(traj32) - 1}; "
+          f"first pass: {len(diff)} of {N} neighbours differ between f32 and f64 search (relative gap to the 2nd neighbour: "
+          f"max {gap.max() if len(gap) else 0:.2e})")
+    for it in [0, 1, 2, 3, 5, 10, 20, 30]:
+        T, fit, rmse = reg.icp_point_to_point(src, lower, 20, init, max_iter=it)
+        a, b = traj32[min(it, len(traj32) - 1)], traj64[min(it, len(traj64) - 1)]
+        print(f"  max_iter={it:2d}: device vs f32-search oracle rot {synth.rot_angle(T[:3,:3], a[0][:3,:3]):.2e} rad "
+              f"|dt| {np.linalg.norm(T[:3,3]-a[0][:3,3]):.2e} mm fit {fit:.6f}/{a[1]:.6f} | vs f64 oracle rot "
+              f"{synth.rot_angle(T[:3,:3], b[0][:3,:3]):.2e} rad |dt| {np.linalg.norm(T[:3,3]-b[0][:3,3]):.2e} mm fit {fit:.6f}/{b[1]:.6f} "
+              f"rmse {rmse:.9f}/{a[2]:.9f}/{b[2]:.9f}")

@@ -1,0 +1,110 @@
+"""The reference's own per-image loop shape (inference.py:163, 248-293; genFeat.py:201), BATCHED:
+1 280 images of a 224 x 224 crop -> 75 x 75 lattice (P_cap = 5 625), D = 12, N = 80 000 keys, through
+sequence.register_crops (isr_prep_queries_batch + ONE K1 launch per group + one filter / RANSAC chain per group)
+against the single-image chain sequence.register_crop.
+
+    python tools/time_ref_shape_batched.py [--batch 64] [--images 1280] [--distinct 128] [--dtype f32|bf16] [--once]
+
+--once: one pass over the distinct crops and nothing else (for rocprofv3 --kernel-trace: launches per image)."""
+import argparse, sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, sequence, synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=64)
+ap.add_argument("--images", type=int, default=1280)
+ap.add_argument("--distinct", type=int, default=128)
+ap.add_argument("--dtype", default="both")
+ap.add_argument("--itr", type=int, default=500)
+ap.add_argument("--once", action="store_true")
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(0)
+N, D, H, W, ds = 80000, 12, 224, 224, 3
+S1 = 75
+pts = synth.tless_like(rng, N)
+keys = synth.unit_keys(rng, N, D, tau=6.0)
+Kc = synth.camera(S1, S1, f=400.0)
+n = args.distinct
+R, t = synth.random_poses(rng, n)
+pts_d, keys_d = torch.from_numpy(pts).to(dev), torch.from_numpy(keys).to(dev)
+g = torch.Generator(device=dev).manual_seed(1)
+feats = torch.empty((n, H, W, 13), dtype=torch.float32, device=dev)
+masks = torch.zeros((n, H, W, 3), dtype=torch.uint8, device=dev)
+counts = []
+for i in range(n):
+    Rt = torch.from_numpy(np.concatenate([R[i], t[i][:, None]], 1)).to(dev)
+    Xc = pts_d.double() @ Rt[:, :3].T + Rt[:, 3]
+    p = Xc @ torch.from_numpy(Kc).to(dev).T
+    uv = p[:, :2] / p[:, 2:3]
+    px = torch.round(uv).long()
+    ok = (px[:, 0] >= 0) & (px[:, 0] < S1) & (px[:, 1] >= 0) & (px[:, 1] < S1) & ((uv - px).abs().max(1).values < 0.45)
+    owner = torch.full((S1 * S1,), -1, dtype=torch.long, device=dev)
+    sel = torch.nonzero(ok)[:, 0]
+    sel = sel[torch.randperm(len(sel), device=dev, generator=g)]
+    owner[px[sel, 1] * S1 + px[sel, 0]] = sel                     # one surface point per lattice pixel
+    hit = torch.nonzero(owner >= 0)[:, 0]
+    rows, cols = hit // S1, hit % S1
+    src = owner[hit]
+    wrong = torch.rand(len(src), device=dev, generator=g) < 0.25
+    src_f = torch.where(wrong, torch.randint(N, (len(src),), device=dev, generator=g), src)
+    feats[i] = 0.3 * torch.randn(H, W, 13, device=dev, generator=g)
+    feats[i, rows * ds, cols * ds, :D] = keys_d[src_f] + 0.2 * torch.randn(len(src), D, device=dev, generator=g)
+    masks[i, rows * ds, cols * ds] = 255
+    counts.append(len(src))
+torch.cuda.synchronize()
+print(f"{n} distinct crops, masked lattice pixels per crop: mean {np.mean(counts):.0f} (min {min(counts)}, max {max(counts)}) of {S1 * S1}; "
+      f"N = {N}, D = {D}, itr = {args.itr}", flush=True)
+cams = np.broadcast_to(Kc, (n, 3, 3))
+reps = max(1, args.images // n)
+
+
+def run(model, label):
+    seeds = list(range(n))
+    if args.once:
+        res, nd = sequence.register_crops(model, feats, masks, cams, n_feat=D, down_sample=ds, itr=args.itr, seeds=seeds,
+                                          refine_iters=6, group=args.batch)
+        torch.cuda.synchronize()
+        return
+    # single-image chain (round 2's path) on a subset
+    m1 = min(n, 64)
+    for i in range(4):
+        sequence.register_crop(model, feats[i:i + 1], masks[i], Kc, n_feat=D, down_sample=ds, itr=args.itr, seed=i, refine_iters=6)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    single = [sequence.register_crop(model, feats[i:i + 1], masks[i], Kc, n_feat=D, down_sample=ds, itr=args.itr, seed=i,
+                                     refine_iters=6)[0] for i in range(m1)]
+    torch.cuda.synchronize()
+    t_single = (time.perf_counter() - t0) / m1
+    # batched
+    ops.enable_timing(True)
+    res, nd = sequence.register_crops(model, feats, masks, cams, n_feat=D, down_sample=ds, itr=args.itr, seeds=seeds,
+                                      refine_iters=6, group=args.batch)
+    torch.cuda.synchronize()
+    ops.drain_timing()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res, nd = sequence.register_crops(model, feats, masks, cams, n_feat=D, down_sample=ds, itr=args.itr, seeds=seeds,
+                                          refine_iters=6, group=args.batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = ops.drain_timing()
+    ops.enable_timing(False)
+    calls, ms, flop = tm["corr_argmax"]
+    same = all(torch.equal(res[i].pose, single[i].pose) and torch.equal(res[i].idx[:counts[i]], single[i].idx[:counts[i]])
+               for i in range(m1))
+    ok = sum(int(r.status.item()) for r in res)
+    errs = [synth.rot_angle(res[i].pose.cpu().numpy()[:, :3], R[i]) for i in range(n) if int(res[i].status.item())]
+    print(f"[{label}] single-image chain: {t_single * 1e3:.3f} ms/image = {1 / t_single:.0f} images/s")
+    print(f"[{label}] batched, {args.batch} images per group, {reps * n} images: {dt / (reps * n) * 1e3:.4f} ms/image = "
+          f"{reps * n / dt:.0f} images/s ({1 / t_single and (reps * n / dt) * t_single:.1f}x the single-image rate); "
+          f"K1 {ms / calls:.3f} ms per launch of {args.batch} x {S1 * S1} rows = {flop / (ms * 1e-3) * 1e-12:.1f} TFLOP/s "
+          f"(2 P N D with D as padded); registered {ok}/{n}, median rot err {np.median(errs):.2e} rad; "
+          f"per-image results identical to the single-image chain: {same}", flush=True)
+
+
+if args.dtype in ("f32", "both"):
+    run(sequence.SequenceModel(keys=keys_d, pts=pts_d), "f32 exact, D = 12")
+if args.dtype in ("bf16", "both"):
+    run(sequence.SequenceModel(keys=keys_d.bfloat16(), pts=pts_d, log2_queries=True), "bf16 log2, D = 12 padded to 16")
