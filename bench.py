@@ -78,6 +78,10 @@ def parse_args():
                          "call uses); 1 scores every hypothesis")
     ap.add_argument("--ablate", default="", help="debug only (not a valid bench line): 'noverify' skips a13-a15")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg")
+    ap.add_argument("--verify", choices=("pick", "vote"), default="pick",
+                    help="verification stage: 'pick' = consecutive-pair Chamfer pick (verfication.py:61-108, the headline); "
+                         "'vote' = the n x n ADD-S vote whose top choice icp.py:37-39 reads (choosePose.py:121-151)")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed oracle re-computation of the last step")
     return ap.parse_args()
 
 
@@ -185,8 +189,17 @@ def cpu_baseline(args, keys_bf16, pts, Q0, pix0, Kcam, upper, lower, cad, R_gt, 
             t = legs()
         out[label] = {"images_per_s": 1.0 / sum(t.values()), "cores": n, "seconds_per_image": t}
     torch.set_num_threads(cores)
+    # ONE full-size leg measured, not scaled (round-2 verdict: the x75 extrapolation of getCors had no check):
+    # the whole image's getCors on all cores, one repetition
+    q_full = Q0.float().cpu() / (ops.LOG2E if args.k1 == "log2" else 1.0)
+    t0 = time.perf_counter()
+    ro.getCors_chunked(q_full, k, chunk=4096)
+    full_s = time.perf_counter() - t0
     return {
         "value": out["all_cores"]["images_per_s"], "unit": "images/s", "cores": cores, "kind": "port",
+        "getCors_full_image": {"measured_s": full_s, "extrapolated_s": out["all_cores"]["seconds_per_image"]["getCors"],
+                               "note": f"all {P} query rows, {cores} threads, one repetition, against the x{P / Ps:.0f} "
+                                       f"extrapolation of the {Ps}-row sample used in `value`"},
         "one_core_value": out["one_core"]["images_per_s"],
         "protocol": "per leg: 1 warm-up + median of 5 (ICP: 3); legs scaled to one image's share of the step",
         "sample": (f"1 image: getCors on {Ps}/{P} query rows (torch-CPU f32) x{P / Ps:.0f}; filter on all {P} values; "
@@ -267,6 +280,87 @@ def spawn_ranks(n: int) -> int:
     return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
 
 
+def measure_nn_vote(cad_d, pts, dev, items=4096):
+    """K3 at the vote's shape (choosePose.py:121-138): `items` ADD-S items of V CAD vertices against N surface points,
+    brute force (the vote's items take nn_search_kernel: queries sit far from their targets), HIP events."""
+    V, N = cad_d.shape[0], pts.shape[0]
+    rng = np.random.default_rng(6)
+    Ra, ta = synth.random_poses(rng, items, tz=0.0, t_sigma=2.0)
+    Rb, tb = synth.random_poses(rng, items, tz=0.0, t_sigma=2.0)
+    Tq = torch.from_numpy(np.concatenate([Ra, ta[:, :, None]], 2)).to(dev)
+    Tt = torch.from_numpy(np.concatenate([Rb, tb[:, :, None]], 2)).to(dev)
+    ops.nn_batched(cad_d, pts, Tq, Tt)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(2):
+        ops.nn_batched(cad_d, pts, Tq, Tt)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / 2
+    n_pairs = float(items) * V * N
+    alg_bytes = 12.0 * V + 12.0 * N + 192.0 * items
+    return {"kernel": "isr_nn_batched on the vote's items (default plan)", "shape": f"{items} items of {V} x {N}",
+            "ms": sec * 1e3, "pairs_per_s": n_pairs / sec, "bound": "f32 VALU (8 FLOP/pair convention)",
+            "valu_frac": 8.0 * n_pairs / sec / PEAK_FP32_VALU, "algorithmic_bytes": alg_bytes,
+            "algorithmic_hbm_frac": alg_bytes / sec / 8.0e12}
+
+
+def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower, cad, max_pairs=63):
+    """UNTIMED tail, rank 0: what the last timed step produced, recomputed by the CPU oracle (round-2 verdict:
+    the bench's own pick / ICP / final Chamfer had never been compared with anything).
+      * K1: the arg-max of 1 024 query rows of the first image against oracle/isr_oracle.c (exact bf16 products);
+      * pick: every consecutive-pair Chamfer value of the last step (up to `max_pairs` pairs, the picked one always
+        among them) against the f64 cKDTree oracle, and the same first minimum (verfication.py:61-108);
+      * ICP + final Chamfer for the picked image (icp.py:83-117) against the oracle loop — with the device's
+        neighbour definition (f32 search: must agree to rounding) and with exact f64 neighbours (Open3D's
+        definition: agrees to well inside north_star's 1e-4 rad / 1e-3 mm)."""
+    from oracle import cbind, registration_oracle as ro
+    out = {}
+    rows = min(1024, Q_rows.shape[0])
+    step = max(1, Q_rows.shape[0] // rows)
+    q = Q_rows[::step][:rows].contiguous()
+    idx_dev, _ = ops.corr_argmax(q, keys, log2_prescaled=model.log2_queries)
+    bits = lambda x: x.cpu().view(torch.int16).numpy().view(np.uint16)
+    o = cbind.corr_argmax_bf16(bits(q), bits(keys), logit_scale=float(np.log(2.0)) if model.log2_queries else 1.0)
+    out["k1_rows_checked"] = int(rows)
+    out["k1_idx_equal_rows"] = int((idx_dev.cpu().numpy() == o["idx"]).sum())
+    poses = np.asarray(last["poses_all"], np.float64).reshape(-1, 3, 4)
+    n = poses.shape[0]
+    pc = pts.cpu().numpy().astype(np.float64)
+    if last.get("chamfer_table") is not None:
+        table = np.asarray(last["chamfer_table"], np.float64)
+        picked = int(last["picked_pair"])
+        sel = np.arange(n - 1) if n - 1 <= max_pairs else np.unique(np.concatenate(
+            [np.linspace(0, n - 2, max_pairs - 1).astype(int), [picked]]))
+        ref = np.array([ro.chamfer(pc.dot(poses[i + 1, :, :3]),
+                                   pc.dot(poses[i, :, :3].T).dot(ro.calculate_relative_pose(R_gt[i], t_gt[i], R_gt[i + 1], t_gt[i + 1])[0]))
+                        for i in sel])
+        out["pairs_checked"] = int(len(sel))
+        out["pairs_total"] = int(n - 1)
+        out["chamfer_max_abs"] = float(np.max(np.abs(table[sel] - ref)))
+        out["pick_idx_equal"] = bool(sel[int(np.argmin(ref))] == picked) if len(sel) == n - 1 else bool(
+            abs(ref[list(sel).index(picked)] - ref.min()) == 0.0)
+    best = int(last["picked_image"])
+    pose = poses[best]
+    src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)
+    init = np.linalg.inv(np.vstack([pose, [0, 0, 0, 1]]))
+    T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init)
+    fc = registration.final_chamfer(src, lower, T, cad)
+    for tag, search in (("", "f32"), ("_f64nn", "f64")):
+        Tr, rfit, rrmse, traj = ro.icp_point_to_point(src, lower, 20, init, search=search)
+        out["icp_rot_rad" + tag] = synth.rot_angle(T[:3, :3], Tr[:3, :3])
+        out["icp_trans_mm" + tag] = float(np.linalg.norm(T[:3, 3] - Tr[:3, 3]))
+        out["icp_iterations" + tag] = [int(len(traj) - 1)]
+        out["final_chamfer_abs" + tag] = float(abs(fc - ro.final_chamfer(src, lower, Tr, cad)))
+    out["icp_fitness_abs"] = float(abs(fit - rfit))
+    out["final_chamfer_device"] = fc
+    out["note"] = ("oracle = oracle/ (C restatement, cKDTree + Kabsch); icp_*: device loop vs the oracle loop with the device's "
+                   "neighbour definition (f32 search, lowest index on ties); *_f64nn: vs exact f64 neighbours (Open3D's "
+                   "definition, unpinned: Open3D absent)")
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -287,6 +381,8 @@ def main():
     keys_f32, pts, upper, lower, cad = make_model(dev, N, D, args.tau)
     keys = keys_f32.bfloat16().contiguous()
     model = sequence.SequenceModel(keys=keys, pts=pts, log2_queries=args.k1 == "log2")
+    cad_d = torch.from_numpy(cad).to(dev)
+    diameter = synth.diameter(pts.cpu().numpy())
     rng = np.random.default_rng(99)
     R_gt, t_gt = synth.random_poses(rng, n_total)          # every rank knows every GT pose (scene_gt.json)
     lo, hi = shard.block_range(n_total, rank, world)
@@ -298,7 +394,7 @@ def main():
     images = [(Q_all[j], pix_all[j]) for j in range(n_local)]
     torch.cuda.synchronize()
 
-    def register(s: int):
+    def register(s: int, confidence: float):
         """Every rank: its block of images through a1-a5.  Enqueue only — returns the device tensors and
         an event that fires when the poses are complete.  Consecutive steps alternate between two
         issuing streams: the driver makes its issuing stream wait for every chain of the step, and
@@ -307,24 +403,30 @@ def main():
             if args.group > 1:
                 res = sequence.register_block(model, Q_all, pix_all, Kcam, itr=args.itr, reperr=2.0,
                                               seed0=(s << 20) + lo, refine_iters=args.refine_iters,
-                                              n_streams=args.streams, group=args.group, confidence=args.confidence)
+                                              n_streams=args.streams, group=args.group, confidence=confidence)
             else:
                 res = sequence.register_images(model, images, Kcam, itr=args.itr, reperr=2.0, seed0=(s << 20) + lo,
                                                refine_iters=args.refine_iters, n_streams=args.streams,
-                                               confidence=args.confidence)
+                                               confidence=confidence)
             poses, status = sequence.stack_poses(res)
+            n_eval = torch.cat([r.n_eval for r in res])
             ev = torch.cuda.Event()
             ev.record(reg_streams[s & 1])
-        return poses, status, ev
+        return poses, status, n_eval, ev
 
     reg_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     tail_stream = torch.cuda.Stream(device=dev, priority=-1)
 
-    def verify(poses, status, ev):
-        """Every rank: pose all-gather + sharded Chamfer pick (one packed all-reduce(MIN)); rank 0: ICP of
-        the picked image's upper half onto the lower half + final Chamfer (a13-a15).  Runs on its own
-        stream and, pipelined, in a worker thread (current device and stream are thread-local; this
-        thread issues the step's collectives, the main thread issues none inside the timed loop)."""
+    def owner_of(image: int) -> int:
+        return next(r for r in range(world) if shard.block_range(n_total, r, world)[0] <= image < shard.block_range(n_total, r, world)[1])
+
+    def verify(poses, status, n_eval, ev):
+        """Every rank: pose all-gather + its share of the verification — `--verify pick`: the consecutive pairs it
+        owns, then ONE all-reduce(MIN) over the f64 table (verfication.py:61-108); `--verify vote`: its rows of the
+        n x n ADD-S vote, then the row-sum all-gather (choosePose.py:121-151 -> icp.py:37-39).  The rank that OWNS the
+        chosen image runs ICP + final Chamfer for it (a14-a15): no rank is the slow one of every step.  Runs on its
+        own stream and, pipelined, in a worker thread (current device and stream are thread-local; this thread
+        issues the step's collectives, the main thread issues none inside the timed loop)."""
         torch.cuda.set_device(dev)
         if args.ablate == "noverify":
             ev.synchronize()
@@ -332,11 +434,20 @@ def main():
         with torch.cuda.stream(tail_stream):
             tail_stream.wait_event(ev)
             poses_all = shard.allgather_rows(poses, n_total)
-            best, ch = sequence.pick_by_chamfer(pts, poses_all, R_gt, t_gt, n_total)
-            out = {"picked_pair": best, "pair_chamfer": ch, "registered_this_rank": int(status.sum().item()),
-                   "images_this_rank": int(status.numel())}
-            if rank == 0:
-                pose = poses_all[best].reshape(3, 4).cpu().numpy()
+            out = {}
+            if args.verify == "vote":
+                Pa = poses_all.reshape(-1, 3, 4)
+                best, top, err = sequence.vote_choose_image(cad_d, pts, R_gt, t_gt, Pa[:, :, :3], Pa[:, :, 3], diameter)
+                out.update(picked_image=best, vote_top5=[int(v) for v in top[:5]], vote_row_sum=float(err.sum(1).max()) if len(err) else None)
+            else:
+                best, ch, table = sequence.pick_by_chamfer_table(pts, poses_all, R_gt, t_gt, n_total)
+                out.update(picked_pair=best, picked_image=best, pair_chamfer=ch, chamfer_table=table)
+            st = status.cpu()
+            out.update(registered_this_rank=int(st.sum().item()), images_this_rank=int(st.numel()),
+                       hypotheses_scored_mean=float(n_eval.float().mean().item()), icp_rank=owner_of(best),
+                       poses_all=poses_all.cpu().numpy())
+            if rank == out["icp_rank"]:
+                pose = out["poses_all"][best].reshape(3, 4)
                 src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)   # icp.py:68
                 init = np.linalg.inv(np.vstack([pose, [0, 0, 0, 1]]))                               # icp.py:88-92
                 T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init)
@@ -345,9 +456,9 @@ def main():
                            trans_err_mm=float(np.linalg.norm(pose[:, 3] - t_gt[best])))
         return out
 
-    def run_steps(first: int, count: int):
+    def run_steps(first: int, count: int, confidence: float):
         """`count` steps.  Pipelined (default): registration of batch s + 1 is enqueued as soon as batch
-        s's registration is, and batch s's verification (all-gather, Chamfer pick, ICP, final Chamfer —
+        s's registration is, and batch s's verification (all-gather, pick or vote, ICP, final Chamfer —
         VALU work and chains of small dependent launches) runs from a worker thread on a high-priority
         stream beside it; the main thread never runs more than one batch ahead.  Batches are
         independent and every step's work is finished before this returns.  --no-pipeline runs
@@ -355,14 +466,14 @@ def main():
         last = None
         if args.no_pipeline or count <= 1:
             for s in range(first, first + count):
-                last = verify(*register(s))
+                last = verify(*register(s, confidence))
             return last
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         pending = deque()
         with ThreadPoolExecutor(max_workers=1) as pool:      # one worker: the collectives keep their order
             for s in range(first, first + count):
-                r = register(s)
+                r = register(s, confidence)
                 while len(pending) >= max(args.depth, 1):
                     last = pending.popleft().result()
                 pending.append(pool.submit(verify, *r))
@@ -376,7 +487,21 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    run_steps(0, args.warmup)
+    def timed(first: int, count: int, confidence: float):
+        barrier()
+        t0 = time.perf_counter()
+        last = run_steps(first, count, confidence)
+        barrier()
+        dt_rank = time.perf_counter() - t0
+        dts = [dt_rank]
+        if world > 1:
+            tt = torch.zeros(world, dtype=torch.float64, device=shard._coll_device())
+            tt[rank] = dt_rank
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            dts = [float(v) for v in tt.cpu()]
+        return last, max(dts), dts
+
+    run_steps(0, args.warmup, args.confidence)
     # K1 with the chip to itself (untimed region, rank 0): the in-step figure below shares the GPU with the
     # RANSAC chains and the previous batch's verification, this one is the kernel alone
     k1_alone_ms = k1_clock_mhz = k1_rechecked = None
@@ -394,22 +519,34 @@ def main():
         k1_clock_mhz = ops.corr_clock_mhz()        # shader clock held under the kernel (s_memtime / s_memrealtime)
         k1_rechecked = ops.corr_recheck_count()
     # untimed region, rank 0: the brute-force NN rate at the Chamfer-pair shape and the exact-f32 K1 on one image
-    nn_live = f32_exact = None
+    nn_live = f32_exact = nn_vote = None
     if rank == 0:
         nn_live = measure_nn(pts, dev)
+        if args.verify == "vote":
+            nn_vote = measure_nn_vote(cad_d, pts, dev, items=min(4096, n_local * n_total))
         f32_exact = measure_k1_f32(Q_all[0], keys_f32, dev, args.k1 == "log2")
     ops.enable_timing(True)
-    barrier()
-    t0 = time.perf_counter()
-    last = run_steps(args.warmup, args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=shard._coll_device())
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+    last, dt, dts = timed(args.warmup, args.steps, args.confidence)
     timing = ops.drain_timing()
     ops.enable_timing(False)
+    # the ICP result of the last step lives on the rank that owned the chosen image: bring it to rank 0
+    if world > 1 and args.ablate != "noverify":
+        vals = torch.zeros(5, dtype=torch.float64, device=shard._coll_device())
+        if rank == last["icp_rank"]:
+            vals[:] = torch.tensor([last["final_chamfer"], last["icp_fitness"], last["icp_rmse"], last["rot_err_rad"],
+                                    last["trans_err_mm"]], dtype=torch.float64)
+        torch.distributed.broadcast(vals, src=last["icp_rank"])
+        v = [float(x) for x in vals.cpu()]
+        last.update(final_chamfer=v[0], icp_fitness=v[1], icp_rmse=v[2], rot_err_rad=v[3], trans_err_mm=v[4])
+    # second short timed loop (untimed for `value`): the same step with EVERY hypothesis scored (confidence 1), so the
+    # line carries the cv2-default figure and the score-everything one side by side
+    all_hyp = None
+    if args.confidence < 1.0 and args.ablate != "noverify":
+        k = max(2, min(4, args.steps))
+        last_all, dt_all, _ = timed(args.warmup + args.steps, k, 1.0)
+        all_hyp = {"value": n_total * k / dt_all, "unit": "images/s", "steps": k, "ms_per_step": dt_all / k * 1e3,
+                   "ransac_confidence": 1.0, "hypotheses_scored_mean": last_all.get("hypotheses_scored_mean"),
+                   "note": "same step, every one of the --itr hypotheses scored (round 1's rule); not `value`"}
 
     if rank == 0:
         calls, ms, flop = timing.get("corr_argmax", (0, 0.0, 0.0))
@@ -424,6 +561,9 @@ def main():
             if rec:
                 traffic, traffic_src = rec["hbm_bytes"], "profiles/k1_hbm_traffic.json: " + rec.get("source", "rocprofv3 --pmc")
         ncalls, nms, pairs = timing.get("nn_batched", (0, 0.0, 0.0))
+        verification = ("consecutive-pair Chamfer pick (one f64 min-table all-reduce)" if args.verify == "pick" else
+                        "n x n ADD-S vote, rows sharded (row-sum all-gather)")
+        last_pub = {k: v for k, v in last.items() if k not in ("poses_all", "chamfer_table")}
         line = {
             "metric": "registered images/sec (T-LESS obj 1-like, synthetic) + final Chamfer error",
             "value": n_total * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
@@ -431,15 +571,20 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[1]: {n_local} images/GPU, {args.width}x{args.height}x{D}-D bf16 "
                                     f"queries vs {N} keys; per image getCors + top-80% filter + PnP-RANSAC "
-                                    f"({args.itr} P3P hypotheses, 2 px); per step consecutive-pair Chamfer pick "
-                                    f"(packed min all-reduce), ICP + final Chamfer on rank 0"),
+                                    f"(<= {args.itr} P3P hypotheses, adaptive at confidence {args.confidence}, 2 px); per step "
+                                    f"{verification}, ICP + final Chamfer on the rank that owns the chosen image"),
+                       "verification": args.verify,
                        "images_per_gpu": n_local, "P": P, "N": N, "D": D, "hypotheses": args.itr,
                        "ransac_confidence": args.confidence,
+                       "hypotheses_scored_mean": last.get("hypotheses_scored_mean"),
                        "parallelism": f"image-sharded x{world}",
                        "step_overlap": ("none" if args.no_pipeline else
-                                        "verification (all-gather, Chamfer pick, ICP, final Chamfer) of batch s "
+                                        "verification (all-gather, pick/vote, ICP, final Chamfer) of batch s "
                                         "overlaps the registration of batch s+1")},
-            "final_chamfer": last.get("final_chamfer"), "last_step": last,
+            "final_chamfer": last.get("final_chamfer"), "last_step": last_pub,
+            "per_rank_ms_per_step": {"min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
+                                     "all": [d / args.steps * 1e3 for d in dts]},
+            "ransac_all_hypotheses": all_hyp,
             "roofline": {"kernel": ("corr_bf16_direct_kernel" if args.k1 == "log2" else "corr_bf16_kernel")
                                    + " (K1 getCors: MFMA GEMM + online LSE + argmax)",
                          "k1_domain": args.k1,
@@ -460,16 +605,23 @@ def main():
                          "exp_per_s": flop / max(calls, 1) / (2.0 * D) / (k1_ms * 1e-3) if calls else 0.0,
                          "f32_exact": f32_exact},
             "roofline_nn": nn_live,
+            "roofline_nn_vote": nn_vote,
             # K3 is no longer one kernel at one rate: single-item calls (ICP steps, final Chamfer) scan every
             # target (nn_search_kernel, VALU-bound), the batched Chamfer pick runs the block-cooperative grid
             # search, which evaluates only the candidates near each query cell.  Reported: the rate in
             # brute-force-EQUIVALENT pairs (B Nq Nt per call) — a throughput figure, not a roofline fraction.
-            "nn_stage": {"kernels": "nn_search_kernel (brute force, B < 4) / nn_tile_search_kernel (grid, batched pick)",
+            "nn_stage": {"kernels": "nn_search_kernel (brute force: ICP, final Chamfer, vote items) / nn_tile_search_kernel "
+                                    "(block-cooperative grid: batched pick)",
                          "equivalent_pairs_per_s": pairs / (nms * 1e-3) if ncalls else 0.0, "calls": ncalls,
                          "ms_per_step": nms / args.steps,
                          "note": "brute-force rate measured live: roofline_nn; DESIGN.md section 4 (K3/K4)"},
             "stage_ms_per_step": {k: v[1] / args.steps for k, v in timing.items()},
         }
+        if not args.no_parity_check and args.ablate != "noverify":
+            try:
+                line["parity_check"] = parity_check(args, model, Q_all[0], keys, pts, last, R_gt, t_gt, upper, lower, cad)
+            except Exception as e:  # the GPU line must survive a checker-side failure
+                line["parity_check"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args, keys, pts, images[0][0], images[0][1], Kcam, upper,

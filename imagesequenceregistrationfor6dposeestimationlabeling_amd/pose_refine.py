@@ -25,11 +25,17 @@ from ._capi import check, current_stream, lib, ptr, require_cuda
 from .registration import _dev
 
 
+INTERPOLATION = {"bilinear": 0, "nearest": 1, "bicubic": 2}     # F.grid_sample's modes -> ISR_INTERP_*
+
+
 class RefineObjective:
     """score(t), grad(t) of pose_refine.py:70-91 for a fixed rotation, evaluated on the device."""
 
     def __init__(self, coord_obj: torch.Tensor, keys_masked: torch.Tensor, query_img: torch.Tensor,
-                 denom_img: torch.Tensor, K_crop, R):
+                 denom_img: torch.Tensor, K_crop, R, interpolation: str = "bilinear"):
+        if interpolation not in INTERPOLATION:
+            raise ValueError(f"interpolation={interpolation!r}: F.grid_sample knows {sorted(INTERPOLATION)}")
+        self.mode = INTERPOLATION[interpolation]
         self.dev = require_cuda(coord_obj, keys_masked, query_img, denom_img)
         self.X = coord_obj.to(torch.float32).contiguous()
         self.keys = keys_masked.to(torch.float32).contiguous()
@@ -47,7 +53,7 @@ class RefineObjective:
         N, e = self.keys.shape
         fn = lib().isr_refine_objective_full if full else lib().isr_refine_objective
         with torch.cuda.device(self.dev):
-            rc = fn(ptr(self.X), ptr(self.keys), N, e, ptr(self.q), ptr(self.den), self.q.shape[0],
+            rc = fn(ptr(self.X), ptr(self.keys), N, e, ptr(self.q), ptr(self.den), self.q.shape[0], self.mode,
                     ctypes.cast(self.K, ctypes.c_void_p), ctypes.cast(rt, ctypes.c_void_p), ptr(self.out), ptr(self.ws),
                     self.ws.numel(), current_stream(self.dev))
         check(rc, "isr_refine_objective")
@@ -101,8 +107,8 @@ def refine_pose(R, t, query_img, renderer, obj_idx, K_crop, obj_, neural_radianc
                 optimize_rotation=False):
     """pose_refine.py:21-104.  Returns (R, t (3,), result.fun).  optimize_rotation=True also refines R (returned
     as Rodrigues(result.x[:3])); the default keeps the reference's behaviour (R constant, returned unchanged)."""
-    if interpolation != 'bilinear':
-        raise ValueError("only interpolation='bilinear' is built (the reference's default)")
+    if interpolation not in INTERPOLATION:
+        raise ValueError(f"interpolation={interpolation!r}: F.grid_sample knows {sorted(INTERPOLATION)}")
     query_img = _dev(query_img, torch.float32)
     h, w, _ = query_img.shape
     assert h == w
@@ -119,7 +125,7 @@ def refine_pose(R, t, query_img, renderer, obj_idx, K_crop, obj_, neural_radianc
     keys_verts = _dev(keys_verts, torch.float32)
     perm = torch.randperm(len(keys_verts), device=dev, generator=generator)[:n_samples_denom]
     denom_img = denominator_image(query_img, keys_verts[perm])
-    obj = RefineObjective(coord_masked.float(), keys_masked.float(), query_img, denom_img, K_crop, R)
+    obj = RefineObjective(coord_masked.float(), keys_masked.float(), query_img, denom_img, K_crop, R, interpolation)
     if optimize_rotation:
         from scipy.spatial.transform import Rotation
         rvec = Rotation.from_matrix(np.asarray(R, np.float64)).as_rotvec()

@@ -343,25 +343,37 @@ def pick_by_chamfer_table(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: 
     return idx, val, table
 
 
-def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, top: int = 50):
+def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, top: int = 50, chunk: int = 4096):
     """choosePose.py:79-151 sharded by rows: every rank holds all n predicted and GT
     poses, builds rows block_range(n, rank, world) of the two relative-pose tables on the device
     (compute_rel_poses, choosePose.py:43-51), evaluates its rows of
         error[i][j] = ADDS(modelVerts, gt_rel[i][j], pred_rel[i][j]) < 0.1 * diameter
     with the batched NN kernel, and all-gathers the int32 row sums; argmax / top-50 are then computed
-    identically on every rank (ties -> lower index).  Returns (image_id, top indices, local error rows)."""
+    identically on every rank (ties -> lower index).  The tables, the ADD-S values and the comparison stay on
+    the device: one copy brings back this rank's error rows (the reference writes them to error.npy), one the
+    row sums.  Returns (image_id, top indices, local error rows (rows, n) f64 of 0/1)."""
     rank, size = shard.world()
     n = len(R_gt)
     lo, hi = shard.block_range(n, rank, size)
-    gt_rel = registration.relative_pose_table(R_gt, t_gt, "choose", rows=(lo, hi)) if hi > lo else np.zeros((0, n, 4, 4))
-    pr_rel = registration.relative_pose_table(R_pred, t_pred, "choose", rows=(lo, hi)) if hi > lo else np.zeros((0, n, 4, 4))
+    dev = registration.device()
     if hi > lo:
-        err, _ = registration.vote_error_rows(model_verts, surface_pts, gt_rel, pr_rel, diameter)
+        v = registration._dev(model_verts, torch.float32)
+        sp = registration._dev(surface_pts, torch.float32)
+        Rg, tg = registration._dev(R_gt, torch.float64), registration._dev(t_gt, torch.float64)     # arrays or tensors
+        Rp, tp = registration._dev(R_pred, torch.float64), registration._dev(t_pred, torch.float64)
+        gt_rel = ops.rel_pose_table(Rg, tg, 0, lo, hi).reshape(-1, 12)        # (rows * n, 12) f64, [R_i^T R_j | t_j - t_i]
+        pr_rel = ops.rel_pose_table(Rp, tp, 0, lo, hi).reshape(-1, 12)
+        parts = [ops.nn_batched(v, sp, gt_rel[s0:s0 + chunk], pr_rel[s0:s0 + chunk]).sum_d
+                 for s0 in range(0, (hi - lo) * n, chunk)]
+        adds = torch.cat(parts).reshape(hi - lo, n) / v.shape[0]
+        err_d = adds < 0.1 * float(diameter)
+        sums_local = err_d.sum(dim=1, dtype=torch.int32)[:, None]
+        err = err_d.to(torch.float64).cpu().numpy()
     else:
         err = np.zeros((0, n))
-    sums_local = torch.from_numpy(err.sum(axis=1).astype(np.int32))[:, None]
-    if size > 1:
-        sums_local = sums_local.to(shard._coll_device())
+        sums_local = torch.zeros((0, 1), dtype=torch.int32, device=dev)
+    if size > 1 and shard._coll_device().type == "cpu":
+        sums_local = sums_local.cpu()
     sums = shard.allgather_rows(sums_local, n)[:, 0].cpu().numpy().astype(np.float64)
     image_id = int(np.argmax(sums))
     return image_id, np.argsort(-sums, kind="stable")[:top], err

@@ -324,15 +324,19 @@ int isr_zbuf_score(const float* obj_pts, int m, const float* Rt, int B, const do
  *   query_img (res,res,e), denom_img (res,res) all f32; Kcrop (9) and Rt (12, [R|t]) HOST doubles.
  *   The reference's rotation is constant inside the objective (pose_refine.py:73-76), so only the
  *   translation gradient exists.  ws >= 64*14*8 + 256 bytes. */
+#define ISR_INTERP_BILINEAR 0
+#define ISR_INTERP_NEAREST 1 /* piecewise constant: the gradient is 0, as torch autograd reports it */
+#define ISR_INTERP_BICUBIC 2 /* cubic convolution A = -0.75, taps clipped to the border, source coordinate not clipped */
+/* `interpolation`: the `mode=` the reference forwards to F.grid_sample (pose_refine.py:60-68), ISR_INTERP_*. */
 int isr_refine_objective(const float* X, const float* keys, int N, int e, const float* query_img,
-                         const float* denom_img, int res, const double* Kcrop, const double* Rt,
+                         const float* denom_img, int res, int interpolation, const double* Kcrop, const double* Rt,
                          double* out4, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* The same objective with the rotation live (the evidently intended variant): out13 (device, 13 f64)
  * = { score, d score / d t (3), d score / d R (9, row-major) }; the caller chains d/dR with the Rodrigues Jacobian.
  * ws >= 64*14*8 + 256 bytes (also enough for isr_refine_objective). */
 int isr_refine_objective_full(const float* X, const float* keys, int N, int e, const float* query_img,
-                              const float* denom_img, int res, const double* Kcrop, const double* Rt,
+                              const float* denom_img, int res, int interpolation, const double* Kcrop, const double* Rt,
                               double* out13, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* a8  ADD(verts, gtR, gtT, R, T)   inference.py:116-117

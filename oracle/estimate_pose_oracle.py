@@ -78,10 +78,21 @@ def corr_matrices_patch(query_img, obj_keys, res, down_sample_scale=3, max_pool=
     m = obj_keys.shape[0]
     R = res * ds
     q = query_img[:R, :R]
-    full = torch.log_softmax(q.reshape(R * R, e) @ obj_keys.T, dim=1).view(R, R, m)
     off = ds // 2
-    centre = full[off::ds, off::ds].reshape(res * res, m)
-    blk = F.max_pool2d(full.permute(2, 0, 1), ds)                                  # (m, res, res)
+    if R * R * m > (1 << 31):
+        # the reference's size (r = 224, m = 80 000): the (R, R, m) matrix is 15.8 GB — the same expressions band by
+        # band of `ds` pixel rows (log_softmax is per pixel and a block never crosses a band)
+        centre = torch.empty((res, res, m))
+        blk = torch.empty((m, res, res))
+        for b in range(res):
+            band = torch.log_softmax(q[b * ds:(b + 1) * ds].reshape(ds * R, e) @ obj_keys.T, dim=1).view(ds, R, m)
+            centre[b] = band[off, off::ds]
+            blk[:, b] = F.max_pool2d(band.permute(2, 0, 1), ds)[:, 0]
+        centre = centre.reshape(res * res, m)
+    else:
+        full = torch.log_softmax(q.reshape(R * R, e) @ obj_keys.T, dim=1).view(R, R, m)
+        centre = full[off::ds, off::ds].reshape(res * res, m)
+        blk = F.max_pool2d(full.permute(2, 0, 1), ds)                              # (m, res, res)
     if max_pool:
         blk = F.max_pool2d(blk, kernel_size=3, stride=1, padding=1)
     return blk.permute(1, 2, 0).reshape(res * res, m).contiguous(), centre.contiguous()

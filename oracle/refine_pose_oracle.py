@@ -15,7 +15,7 @@ def sample(img, p_img_norm, interpolation="bilinear"):
     return samples[0, :, 0].T
 
 
-def objective(t, R, coord_masked, keys_masked, query_img, denom_img, K_crop, return_grad=False):
+def objective(t, R, coord_masked, keys_masked, query_img, denom_img, K_crop, return_grad=False, interpolation="bilinear"):
     """pose_refine.py:70-91 with pose[3:] = t.  All tensors torch-CPU f32."""
     res = query_img.shape[0]
     tt = torch.tensor(np.asarray(t, np.float64), dtype=torch.float32, requires_grad=return_grad)
@@ -25,13 +25,14 @@ def objective(t, R, coord_masked, keys_masked, query_img, denom_img, K_crop, ret
     p_img = X @ P.T
     p_img = p_img[..., :2] / p_img[..., 2:]
     p_norm = (p_img + 0.5) * (2 / res) - 1
-    q = sample(query_img, p_norm)
+    q = sample(query_img, p_norm, interpolation)
     log_nom = (keys_masked * q).sum(dim=-1)
-    log_den = sample(denom_img, p_norm)[:, 0]
+    log_den = sample(denom_img, p_norm, interpolation)[:, 0]
     score = -(log_nom.mean() - log_den.mean()) / 2
     if return_grad:
         score.backward()
-        return score.item(), tt.grad.detach().numpy().astype(np.float64)
+        g = tt.grad if tt.grad is not None else torch.zeros(3)
+        return score.item(), g.detach().numpy().astype(np.float64)
     return score.item()
 
 

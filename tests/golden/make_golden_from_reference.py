@@ -19,6 +19,7 @@ reference text is stored.
   ref_normalize.npz      normalize             inference.py:135-141
   ref_estimate_front.npz estimate_pose front   poseEstSurf.py:37-107 (statements; both avg_queries branches)
   ref_refine_objective.npz  refine_pose `sample` + objective body   pose_refine.py:60-68, 78-87 (statements)
+  ref_refine_modes.npz      the same with interpolation = 'nearest' / 'bicubic'   (`... make_golden_from_reference.py refine_modes`)
 
 Not reproducible this way (cv2 / open3d / torch_scatter are absent and must not be stood in for):
 pnp (inference.py:123-134), estimate_pose's P3P loop and batch_score (poseEstSurf.py:133-237),
@@ -233,5 +234,44 @@ def main():
     print("wrote", sorted(p.name for p in OUT.glob("ref_*.npz")))
 
 
+def refine_modes():
+    """refine_pose's objective with interpolation = 'nearest' / 'bicubic' (pose_refine.py:60-68 forwards `mode=` to
+    F.grid_sample): the reference's own `sample` + objective statements executed under autograd.  Own RNG stream, so the
+    files main() writes do not move.  -> ref_refine_modes.npz"""
+    rng = np.random.default_rng(20261005)
+    base = {"torch": torch, "np": np, "F": F}
+    sample_def = ref_statements("pose_refine.py", 60, 68, ("F.grid_sample", "padding_mode"))
+    body = ref_statements("pose_refine.py", 78, 87, ("p_img_norm", "log_nominator", "score"))
+    res, e, Npt = 32, 12, 150
+    query_img = torch.from_numpy(rng.normal(size=(res, res, e)).astype(np.float32))
+    denom_img = torch.from_numpy(rng.normal(size=(res, res, 1)).astype(np.float32) + 5)
+    keys_masked = torch.from_numpy(rng.normal(size=(Npt, e)).astype(np.float32))
+    X = rng.normal(size=(Npt, 3)).astype(np.float32) * 20
+    coord_masked = torch.from_numpy(np.concatenate([X, np.ones((Npt, 1), np.float32)], 1))
+    K_crop = torch.tensor([[45.0, 0, 15.5], [0, 45.0, 15.5], [0, 0, 1]])
+    Rm = torch.from_numpy(random_rotation(rng).astype(np.float32))
+    out = dict(query_img=query_img.numpy(), denom_img=denom_img.numpy()[..., 0], keys=keys_masked.numpy(), X=X,
+               K_crop=K_crop.numpy().astype(np.float64), R=Rm.numpy().astype(np.float64))
+    ts = [(1.5, -2.0, 120.0), (1.5, -2.0, 60.0), (1.5, -2.0, 35.0)]     # the last pushes projections across the border
+    out["t"] = np.array(ts, np.float64)
+    for mode in ("nearest", "bicubic"):
+        scores, grads = [], []
+        for tv in ts:
+            tvec = torch.tensor(tv, requires_grad=True)
+            ns = dict(base, interpolation=mode, query_img=query_img, denom_img=denom_img, keys_masked=keys_masked,
+                      coord_masked=coord_masked, K_crop=K_crop, res_crop=res, Rt=torch.cat((Rm, tvec[:, None]), dim=1))
+            exec(sample_def, ns)
+            exec(body, ns)
+            ns["score"].backward()
+            scores.append(ns["score"].item())
+            grads.append(tvec.grad.numpy().copy())
+        out[f"score_{mode}"] = np.array(scores)
+        out[f"grad_t_{mode}"] = np.array(grads)
+    np.savez_compressed(OUT / "ref_refine_modes.npz", **out)
+    print("wrote ref_refine_modes.npz", {k: out[k] for k in out if k.startswith(("score", "grad"))})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "refine_modes":
+        sys.exit(refine_modes())
     sys.exit(main())

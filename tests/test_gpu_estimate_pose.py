@@ -190,6 +190,13 @@ def test_zbuf_score_vs_oracle(cuda0):
     assert int(torch.argmax(got[0][:-1]).item()) == 0                 # the true pose scores best
 
 
+def ops_corr_raw(pes, args, dev):
+    """The unpooled log-softmax matrix estimate_pose samples from (avg_queries=True)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    _, _, _, q, _ = pes.prepare(args[0].to(dev), args[1].to(dev))
+    return ops.corr_logsoftmax(q, args[4].to(dev))
+
+
 def test_estimate_pose_end_to_end(cuda0):
     from imagesequenceregistrationfor6dposeestimationlabeling_amd import pose_est_surf as pes
     from oracle import estimate_pose_oracle as eo
@@ -202,11 +209,18 @@ def test_estimate_pose_end_to_end(cuda0):
     R, t, ps, ms, cs, d2, sz, nm = out
     assert R.shape[1:] == (3, 3) and R.is_cuda and ps.shape == (R.shape[0],)
     assert d2.shape == sz.shape == nm.shape
-    # same samples -> (almost) the same surviving hypotheses; compare the winners
-    assert abs(len(d2) - len(rd2)) <= 0.05 * len(rd2)
-    assert abs(R.shape[0] - rR.shape[0]) <= 0.1 * max(rR.shape[0], 1)
+    # Independent pipelines (device matrix vs oracle matrix: 1e-5 apart, device P3P vs Grunert + numpy.roots): count what
+    # differs and why, instead of allowing percentages (the stage-by-stage test below feeds both the SAME inputs)
+    ci_d = pes.sample(ops_corr_raw(pes, args, cuda0), pes.prepare(args[0].to(cuda0), args[1].to(cuda0))[2], 1.5, 1500, 11).cpu().numpy()
+    ci_o = inter["corr_idx"]
+    n_other = int((~(ci_d == ci_o).all(axis=1)).sum())     # samples drawn differently: the two matrices differ by ~1e-5
+    assert n_other <= 0.05 * len(ci_o), n_other
+    # per solved sample the reference keeps one entry: on identical samples the two P3P solvers disagree about
+    # solvability only on marginal 3-point problems (rounded pixels; <= 7 % in test_p3p_samples_vs_oracle)
+    assert abs(len(d2) - len(rd2)) <= n_other + 0.07 * len(rd2)
+    assert abs(R.shape[0] - rR.shape[0]) <= n_other + 0.07 * max(rR.shape[0], 1)
     best, rbest = int(torch.argmax(ps).item()), int(torch.argmax(rps).item())
-    assert abs(ps[best].item() - rps[rbest].item()) < 0.02 * abs(rps[rbest].item())
+    assert abs(ps[best].item() - rps[rbest].item()) < 1e-2
     Rb = R[best].cpu().numpy().astype(np.float64)
     # the device's winner is the oracle's winner (same samples, same P3P roots, same scores) ...
     assert synth.rot_angle(Rb, rR[rbest].numpy().astype(np.float64)) < 1e-3
@@ -223,3 +237,135 @@ def test_estimate_pose_end_to_end(cuda0):
     b3 = int(torch.argmax(o3[2]).item())
     assert o3[0].shape[0] > 0 and bool(torch.isfinite(o3[2][b3]))
     assert synth.rot_angle(o3[0][b3].cpu().numpy().astype(np.float64), s["R"]) < 0.5
+
+
+def _scene_ref(seed=7, r=224, e=12, m=80000, f=700.0):
+    """_scene at the reference's own size (poseEstSurf.py:11-15 as called from inference.py: a 224 x 224 crop, 12-D
+    descriptors, m = 80 000 surface points, genFeat.py:201), vectorised."""
+    rng = np.random.default_rng(seed)
+    pts = synth.bumpy_ellipsoid(rng, m)
+    nrm = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+    keys = synth.unit_keys(rng, m, e, tau=6.0)
+    R, t = synth.random_poses(rng, 1, tz=420.0, t_sigma=5.0)
+    R, t = R[0], t[0]
+    K = np.array([[f, 0, r / 2 - 0.5], [0, f, r / 2 - 0.5], [0, 0, 1]])
+    uv = synth.project(K, R, t, pts)
+    cam = pts.astype(np.float64) @ R.T + t
+    vis = (nrm @ R.T * cam).sum(1) < 0
+    ui, vi = np.rint(uv[:, 0]).astype(int), np.rint(uv[:, 1]).astype(int)
+    ok = np.nonzero(vis & (ui >= 0) & (ui < r) & (vi >= 0) & (vi < r))[0]
+    ok = ok[np.argsort(-cam[ok, 2])]                                 # nearest written last
+    mask_lgts = np.full((r, r), -6.0, np.float32)
+    query = (0.3 * rng.normal(size=(r, r, e))).astype(np.float32)
+    mask_lgts[vi[ok], ui[ok]] = 6.0
+    query[vi[ok], ui[ok]] = keys[ok] + 0.2 * rng.normal(size=(len(ok), e)).astype(np.float32)
+    return dict(pts=pts, normals=nrm, keys=keys, R=R, t=t, K=K, mask_lgts=mask_lgts, query=query,
+                diameter=synth.diameter(pts), r=r, e=e, m=m)
+
+
+@pytest.mark.parametrize("avg_queries", [True, False])
+def test_estimate_pose_reference_size_stage_by_stage(cuda0, avg_queries):
+    """estimate_pose at the reference's size — r = 224, e = 12, scale 3 (res 74, n = 5 476), m = 80 000,
+    max_poses = 10 000, max_pose_evaluations = 1 000, batches of 500 — both avg_queries branches, each stage against
+    oracle/estimate_pose_oracle.py on the SAME inputs (the previous stage's device output), every mismatch counted
+    and explained, then the end-to-end call against the composition of the stages."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, pose_est_surf as pes
+    from oracle import estimate_pose_oracle as eo
+    s = _scene_ref()
+    r, m, ds, S, seed = s["r"], s["m"], 3, 10000, 23
+    ml_h, q_h, keys_h, pts_h = (torch.from_numpy(s[k]) for k in ("mask_lgts", "query", "keys", "pts"))
+    ml_d, q_d, keys_d, pts_d = (x.to(cuda0) for x in (ml_h, q_h, keys_h, pts_h))
+    # ---- stage 1: pooling (poseEstSurf.py:47-69)
+    mlp, nmlp, mprob, queries, res = pes.prepare(ml_d, q_d, ds, True)
+    rmlp, rnmlp, rmprob, rqueries, rres = eo.prepare(ml_h, q_h, ds, True)
+    assert res == rres == 74
+    for a, b in ((mlp, rmlp), (nmlp, rnmlp), (mprob, rmprob), (queries, rqueries)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=2e-6, rtol=1e-6)
+    # ---- stage 2: the (n x m) log-softmax matrices (:70-107) — 1.75 GB each
+    if avg_queries:
+        corr_raw = ops.corr_logsoftmax(queries, keys_d)
+        corr_blk = corr_raw
+        rcorr_log, rcorr_raw = eo.corr_matrices(rqueries, keys_h, rmprob, res, True)
+    else:
+        corr_raw, corr_blk, _ = pes.patch_corr(q_d, keys_d, ds)
+        rcorr_log, rcorr_raw = eo.corr_matrices_patch(q_h, keys_h, res, ds, True)
+    corr_log = pes.pool_corr(corr_blk, res)
+    assert corr_raw.shape == (res * res, m)
+    d_raw = (corr_raw.cpu() - rcorr_raw).abs().max().item()
+    d_log = (corr_log.cpu() - rcorr_log).abs().max().item()
+    assert d_raw < 5e-5 and d_log < 5e-5, (d_raw, d_log)
+    del rcorr_raw
+    # ---- stage 3: inversion sampling (:111-119) on the SAME matrix: f64 cumsum + searchsorted in the oracle
+    corr_idx = pes.sample(corr_raw, mprob, 1.5, S, seed)
+    ref_idx = eo.sample(corr_raw.cpu(), mprob.cpu(), 1.5, S, seed)
+    got_idx = corr_idx.cpu().numpy()
+    n_diff = int((got_idx != ref_idx).sum())
+    assert n_diff <= 20 and np.abs(got_idx - ref_idx).max() <= 1, n_diff      # a uniform within rounding of a boundary
+    # ---- stage 4: P3P per sample (:137-145) on the device's samples
+    Ks = pes._k_scaled(s["K"], ds)
+    poses_d, ok_d = pes.p3p_samples(corr_idx, res, m, pts_d, Ks, seed)
+    poses, ok = poses_d.cpu().numpy(), ok_d.cpu().numpy().astype(bool)
+    p2d_idx, p3d_idx = got_idx // m, got_idx % m
+    p2d = np.stack([p2d_idx % res, p2d_idx // res], axis=-1).astype(np.float64)
+    X = s["pts"].astype(np.float64)[p3d_idx]
+    pk = eo.picks(S, seed)
+    all_roots, n_roots = ops.p3p_all_roots(torch.from_numpy(X[:, :3]).to(cuda0), torch.from_numpy(p2d[:, :3]).to(cuda0), Ks)
+    n_roots = n_roots.cpu().numpy()
+    sub = np.arange(0, S, 4)                                          # every 4th sample through the NumPy P3P
+    root_count_differs = pick_differs = 0
+    for i in sub:
+        if len(set(got_idx[i].tolist())) < 4:
+            assert not ok[i]
+            continue
+        sols = eo.p3p_sorted(X[i], p2d[i], Ks)
+        if len(sols) != n_roots[i]:
+            root_count_differs += 1                                   # a root pair about to merge / a sliver triangle
+            continue
+        assert bool(sols) == bool(ok[i]), i
+        if sols:
+            Rr, tr = sols[int((int(pk[i]) * len(sols)) >> 32)]
+            pick_differs += int(not (synth.rot_angle(Rr, poses[i][:, :3]) < 1e-5 and np.linalg.norm(tr - poses[i][:, 3]) < 1e-3))
+    assert root_count_differs <= 0.07 * len(sub), root_count_differs
+    assert pick_differs <= 0.01 * len(sub), pick_differs              # 4th-point-error ties between two roots
+    # ---- stage 5: pruning masks and the ordered selection (:147-177) from the device's poses
+    nrm_d = torch.from_numpy(s["normals"].astype(np.float64)).to(cuda0)
+    dist, sm, nm, keep, kidx, nk, Rt32 = pes.prune(corr_idx, poses_d, ok_d, pts_d, nrm_d, res, m, Ks[0, 0], s["diameter"], 0.1,
+                                                   True, 1000)
+    rd, rdm, rsm, rnm = eo.prune_masks(poses, p2d.astype(np.float32), X, s["normals"].astype(np.float64)[p3d_idx[:, :3]], Ks,
+                                       s["diameter"], res)
+    assert np.array_equal(dist.cpu().numpy(), rd.astype(np.float32))
+    assert np.array_equal(sm.cpu().numpy().astype(bool), rsm) and np.array_equal(nm.cpu().numpy().astype(bool), rnm)
+    want = ok & rdm & rsm & rnm
+    n_keep = int(nk.item())
+    assert n_keep == want.sum() > 100 and np.array_equal(kidx[:n_keep].cpu().numpy(), np.nonzero(want)[0])
+    first = np.nonzero(want)[0][:1000]
+    assert np.array_equal(Rt32[:len(first)].cpu().numpy(), poses[first].astype(np.float32))
+    # ---- stage 6: batch_score (:182-237) for the selected poses, batches of 500, on the SAME matrices
+    n_poses = len(first)
+    Rsel, tsel = Rt32[:n_poses, :, :3].contiguous(), Rt32[:n_poses, :, 3].contiguous()
+    Kt = torch.from_numpy(Ks).float()
+    corr_log_h, mlp_h, nmlp_h = corr_log.cpu(), mlp.cpu(), nmlp.cpu()
+    worst = 0.0
+    ps_all = []
+    for l in range(0, n_poses, 500):
+        got = pes.zbuf_score(pts_d, Rsel[l:l + 500], tsel[l:l + 500], Ks, res, mlp, nmlp, corr_log)
+        ref = eo.batch_score(Rsel[l:l + 500].cpu(), tsel[l:l + 500].cpu(), Kt, pts_h, res, mlp_h, nmlp_h, corr_log_h)
+        ps_all.append(got[0])
+        for g, r_ in zip(got, ref):
+            g, r_ = g.cpu().numpy(), r_.numpy()
+            assert np.array_equal(np.isinf(g), np.isinf(r_))
+            fin = np.isfinite(r_)
+            worst = max(worst, float(np.abs(g[fin] - r_[fin]).max()) if fin.any() else 0.0)
+    # a vertex whose projection sits on a .5 boundary may round to the other pixel under a different f32 evaluation
+    # order; scores are means over ~5 000 pixels of values of a few units
+    assert worst < 1e-3, worst
+    ps_all = torch.cat(ps_all)
+    # ---- end to end: the one call = the composition of the stages above (same seed)
+    out = pes.estimate_pose(ml_d, q_d, pts_d, s["normals"], keys_d, s["diameter"], s["K"], max_poses=S,
+                            max_pose_evaluations=1000, avg_queries=avg_queries, seed=seed)
+    Rn, tn, ps, ms, cs, d2, sz, nmk = out
+    assert Rn.shape == (n_poses, 3, 3) and torch.equal(Rn, Rsel) and torch.equal(tn, tsel)
+    assert torch.equal(ps, ps_all)
+    assert np.array_equal(d2, rd.astype(np.float32)[ok]) and np.array_equal(sz, rsm[ok]) and np.array_equal(nmk, rnm[ok])
+    best = int(torch.argmax(ps).item())
+    assert synth.rot_angle(Rn[best].cpu().numpy().astype(np.float64), s["R"]) < 0.15       # a sane coarse estimate

@@ -104,3 +104,24 @@ def test_refine_objective_vs_reference_statements(cuda0):
         pose = np.concatenate([np.zeros(3), t])
         assert abs(obj(pose) - s) <= 2e-5 * max(1.0, abs(s))
         np.testing.assert_allclose(obj(pose, return_grad=True)[3:], gr, rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bicubic"])
+def test_refine_objective_modes_vs_reference_statements(cuda0, mode):
+    """isr_refine_objective with ISR_INTERP_NEAREST / ISR_INTERP_BICUBIC vs pose_refine.py:60-68, 78-87 executed from the
+    reference with interpolation = 'nearest' / 'bicubic' under autograd (nearest: zero gradient there and here)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import pose_refine
+    g = np.load(G / "ref_refine_modes.npz")
+    q, den = torch.from_numpy(g["query_img"]).to(cuda0), torch.from_numpy(g["denom_img"]).to(cuda0)
+    obj = pose_refine.RefineObjective(torch.from_numpy(g["X"]).to(cuda0), torch.from_numpy(g["keys"]).to(cuda0), q, den,
+                                      g["K_crop"], g["R"], interpolation=mode)
+    for t, s, gr in zip(g["t"], g[f"score_{mode}"], g[f"grad_t_{mode}"]):
+        pose = np.concatenate([np.zeros(3), t])
+        # nearest is discontinuous: a sample within f32 rounding of a half-integer may land on the neighbouring pixel
+        # (the reference evaluates the coordinates in f32, the kernel in f64): one of 150 points moves the mean by < 2e-2
+        tol = 2e-2 if mode == "nearest" else 5e-5 * max(1.0, abs(s))
+        assert abs(obj(pose) - s) <= tol
+        np.testing.assert_allclose(obj(pose, return_grad=True)[3:], gr, rtol=5e-3, atol=2e-6)
+    with pytest.raises(ValueError):
+        pose_refine.RefineObjective(torch.from_numpy(g["X"]).to(cuda0), torch.from_numpy(g["keys"]).to(cuda0), q, den,
+                                    g["K_crop"], g["R"], interpolation="lanczos")

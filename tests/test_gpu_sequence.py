@@ -167,3 +167,33 @@ def test_vote_choose_image_config1_size(cuda0):
     sums = rerr.sum(1)
     assert img == int(np.argmax(sums)) and img != 5 and sums[5] == sums.min()
     assert list(top) == list(np.argsort(-sums, kind="stable")[:50])
+
+
+def test_vote_choose_image_bench_shape_sampled_rows(cuda0):
+    """The vote at the bench's shape (bench.py --verify vote: n = 64 images, V = 5 000 CAD vertices, N = 20 000
+    surface points of the T-LESS-like solid -> 4 096 ADD-S items in one launch): rows 0, 17, 40 and 63 of the error
+    matrix against the oracle's loop with the reference's own sklearn KDTree(leaf_size=2) (choosePose.py:121-138);
+    predicted poses a few degrees off with some failures, so that both outcomes of the 0.1 * diameter test occur."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence
+    from oracle import registration_oracle as ro
+    rng = np.random.default_rng(20240)
+    S = synth.tless_like(rng, 20000)
+    V = synth.tless_like(rng, 5000)
+    diam = synth.diameter(S)
+    n = 64
+    Rg, tg = synth.random_poses(rng, n)
+    deg = rng.choice([0.5, 4.0, 9.0, 14.0], size=n)
+    deg[[3, 29, 50]] = 90.0
+    P = [synth.perturb_pose(rng, Rg[i], tg[i], deg[i], 1.0) for i in range(n)]
+    Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
+    img, top, err = sequence.vote_choose_image(V, S, Rg, tg, Rp, tp, diam)
+    assert err.shape == (n, n) and 0.1 < err.mean() < 0.95                         # a discriminating case
+    rows = [0, 17, 40, 63]
+    gt_rel, pr_rel = ro.rel_pose_table(Rg, tg), ro.rel_pose_table(Rp, tp)
+    rerr, radds = ro.vote(V.astype(np.float64), S.astype(np.float64), gt_rel[rows], pr_rel[rows], diam)
+    margin = np.abs(radds - 0.1 * diam)
+    assert margin.min() > 1e-3                                                     # no item sits on the threshold
+    assert np.array_equal(err[rows], rerr)
+    sums = err.sum(1)
+    assert img == int(np.argmax(sums)) and img not in (3, 29, 50)
+    assert list(top) == list(np.argsort(-sums, kind="stable")[:50])

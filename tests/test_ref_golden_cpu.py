@@ -114,3 +114,15 @@ def test_refine_objective_matches_reference_statements():
         val, grad = rpo.objective(t, g["R"], X, keys, q, den, g["K_crop"], return_grad=True)
         assert abs(val - s) <= 1e-6 * max(1.0, abs(s))
         np.testing.assert_allclose(grad, gr, rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("mode", ["nearest", "bicubic"])
+def test_refine_objective_modes_match_reference_statements(mode):
+    """The same statements with interpolation = 'nearest' / 'bicubic' (pose_refine.py:60-68 forwards `mode=`)."""
+    g = np.load(G / "ref_refine_modes.npz")
+    q, den = torch.from_numpy(g["query_img"]), torch.from_numpy(g["denom_img"])[..., None]
+    keys, X = torch.from_numpy(g["keys"]), torch.from_numpy(g["X"])
+    for t, s, gr in zip(g["t"], g[f"score_{mode}"], g[f"grad_t_{mode}"]):
+        val, grad = rpo.objective(t, g["R"], X, keys, q, den, g["K_crop"], return_grad=True, interpolation=mode)
+        assert abs(val - s) <= 1e-6 * max(1.0, abs(s))
+        np.testing.assert_allclose(grad, gr, rtol=1e-4, atol=1e-7)
