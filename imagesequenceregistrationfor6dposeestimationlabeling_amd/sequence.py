@@ -306,6 +306,44 @@ def stack_poses(results: list[ImageResult]) -> tuple[torch.Tensor, torch.Tensor]
             torch.cat([r.status for r in results]))
 
 
+def acceptance_counts(model_verts, surface_pts, R_gt, t_gt, poses: torch.Tensor, status: torch.Tensor, diameter: float,
+                      dataset: str = "tless", names=None) -> dict:
+    """The per-image acceptance bookkeeping of inference.py:300-320 for a whole block of registered images in two
+    launches instead of two KD-tree builds per image:
+        final_error  = ADDS(modelVerts, gtR, gtT, R2, T2)            (dataset == "tless";  ADD otherwise)
+        final_errorR = ADDS(modelVerts, gtR, 0, R2, 0)               (rotation only)
+        workCT += final_error < 0.1 * diameter;  rotWorkCT += final_errorR < 0.1 * diameter
+        correct_predicted_ids.append(name)  for accepted images      (-> correctly_predicted_list.txt, :369-374)
+    poses (n, 12) [R|t] f64 and status (n,) on the device (sequence.stack_poses).  An image whose pnp failed (status
+    0; the reference's `(1, 1, 1)` sentinel would raise inside ADDS there) is never accepted: its errors are inf.
+    Returns {final_error (n,), final_errorR (n,), work (n,) bool, rot_work (n,) bool, workCT, rotWorkCT,
+    correct_predicted_ids}."""
+    v = registration._dev(model_verts, torch.float32)
+    n = poses.shape[0]
+    Tp = poses.reshape(n, 3, 4).to(torch.float64)
+    Tg = torch.cat([registration._dev(R_gt, torch.float64).reshape(n, 3, 3),
+                    registration._dev(t_gt, torch.float64).reshape(n, 3, 1)], dim=2)
+    Tp0, Tg0 = Tp.clone(), Tg.clone()
+    Tp0[:, :, 3] = 0.0
+    Tg0[:, :, 3] = 0.0
+    if dataset == "tless":
+        sp = registration._dev(surface_pts, torch.float32)
+        # queries = GT-pose CAD vertices, targets = predicted-pose surface points (inference.py:118-120)
+        err = ops.nn_batched(v, sp, Tg.reshape(n, 12), Tp.reshape(n, 12)).sum_d / v.shape[0]
+        errR = ops.nn_batched(v, sp, Tg0.reshape(n, 12), Tp0.reshape(n, 12)).sum_d / v.shape[0]
+    else:
+        err = ops.add_metric(v, Tg.reshape(n, 12), Tp.reshape(n, 12))
+        errR = ops.add_metric(v, Tg0.reshape(n, 12), Tp0.reshape(n, 12))
+    ok = status.reshape(n) != 0
+    inf = torch.full_like(err, float("inf"))
+    err, errR = torch.where(ok, err, inf), torch.where(ok, errR, inf)
+    host = torch.stack([err, errR]).cpu().numpy()           # one copy
+    work, rot = host[0] < 0.1 * diameter, host[1] < 0.1 * diameter
+    ids = [names[i] if names is not None else i for i in np.nonzero(work)[0]]
+    return dict(final_error=host[0], final_errorR=host[1], work=work, rot_work=rot, workCT=int(work.sum()),
+                rotWorkCT=int(rot.sum()), correct_predicted_ids=ids)
+
+
 def _orthonormal(R, tol=1e-9) -> bool:
     """R2 inv(R1) = R2 R1^T exactly when R1 is orthonormal (then np.linalg.inv and the transpose agree
     to rounding); scene_gt rotations with few printed digits fall back to the general inverse."""

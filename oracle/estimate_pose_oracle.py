@@ -98,7 +98,7 @@ def corr_matrices_patch(query_img, obj_keys, res, down_sample_scale=3, max_pool=
     return blk.permute(1, 2, 0).reshape(res * res, m).contiguous(), centre.contiguous()
 
 
-def sample(corr_log_raw, mask_prob, alpha, n_samples, seed):
+def sample(corr_log_raw, mask_prob, alpha, n_samples, seed, return_cum=False):
     """poseEstSurf.py:111-119 with explicit uniforms and an f64 cumulative sum.  The weight
     (exp(corr_log) * mask_prob)^alpha is evaluated in f64 as exp(alpha*corr_log) * mask_prob^alpha
     (the reference does it in f32; for a sampling distribution the difference is immaterial and the
@@ -106,7 +106,8 @@ def sample(corr_log_raw, mask_prob, alpha, n_samples, seed):
     w = (np.exp(alpha * corr_log_raw.double().numpy()) * (mask_prob.double().numpy() ** alpha)[:, None]).reshape(-1)
     cum = np.cumsum(w)
     u = uniforms(n_samples, seed)
-    return np.searchsorted(cum, u * cum[-1]).astype(np.int64)        # (n_samples, 4)
+    idx = np.searchsorted(cum, u * cum[-1]).astype(np.int64)        # (n_samples, 4)
+    return (idx, cum) if return_cum else idx
 
 
 def p3p_sorted(X, uv, K):

@@ -15,13 +15,18 @@ def sample(img, p_img_norm, interpolation="bilinear"):
     return samples[0, :, 0].T
 
 
-def objective(t, R, coord_masked, keys_masked, query_img, denom_img, K_crop, return_grad=False, interpolation="bilinear"):
-    """pose_refine.py:70-91 with pose[3:] = t.  All tensors torch-CPU f32."""
+def objective(t, R, coord_masked, keys_masked, query_img, denom_img, K_crop, return_grad=False, interpolation="bilinear",
+              dtype=torch.float32):
+    """pose_refine.py:70-91 with pose[3:] = t.  All tensors torch-CPU, f32 as in the reference; dtype=torch.float64
+    evaluates the same statements in double (the f32 autograd gradient of the bicubic mode carries rounding noise from
+    points that project far outside the image: their coefficient derivatives cancel only to ~1e-7 and are multiplied
+    by (c_x - u) / z, which is huge there)."""
     res = query_img.shape[0]
-    tt = torch.tensor(np.asarray(t, np.float64), dtype=torch.float32, requires_grad=return_grad)
-    Rt = torch.cat((torch.from_numpy(np.asarray(R, np.float64)).float(), tt[:, None]), dim=1)
-    P = torch.from_numpy(np.asarray(K_crop, np.float64)).float() @ Rt
-    X = torch.cat((coord_masked, torch.ones(len(coord_masked), 1)), dim=1).float()
+    coord_masked, keys_masked, query_img, denom_img = (x.to(dtype) for x in (coord_masked, keys_masked, query_img, denom_img))
+    tt = torch.tensor(np.asarray(t, np.float64), dtype=dtype, requires_grad=return_grad)
+    Rt = torch.cat((torch.from_numpy(np.asarray(R, np.float64)).to(dtype), tt[:, None]), dim=1)
+    P = torch.from_numpy(np.asarray(K_crop, np.float64)).to(dtype) @ Rt
+    X = torch.cat((coord_masked, torch.ones(len(coord_masked), 1, dtype=dtype)), dim=1)
     p_img = X @ P.T
     p_img = p_img[..., :2] / p_img[..., 2:]
     p_norm = (p_img + 0.5) * (2 / res) - 1

@@ -115,13 +115,26 @@ def test_refine_objective_modes_vs_reference_statements(cuda0, mode):
     q, den = torch.from_numpy(g["query_img"]).to(cuda0), torch.from_numpy(g["denom_img"]).to(cuda0)
     obj = pose_refine.RefineObjective(torch.from_numpy(g["X"]).to(cuda0), torch.from_numpy(g["keys"]).to(cuda0), q, den,
                                       g["K_crop"], g["R"], interpolation=mode)
+    from oracle import refine_pose_oracle as rpo
+    qh, dh = torch.from_numpy(g["query_img"]), torch.from_numpy(g["denom_img"])[..., None]
+    kh, Xh = torch.from_numpy(g["keys"]), torch.from_numpy(g["X"])
     for t, s, gr in zip(g["t"], g[f"score_{mode}"], g[f"grad_t_{mode}"]):
         pose = np.concatenate([np.zeros(3), t])
         # nearest is discontinuous: a sample within f32 rounding of a half-integer may land on the neighbouring pixel
         # (the reference evaluates the coordinates in f32, the kernel in f64): one of 150 points moves the mean by < 2e-2
         tol = 2e-2 if mode == "nearest" else 5e-5 * max(1.0, abs(s))
         assert abs(obj(pose) - s) <= tol
-        np.testing.assert_allclose(obj(pose, return_grad=True)[3:], gr, rtol=5e-3, atol=2e-6)
+        got = obj(pose, return_grad=True)[3:]
+        # the reference's f32 autograd gradient (the fixture).  bicubic: a point that projects far outside the image
+        # (camera-frame z near 0) has four coefficient derivatives that cancel only to f32 rounding, multiplied by
+        # (c_x - u) / z ~ 1e4..1e6 — the fixture's d/dt_z carries that noise (2.4e-2 at t_z = 60, against the same
+        # statements evaluated in f64 below); bilinear / nearest zero the gradient of clamped samples explicitly
+        np.testing.assert_allclose(got, gr, rtol=5e-3, atol=5e-2 if mode == "bicubic" else 2e-6)
+        # the same statements evaluated in f64 (torch autograd): the kernel's f64 value and gradient agree tightly
+        v64, g64 = rpo.objective(t, g["R"], Xh, kh, qh, dh, g["K_crop"], return_grad=True, interpolation=mode, dtype=torch.float64)
+        if mode != "nearest":
+            assert abs(obj(pose) - v64) <= 1e-9 * max(1.0, abs(v64))
+        np.testing.assert_allclose(got, g64, rtol=1e-7, atol=1e-9)
     with pytest.raises(ValueError):
         pose_refine.RefineObjective(torch.from_numpy(g["X"]).to(cuda0), torch.from_numpy(g["keys"]).to(cuda0), q, den,
                                     g["K_crop"], g["R"], interpolation="lanczos")

@@ -184,7 +184,11 @@ def test_vote_choose_image_bench_shape_sampled_rows(cuda0):
     Rg, tg = synth.random_poses(rng, n)
     deg = rng.choice([0.5, 4.0, 9.0, 14.0], size=n)
     deg[[3, 29, 50]] = 90.0
-    P = [synth.perturb_pose(rng, Rg[i], tg[i], deg[i], 1.0) for i in range(n)]
+    # ADD-S on a box with a boss forgives rotations; translation errors do not: a quarter of the images sit 6-10 mm
+    # off (their pairs fall on both sides of 0.1 * diameter), three are 40 mm off (every pair with them fails)
+    tr = rng.choice([1.0, 1.0, 1.0, 10.0], size=n)
+    tr[[3, 29, 50]] = 40.0
+    P = [synth.perturb_pose(rng, Rg[i], tg[i], deg[i], tr[i]) for i in range(n)]
     Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
     img, top, err = sequence.vote_choose_image(V, S, Rg, tg, Rp, tp, diam)
     assert err.shape == (n, n) and 0.1 < err.mean() < 0.95                         # a discriminating case
@@ -197,3 +201,46 @@ def test_vote_choose_image_bench_shape_sampled_rows(cuda0):
     sums = err.sum(1)
     assert img == int(np.argmax(sums)) and img not in (3, 29, 50)
     assert list(top) == list(np.argsort(-sums, kind="stable")[:50])
+
+
+@pytest.mark.parametrize("dataset", ["tless", "ruapc"])
+def test_acceptance_counts_match_the_reference_loop(cuda0, dataset):
+    """sequence.acceptance_counts = the bookkeeping of inference.py:300-320 (ADDS / ADD of the pose and of its rotation
+    alone against 0.1 * diameter, workCT / rotWorkCT, the list of accepted images), one batched call for the block
+    against the oracle's per-image calls (the reference's own sklearn KDTree for ADDS)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence
+    from oracle import registration_oracle as ro
+    rng = np.random.default_rng(77)
+    S = synth.tless_like(rng, 4000)
+    V = synth.tless_like(rng, 1500)
+    diam = synth.diameter(S)
+    n = 12
+    Rg, tg = synth.random_poses(rng, n)
+    deg = [0.5, 2.0, 30.0, 1.0, 8.0, 90.0, 0.2, 12.0, 3.0, 45.0, 6.0, 1.5]
+    tr = [1.0, 30.0, 1.0, 2.0, 3.0, 1.0, 0.5, 1.0, 25.0, 1.0, 2.0, 40.0]        # some right rotations with wrong translations
+    P = [synth.perturb_pose(rng, Rg[i], tg[i], deg[i], tr[i]) for i in range(n)]
+    Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
+    poses = torch.from_numpy(np.concatenate([Rp, tp[:, :, None]], 2).reshape(n, 12)).to(cuda0)
+    status = torch.ones(n, dtype=torch.int32, device=cuda0)
+    status[7] = 0                                                            # a failed pnp: never accepted
+    names = [f"{i:06d}.png" for i in range(n)]
+    out = sequence.acceptance_counts(V, S, Rg, tg, poses, status, diam, dataset=dataset, names=names)
+    Vd, Sd = V.astype(np.float64), S.astype(np.float64)
+    fe, fr = np.full(n, np.inf), np.full(n, np.inf)
+    for i in range(n):
+        if i == 7:
+            continue
+        if dataset == "tless":
+            fe[i] = ro.ADDS(Vd, Rg[i], tg[i], Rp[i], tp[i], Sd)
+            fr[i] = ro.ADDS(Vd, Rg[i], np.zeros(3), Rp[i], np.zeros(3), Sd)
+        else:
+            fe[i] = ro.ADD(Vd, Rg[i], tg[i], Rp[i], tp[i])
+            fr[i] = ro.ADD(Vd, Rg[i], np.zeros(3), Rp[i], np.zeros(3))
+    fin = np.isfinite(fe)
+    np.testing.assert_allclose(out["final_error"][fin], fe[fin], atol=1e-4)
+    np.testing.assert_allclose(out["final_errorR"][fin], fr[fin], atol=1e-4)
+    assert np.isinf(out["final_error"][7]) and not out["work"][7] and not out["rot_work"][7]
+    assert np.array_equal(out["work"], fe < 0.1 * diam) and np.array_equal(out["rot_work"], fr < 0.1 * diam)
+    assert out["workCT"] == int((fe < 0.1 * diam).sum()) and out["rotWorkCT"] == int((fr < 0.1 * diam).sum())
+    assert 0 < out["workCT"] < n - 1 and out["workCT"] <= out["rotWorkCT"] <= n - 1     # a discriminating case
+    assert out["correct_predicted_ids"] == [names[i] for i in np.nonzero(fe < 0.1 * diam)[0]]
