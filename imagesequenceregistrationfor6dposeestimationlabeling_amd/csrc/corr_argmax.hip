@@ -367,6 +367,28 @@ __global__ __launch_bounds__(kThreads) void corr_f32_kernel(
 
   const int c0 = split * range_chunks;
   const int cend = min((N + kChunk - 1) / kChunk, c0 + range_chunks);
+  // A workgroup whose 256 queries are all the zero vector (the padding rows behind a crop's masked pixels in a
+  // capacity-sized batch, isr_prep_queries_batch) writes what the loop below would compute for them — every logit
+  // exactly 0: chunk maximum 0 at the chunk's first key, chunk sum = the number of keys (an exact f32) — and leaves.
+  bool nonzero = false;
+#pragma unroll
+  for (int qb = 0; qb < kQB; ++qb)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) nonzero |= bq[qb][s] != 0.f;
+  if (!__syncthreads_or(nonzero ? 1 : 0)) {
+#pragma unroll
+    for (int qb = 0; qb < kQB; ++qb) {
+      const int q = q0 + qb * 32 + r;
+      if (h != 0 || q >= P) continue;
+      for (int c = c0; c < cend; ++c) {
+        ws.pmc[(size_t)c * P + q] = 0.f;
+        ws.plc[(size_t)c * P + q] = (float)(min(N, (c + 1) * kChunk) - c * kChunk);
+      }
+      ws.pm[(size_t)split * P + q] = 0.f;
+      ws.pbi[(size_t)split * P + q] = c0 * kChunk;
+    }
+    return;
+  }
   constexpr int NEL = (TKF * DP + kThreads - 1) / kThreads;
   float stg[NEL];
   for (int c = c0; c < cend; ++c) {
@@ -514,6 +536,11 @@ __device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, b
   idx[q] = bi;
   if (logp) logp[q] = (float)lp;
   if (lse) lse[q] = (float)ls;
+  // The zero vector (a padding row of a capacity-sized crop batch, isr_prep_queries_batch): every product is an exact
+  // zero, every logit is exactly 0, the arg-max is the lowest key — which is what `bi` already holds — and there is
+  // nothing an exact recheck could decide differently.  (With eps = 0 the margin test below would list every such row:
+  // 4 600 of the 5 625 rows of a typical crop, each re-scanned against all keys.)
+  if (MODE != 0 && qn2 == 0.f && !anybad) return;
   if (MODE != 0) {
     const double eps = (double)(D + 2) * 1.1920928955078125e-7 * sqrt((double)qn2 * (double)kn2) * 1.0001;
     const double margin = (double)G1 - (double)G2;
@@ -928,6 +955,7 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     const float* q = static_cast<const float*>(Q);
     const float* k = static_cast<const float*>(K);
     if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 12) corr_f32_kernel<12><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);   // the reference's 12-D descriptors: 6 k-steps, not 8
     else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
     else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
     else if (D <= 64) corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);

@@ -99,6 +99,27 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     const int q = q0 + qb * 32 + r;
     if (!whole && split == 0 && h == 0 && q < P) ws.qn2[q] = n2;
   }
+  // ONE key range and every query of the workgroup is the zero vector (the padding rows behind a crop's masked pixels
+  // in a capacity-sized batch, isr_prep_queries_batch): each logit is exactly 0, each chunk sum the number of its keys,
+  // L = N exactly — corr_finish gets what the loop below would have handed it (bit for bit: v_exp_f32(0) = 1 and sums
+  // of ones are exact), and the workgroup leaves without touching the keys.
+  if (whole) {
+    bool nonzero = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) nonzero |= qn2[qb] != 0.f;
+    if (!__syncthreads_or(nonzero ? 1 : 0)) {
+      const float kn2z = kn2_max(ws);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const int q = q0 + qb * 32 + r;
+        if (h == 0 && q < P)
+          corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, 16 * DK, 0.f, kn2z, ws, idx_out, logp_out, lse_out);
+      }
+      if (tid == 0) ws.flags[blockIdx.y * gridDim.x + blockIdx.x] = 0;
+      if (probe && tid == 0) { ws.clk[0] = 0; ws.clk[1] = 0; }
+      return;
+    }
+  }
   DirectState st[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {

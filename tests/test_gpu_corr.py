@@ -238,6 +238,45 @@ def test_corr_single_range_does_not_read_workspace_history(cuda0, oracle_lib, lo
     _check_log2(ops, oracle_lib, cuda0, Q, K, atol=4e-4, log2=log2)
 
 
+@pytest.mark.parametrize("kind", ["bf16_log2", "bf16", "f32"])
+@pytest.mark.parametrize("N", [3000, 20000])
+def test_corr_zero_queries_are_finished_without_a_recheck(cuda0, oracle_lib, kind, N):
+    """Padding rows of a capacity-sized crop batch (isr_prep_queries_batch) are zero vectors: every logit is exactly 0,
+    the arg-max is key 0, logp = -ln N.  A workgroup whose 256 queries are all zero leaves at once (one key range:
+    N = 3 000; the f32 kernel on every route), a zero row inside a mixed workgroup runs the loop — both give the SAME
+    bits, and neither puts the row on the exact-recheck list (round 3: the margin test with eps = 0 listed every
+    padding row, 12 ms per 75 x 75 crop)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(31)
+    P, D = 2048, 16
+    Q, K, gt = _planted(rng, P, N, D, tau=4.0)
+    Q[100:256] = 0.0                      # zero rows inside a mixed workgroup
+    Q[512:1536] = 0.0                     # four whole workgroups of zero rows
+    Q[2000:] = 0.0                        # the tail, ending in a partial workgroup
+    zero = np.zeros(P, bool)
+    zero[100:256] = zero[512:1536] = zero[2000:] = True
+    if kind == "f32":
+        idx, logp, lse = ops.corr_argmax(torch.from_numpy(Q).to(cuda0), torch.from_numpy(K).to(cuda0), want_lse=True)
+        o = oracle_lib.corr_argmax_f32(Q, K)
+        ref_logp, ref_lse = o["maxlogit"].astype(np.float64) - o["lse"], o["lse"]
+    else:
+        log2 = kind == "bf16_log2"
+        qb = ops.prescale_queries_log2(torch.from_numpy(Q)) if log2 else torch.from_numpy(Q).bfloat16()
+        kb = torch.from_numpy(K).bfloat16()
+        idx, logp, lse = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0), want_lse=True, log2_prescaled=log2)
+        o = oracle_lib.corr_argmax_bf16(_bits(qb), _bits(kb), logit_scale=np.log(2.0) if log2 else 1.0)
+        ref_logp, ref_lse = o["maxlogit"] - o["lse"], o["lse"]
+        assert ops.corr_recheck_count() < 20               # the planted rows only; 1 568 zero rows are not listed
+    torch.cuda.synchronize()
+    idx, logp, lse = idx.cpu().numpy(), logp.cpu().numpy(), lse.cpu().numpy()
+    assert np.array_equal(idx, o["idx"]) and (idx[zero] == 0).all()
+    np.testing.assert_allclose(logp, ref_logp, atol=3e-5)
+    np.testing.assert_allclose(lse, ref_lse, atol=3e-5)
+    # one value for every zero row, whichever route finished it: -ln N rounded once
+    assert len(np.unique(logp[zero].view(np.int32))) == 1 and len(np.unique(lse[zero].view(np.int32))) == 1
+    assert abs(float(logp[zero][0]) + np.log(float(N))) < 2e-6
+
+
 @pytest.mark.parametrize("log2", [True, False])
 def test_corr_bf16_log2_ties_lowest_key(cuda0, oracle_lib, log2):
     """Duplicate keys: every query has an exact tie — the margin test sends all of them to the exact
