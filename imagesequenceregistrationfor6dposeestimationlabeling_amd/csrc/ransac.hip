@@ -48,20 +48,37 @@ namespace {
 
 using namespace isr_p3p;
 
-constexpr int kMaxBatch = 16;   // images per launch chain (kernel-argument space: 16 x (144 + 8) B)
+constexpr int kMaxBatch = 16;    // images per set_imgs_kernel launch (kernel-argument space: 16 x (144 + 8) B)
+constexpr int kChainMax = 128;   // images per launch chain (the scratch of one chain: ~100 KB per image at H = 500)
 
 struct ImgBatch {
   Cam cam[kMaxBatch];
   uint32_t seed_lo[kMaxBatch], seed_hi[kMaxBatch];
 };
 
-__global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
-                           const int32_t* __restrict__ M_dev, int M_cap, ImgBatch ib, int H,
-                           double* __restrict__ Rt_out, uint8_t* __restrict__ ok_out,
-                           int32_t* __restrict__ sample_out) {
+// The cameras and seeds of a chain's images live in DEVICE memory (the caller's scratch): the kernels index them by
+// blockIdx.z, so one chain serves up to kChainMax images — round 2 passed them by value, 16 images per chain of ~40
+// launches, and a 64-crop group at the reference's shape spent more host time launching than the GPU spent working.
+struct ImgDev {
+  Cam cam;
+  uint32_t seed_lo, seed_hi;
+};
+
+__global__ void set_imgs_kernel(ImgBatch ib, int nb, ImgDev* __restrict__ dst) {
+  const int b = threadIdx.x;
+  if (b >= nb) return;
+  dst[b].cam = ib.cam[b];
+  dst[b].seed_lo = ib.seed_lo[b];
+  dst[b].seed_hi = ib.seed_hi[b];
+}
+
+__device__ __forceinline__ void p3p_body(const float* __restrict__ p3d, const float* __restrict__ p2d,
+                                         const int32_t* __restrict__ M_dev, int M_cap, const ImgDev& img, int H,
+                                         double* __restrict__ Rt_out, uint8_t* __restrict__ ok_out,
+                                         int32_t* __restrict__ sample_out) {
   const int b = blockIdx.z;
-  const Cam& cam = ib.cam[b];
-  const uint32_t seed_lo = ib.seed_lo[b], seed_hi = ib.seed_hi[b];
+  const Cam& cam = img.cam;
+  const uint32_t seed_lo = img.seed_lo, seed_hi = img.seed_hi;
   p3d += (size_t)b * M_cap * 3; p2d += (size_t)b * M_cap * 2;
   Rt_out += (size_t)b * H * 12; ok_out += (size_t)b * H;
   if (sample_out) sample_out += (size_t)b * H * 4;
@@ -123,6 +140,21 @@ __global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restric
   }
 }
 
+__global__ void p3p_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
+                           const int32_t* __restrict__ M_dev, int M_cap, const ImgDev* __restrict__ ib, int H,
+                           double* __restrict__ Rt_out, uint8_t* __restrict__ ok_out,
+                           int32_t* __restrict__ sample_out) {
+  p3p_body(p3d, p2d, M_dev, M_cap, ib[blockIdx.z], H, Rt_out, ok_out, sample_out);
+}
+
+// one image, camera and seed by value: isr_p3p_hypotheses has no scratch to put them in
+__global__ void p3p_single_kernel(const float* __restrict__ p3d, const float* __restrict__ p2d,
+                                  const int32_t* __restrict__ M_dev, int M_cap, ImgDev img, int H,
+                                  double* __restrict__ Rt_out, uint8_t* __restrict__ ok_out,
+                                  int32_t* __restrict__ sample_out) {
+  p3p_body(p3d, p2d, M_dev, M_cap, img, H, Rt_out, ok_out, sample_out);
+}
+
 // Every root of the P3P solver for S independent 3-point problems (test / diagnostic entry point: the
 // production kernels keep one root per sample, this one shows the whole set so it can be compared with
 // the oracle's root set): X (S,3,3) f64 object points, uv (S,3,2) f64 pixels -> poses (S,4,12), n (S).
@@ -152,10 +184,10 @@ __global__ void p3p_all_roots_kernel(const double* __restrict__ X, const double*
 // ------------------------------------------------------------------------------- scoring
 // Pm (H,12) f32 = float(K [R|t]) with the f64 fma order of oracle/isr_oracle.c:proj_matrix_f32.
 // Also zeroes the image's inlier counters (no memset launch).
-__global__ void proj_matrix_kernel(const double* __restrict__ Rt, ImgBatch ib, int H, float* __restrict__ Pm,
+__global__ void proj_matrix_kernel(const double* __restrict__ Rt, const ImgDev* __restrict__ ib, int H, float* __restrict__ Pm,
                                    int32_t* __restrict__ n_inl) {
   const int b = blockIdx.z;
-  const Cam& cam = ib.cam[b];
+  const Cam& cam = ib[b].cam;
   Rt += (size_t)b * H * 12; Pm += (size_t)b * H * 12; n_inl += (size_t)b * H;
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < H) n_inl[e] = 0;
@@ -337,10 +369,10 @@ __global__ void best_kernel(const int32_t* __restrict__ n_inl, const uint8_t* __
 
 // Local-optimisation round: the f32 projection matrix of each image's REFITTED pose (same f64 fma order
 // as proj_matrix_kernel) and a fresh Gauss-Newton convergence flag.
-__global__ void refined_proj_kernel(const double* __restrict__ pose, ImgBatch ib, float* __restrict__ Pm,
+__global__ void refined_proj_kernel(const double* __restrict__ pose, const ImgDev* __restrict__ ib, float* __restrict__ Pm,
                                     int32_t* __restrict__ gn_state) {
   const int b = blockIdx.x, e = threadIdx.x;
-  const Cam& cam = ib.cam[b];
+  const Cam& cam = ib[b].cam;
   const double* T = pose + 12 * (size_t)b;
   if (e < 12) {
     const int r = e / 4, c = e % 4;
@@ -450,13 +482,13 @@ __device__ void gn_solve(const double* __restrict__ partial, double* __restrict_
 
 __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
     const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev, int M_cap,
-    const uint32_t* __restrict__ mask, int mask_words, ImgBatch ib, const double* __restrict__ Rt,
+    const uint32_t* __restrict__ mask, int mask_words, const ImgDev* __restrict__ ib, const double* __restrict__ Rt,
     const int32_t* __restrict__ status_dev, int32_t* __restrict__ state,
     double* __restrict__ partial) {
   __shared__ double red[kRefThreads / 64][kNAcc];
   __shared__ int last;
   const int img = blockIdx.z;
-  const Cam& cam = ib.cam[img];
+  const Cam& cam = ib[img].cam;
   p3d += (size_t)img * M_cap * 3; p2d += (size_t)img * M_cap * 2;
   if (mask) mask += (size_t)img * mask_words;
   Rt += (size_t)img * 12; state += 4 * img; partial += (size_t)img * kRefBlocks * kNAcc;
@@ -623,20 +655,8 @@ struct RansacWs {
   double* partial;   // B x kRefBlocks x kNAcc
   int32_t* state;    // B x 4: GN convergence flag
   int32_t* cblocks;  // B x comp_blocks: compaction block counts
+  ImgDev* imgs;      // B: cameras and seeds of the chain's images
 };
-
-size_t carve(isr::Workspace& w, int M_cap, int H, int B, RansacWs* o) {
-  o->Rt = w.take<double>((size_t)B * H * 12);
-  o->Pm = w.take<float>((size_t)B * H * 12);
-  o->ok = w.take<uint8_t>((size_t)B * H);
-  o->n_inl = w.take<int32_t>((size_t)B * H);
-  o->best = w.take<int32_t>(B + 4);
-  o->mask = w.take<uint32_t>((size_t)B * mask_words_of(M_cap));
-  o->partial = w.take<double>((size_t)B * kRefBlocks * kNAcc);
-  o->state = w.take<int32_t>((size_t)B * 4);
-  o->cblocks = w.take<int32_t>((size_t)B * (comp_blocks_of(M_cap) + 1));
-  return w.off;
-}
 
 bool make_batch(const double* Kcams, const uint64_t* seeds, int B, ImgBatch* ib) {
   for (int b = 0; b < B; ++b) {
@@ -648,6 +668,35 @@ bool make_batch(const double* Kcams, const uint64_t* seeds, int B, ImgBatch* ib)
   for (int b = B; b < kMaxBatch; ++b) { ib->cam[b] = ib->cam[0]; ib->seed_lo[b] = ib->seed_hi[b] = 0; }
   return true;
 }
+
+size_t carve(isr::Workspace& w, int M_cap, int H, int B, RansacWs* o) {
+  o->Rt = w.take<double>((size_t)B * H * 12);
+  o->Pm = w.take<float>((size_t)B * H * 12);
+  o->ok = w.take<uint8_t>((size_t)B * H);
+  o->n_inl = w.take<int32_t>((size_t)B * H);
+  o->best = w.take<int32_t>(B + 4);
+  o->mask = w.take<uint32_t>((size_t)B * mask_words_of(M_cap));
+  o->partial = w.take<double>((size_t)B * kRefBlocks * kNAcc);
+  o->state = w.take<int32_t>((size_t)B * 4);
+  o->cblocks = w.take<int32_t>((size_t)B * (comp_blocks_of(M_cap) + 1));
+  o->imgs = w.take<ImgDev>(B);
+  return w.off;
+}
+
+// cameras / seeds of `B` images (host) -> the chain's device array, kMaxBatch per launch
+int upload_imgs(const double* Kcams, const uint64_t* seeds, int B, ImgDev* dst, hipStream_t stream, const char* who) {
+  for (int b0 = 0; b0 < B; b0 += kMaxBatch) {
+    const int nb = (B - b0 < kMaxBatch) ? B - b0 : kMaxBatch;
+    ImgBatch ib;
+    if (!make_batch(Kcams + 9 * (size_t)b0, seeds ? seeds + b0 : nullptr, nb, &ib)) {
+      isr::set_error("%s: singular camera matrix", who);
+      return ISR_ERR_ARG;
+    }
+    set_imgs_kernel<<<1, kMaxBatch, 0, stream>>>(ib, nb, dst + b0);
+  }
+  return ISR_OK;
+}
+
 
 }  // namespace
 
@@ -662,7 +711,7 @@ extern "C" size_t isr_pnp_ransac_batch_workspace_bytes(int M_cap, int H, int B) 
   if (M_cap <= 0 || H <= 0 || B <= 0) return 0;
   isr::Workspace w(nullptr, 0);
   RansacWs o;
-  return carve(w, M_cap, H, B < kMaxBatch ? B : kMaxBatch, &o) + 512;
+  return carve(w, M_cap, H, B < kChainMax ? B : kChainMax, &o) + 512;
 }
 
 extern "C" int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap,
@@ -670,9 +719,11 @@ extern "C" int isr_p3p_hypotheses(const float* p3d, const float* p2d, const int3
                                   int32_t* sample, isr_stream_t stream) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt && ok, "isr_p3p_hypotheses: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0, "isr_p3p_hypotheses: M_cap=%d H=%d", M_cap, H);
-  ImgBatch ib;
-  ISR_REQUIRE(make_batch(Kcam, &seed, 1, &ib), "isr_p3p_hypotheses: singular camera matrix");
-  p3p_kernel<<<dim3((H + 63) / 64, 1, 1), 64, 0, isr::as_stream(stream)>>>(p3d, p2d, M_dev, M_cap, ib, H, Rt, ok, sample);
+  ImgDev img;
+  ISR_REQUIRE(make_cam(Kcam, &img.cam), "isr_p3p_hypotheses: singular camera matrix");
+  img.seed_lo = (uint32_t)seed;
+  img.seed_hi = (uint32_t)(seed >> 32);
+  p3p_single_kernel<<<dim3((H + 63) / 64, 1, 1), 64, 0, isr::as_stream(stream)>>>(p3d, p2d, M_dev, M_cap, img, H, Rt, ok, sample);
   ISR_CHECK_LAUNCH("p3p_kernel");
   return ISR_OK;
 }
@@ -687,7 +738,7 @@ extern "C" int isr_p3p_all_roots(const double* X, const double* uv, const double
   return ISR_OK;
 }
 
-static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgBatch& ib,
+static int score_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgDev* ib,
                       const double* Rt, const uint8_t* ok, int H, double confidence, float reperr, float* Pm,
                       int32_t* n_inl, int32_t* best_dev, uint32_t* best_mask, int32_t* status_dev, double* pose_dev,
                       int32_t* gn_state, int32_t* n_eval_dev, hipStream_t stream) {
@@ -716,20 +767,21 @@ extern "C" int isr_ransac_score(const float* p3d, const float* p2d, const int32_
                                 void* ws, size_t ws_bytes, isr_stream_t stream_) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt && ok && n_inl && best_dev, "isr_ransac_score: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH, "isr_ransac_score: M_cap=%d H=%d (H <= %d)", M_cap, H, kMaxH);
-  ImgBatch ib;
-  ISR_REQUIRE(make_batch(Kcam, nullptr, 1, &ib), "isr_ransac_score: singular camera matrix");
   if (!ws || ws_bytes < isr_pnp_ransac_workspace_bytes(M_cap, H)) {
     isr::set_error("isr_ransac_score: workspace %zu < %zu", ws_bytes, isr_pnp_ransac_workspace_bytes(M_cap, H));
     return ISR_ERR_WORKSPACE;
   }
   isr::Workspace w(ws, ws_bytes);
   float* Pm = w.take<float>((size_t)H * 12);
-  return score_impl(p3d, p2d, M_dev, M_cap, 1, ib, Rt, ok, H, 1.0, reperr, Pm, n_inl, best_dev, best_mask,
+  ImgDev* imgs = w.take<ImgDev>(1);
+  const int rc = upload_imgs(Kcam, nullptr, 1, imgs, isr::as_stream(stream_), "isr_ransac_score");
+  if (rc != ISR_OK) return rc;
+  return score_impl(p3d, p2d, M_dev, M_cap, 1, imgs, Rt, ok, H, 1.0, reperr, Pm, n_inl, best_dev, best_mask,
                     nullptr, nullptr, nullptr, nullptr, isr::as_stream(stream_));
 }
 
 static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const uint32_t* mask,
-                       const ImgBatch& ib, int iters, double* Rt_io, const int32_t* status_dev, double* partial,
+                       const ImgDev* ib, int iters, double* Rt_io, const int32_t* status_dev, double* partial,
                        int32_t* state, hipStream_t stream) {
   for (int it = 0; it < iters; ++it) {
     gn_accumulate_kernel<<<dim3(kRefBlocks, 1, B), kRefThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, mask, mask_words_of(M_cap),
@@ -744,9 +796,7 @@ extern "C" int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t*
                               size_t ws_bytes, isr_stream_t stream) {
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && Rt_io, "isr_pnp_refine: null pointer");
   ISR_REQUIRE(M_cap > 0 && iters >= 0, "isr_pnp_refine: M_cap=%d iters=%d", M_cap, iters);
-  ImgBatch ib;
-  ISR_REQUIRE(make_batch(Kcam, nullptr, 1, &ib), "isr_pnp_refine: singular camera matrix");
-  const size_t need = sizeof(double) * kRefBlocks * kNAcc + 1024;
+  const size_t need = sizeof(double) * kRefBlocks * kNAcc + sizeof(ImgDev) + 1024;
   if (!ws || ws_bytes < need) {
     isr::set_error("isr_pnp_refine: workspace %zu < %zu", ws_bytes, need);
     return ISR_ERR_WORKSPACE;
@@ -754,12 +804,15 @@ extern "C" int isr_pnp_refine(const float* p3d, const float* p2d, const int32_t*
   isr::Workspace w(ws, ws_bytes);
   double* partial = w.take<double>((size_t)kRefBlocks * kNAcc);
   int32_t* state = w.take<int32_t>(4);
+  ImgDev* imgs = w.take<ImgDev>(1);
+  const int rc = upload_imgs(Kcam, nullptr, 1, imgs, isr::as_stream(stream), "isr_pnp_refine");
+  if (rc != ISR_OK) return rc;
   ISR_CHECK_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int32_t), isr::as_stream(stream)));
-  return refine_impl(p3d, p2d, M_dev, M_cap, 1, mask, ib, iters, Rt_io, nullptr, partial, state, isr::as_stream(stream));
+  return refine_impl(p3d, p2d, M_dev, M_cap, 1, mask, imgs, iters, Rt_io, nullptr, partial, state, isr::as_stream(stream));
 }
 
 // the chain for B <= kMaxBatch images: hypotheses, scoring, best + mask, refit, compaction
-static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgBatch& ib,
+static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const ImgDev* ib,
                         int H, double confidence, float reperr, int refine_iters, double* pose_dev, int32_t* inl_idx,
                         int32_t* n_inl_dev, int32_t* status_dev, int32_t* n_eval_dev, const RansacWs& b, hipStream_t stream) {
   p3p_kernel<<<dim3((H + 63) / 64, 1, B), 64, 0, stream>>>(p3d, p2d, M_dev, M_cap, ib, H, b.Rt, b.ok, nullptr);
@@ -795,8 +848,6 @@ extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t*
   ISR_REQUIRE(p3d && p2d && M_dev && Kcam && pose_dev && inl_idx && n_inl_dev && status_dev,
               "isr_pnp_ransac: null pointer");
   ISR_REQUIRE(M_cap > 0 && H > 0 && H <= kMaxH, "isr_pnp_ransac: M_cap=%d H=%d (H <= %d)", M_cap, H, kMaxH);
-  ImgBatch ib;
-  ISR_REQUIRE(make_batch(Kcam, &seed, 1, &ib), "isr_pnp_ransac: singular camera matrix");
   if (!ws || ws_bytes < isr_pnp_ransac_workspace_bytes(M_cap, H)) {
     isr::set_error("isr_pnp_ransac: workspace %zu < %zu", ws_bytes, isr_pnp_ransac_workspace_bytes(M_cap, H));
     return ISR_ERR_WORKSPACE;
@@ -805,7 +856,9 @@ extern "C" int isr_pnp_ransac(const float* p3d, const float* p2d, const int32_t*
   RansacWs b;
   carve(w, M_cap, H, 1, &b);
   ISR_REQUIRE(confidence > 0.0, "isr_pnp_ransac: confidence=%g must be > 0 (>= 1: score every hypothesis)", confidence);
-  return ransac_chain(p3d, p2d, M_dev, M_cap, 1, ib, H, confidence, reperr, refine_iters, pose_dev, inl_idx, n_inl_dev,
+  const int urc = upload_imgs(Kcam, &seed, 1, b.imgs, isr::as_stream(stream_), "isr_pnp_ransac");
+  if (urc != ISR_OK) return urc;
+  return ransac_chain(p3d, p2d, M_dev, M_cap, 1, b.imgs, H, confidence, reperr, refine_iters, pose_dev, inl_idx, n_inl_dev,
                       status_dev, n_eval_dev, b, isr::as_stream(stream_));
 }
 
@@ -823,14 +876,14 @@ extern "C" int isr_pnp_ransac_batch(const float* p3d, const float* p2d, const in
     return ISR_ERR_WORKSPACE;
   }
   hipStream_t stream = isr::as_stream(stream_);
-  for (int b0 = 0; b0 < B; b0 += kMaxBatch) {        // kernel-argument space holds kMaxBatch cameras
-    const int nb = (B - b0 < kMaxBatch) ? B - b0 : kMaxBatch;
-    ImgBatch ib;
-    ISR_REQUIRE(make_batch(Kcams + 9 * (size_t)b0, seeds + b0, nb, &ib), "isr_pnp_ransac_batch: singular camera matrix");
+  for (int b0 = 0; b0 < B; b0 += kChainMax) {        // one chain of launches per kChainMax images
+    const int nb = (B - b0 < kChainMax) ? B - b0 : kChainMax;
     isr::Workspace w(ws, ws_bytes);               // chunks run one after the other on the stream: same scratch
     RansacWs wsb;
     carve(w, M_cap, H, nb, &wsb);
-    const int rc = ransac_chain(p3d + (size_t)b0 * M_cap * 3, p2d + (size_t)b0 * M_cap * 2, M_dev + b0, M_cap, nb, ib, H,
+    const int urc = upload_imgs(Kcams + 9 * (size_t)b0, seeds + b0, nb, wsb.imgs, stream, "isr_pnp_ransac_batch");
+    if (urc != ISR_OK) return urc;
+    const int rc = ransac_chain(p3d + (size_t)b0 * M_cap * 3, p2d + (size_t)b0 * M_cap * 2, M_dev + b0, M_cap, nb, wsb.imgs, H,
                                 confidence, reperr, refine_iters, pose_dev + (size_t)b0 * 12, inl_idx + (size_t)b0 * M_cap,
                                 n_inl_dev + b0, status_dev + b0, n_eval_dev ? n_eval_dev + b0 : nullptr, wsb, stream);
     if (rc != ISR_OK) return rc;

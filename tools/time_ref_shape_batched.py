@@ -25,9 +25,9 @@ N, D, H, W, ds = 80000, 12, 224, 224, 3
 S1 = 75
 pts = synth.tless_like(rng, N)
 keys = synth.unit_keys(rng, N, D, tau=6.0)
-Kc = synth.camera(S1, S1, f=400.0)
+Kc = synth.camera(S1, S1, f=600.0)          # the crop is cut to the object box x 1.2 (inference.py:203-206): the object fills it
 n = args.distinct
-R, t = synth.random_poses(rng, n)
+R, t = synth.random_poses(rng, n, t_sigma=3.0)
 pts_d, keys_d = torch.from_numpy(pts).to(dev), torch.from_numpy(keys).to(dev)
 g = torch.Generator(device=dev).manual_seed(1)
 feats = torch.empty((n, H, W, 13), dtype=torch.float32, device=dev)
