@@ -4,8 +4,10 @@ and — for isr_corr_logsoftmax, the HBM-bound stage — per launch with HIP eve
 Run under `rocprofv3 --kernel-trace --stats` for the per-kernel table (profiles/r03_estimate_pose_ref_size.csv)."""
 import argparse, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
-sys.path.insert(0, "tests")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, pose_est_surf as pes
 from test_gpu_estimate_pose import _scene_ref
 

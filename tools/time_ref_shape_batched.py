@@ -8,7 +8,9 @@ against the single-image chain sequence.register_crop.
 --once: one pass over the distinct crops and nothing else (for rocprofv3 --kernel-trace: launches per image)."""
 import argparse, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, sequence, synth
 
 ap = argparse.ArgumentParser()
