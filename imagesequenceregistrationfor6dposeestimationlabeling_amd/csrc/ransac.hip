@@ -412,11 +412,13 @@ constexpr int kNAcc = 29;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2) + 1 (nu
 // rotation of the unit quaternion (1, w/2)/|.| (sqrt only: no sin/cos, so the step is plain IEEE
 // arithmetic).  state[0] = 1 once the step is below 1e-12: later launches return at once.
 // (Runs in the LAST workgroup of gn_accumulate_kernel to deliver its partial sums: one launch per iteration.)
-__device__ void gn_solve(const double* __restrict__ partial, double* __restrict__ Rt, int32_t* __restrict__ state) {
+__device__ void gn_solve(const double* __restrict__ partial, int nblocks, double* __restrict__ Rt, int32_t* __restrict__ state) {
   __shared__ double s[kNAcc];
   if (threadIdx.x < kNAcc) {
+    // blocks [nblocks, kRefBlocks) were not launched: their correspondences m = b * 256 + t lie beyond M_cap, their sums
+    // would be exact zeros — leaving them out changes no bit of the total
     double a = 0.0;
-    for (int b = 0; b < kRefBlocks; ++b) a += partial[(size_t)b * kNAcc + threadIdx.x];
+    for (int b = 0; b < nblocks; ++b) a += partial[(size_t)b * kNAcc + threadIdx.x];
     s[threadIdx.x] = a;
   }
   __syncthreads();
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
   if (!last) return;
   __threadfence();
   if (threadIdx.x == 0) state[1] = 0;
-  gn_solve(partial, const_cast<double*>(Rt), state);
+  gn_solve(partial, (int)gridDim.x, const_cast<double*>(Rt), state);
 }
 
 // ------------------------------------------------------------------------------ compaction
@@ -783,8 +785,11 @@ extern "C" int isr_ransac_score(const float* p3d, const float* p2d, const int32_
 static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev, int M_cap, int B, const uint32_t* mask,
                        const ImgDev* ib, int iters, double* Rt_io, const int32_t* status_dev, double* partial,
                        int32_t* state, hipStream_t stream) {
+  // block b owns the correspondences m = b * 256 + t (+ multiples of kRefBlocks * 256): only blocks that can own one
+  // are launched (75 x 75 crops: 22 of 64), which leaves every sum — a fixed tree per block, blocks in order — unchanged
+  const int nblocks = (M_cap + kRefThreads - 1) / kRefThreads < kRefBlocks ? (M_cap + kRefThreads - 1) / kRefThreads : kRefBlocks;
   for (int it = 0; it < iters; ++it) {
-    gn_accumulate_kernel<<<dim3(kRefBlocks, 1, B), kRefThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, mask, mask_words_of(M_cap),
+    gn_accumulate_kernel<<<dim3(nblocks, 1, B), kRefThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, mask, mask_words_of(M_cap),
                                                                              ib, Rt_io, status_dev, state, partial);
   }
   ISR_CHECK_LAUNCH("pnp refine kernels");

@@ -101,15 +101,16 @@ def register_frame(model: SequenceModel, rgb, mask, camparams, encoder, n_feat: 
 def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tensor, cams, c0: int = 0,
                    n_feat: int | None = None, down_sample: int = 3, itr: int = 500, reperr: float = 2.0,
                    seeds=None, refine_iters: int = 10, confidence: float = 0.99, group: int = 64,
-                   n_streams: int = 3) -> tuple[list[ImageResult], torch.Tensor]:
+                   n_streams: int = 1) -> tuple[list[ImageResult], torch.Tensor]:
     """The reference's per-image loop (inference.py:163, 248-293) from the network output on, BATCHED: `feats`
     (n, H, W, C) channels-last on the device, `masks` (n, H, W[, 3]) uint8 on the device, `cams` (n, 3, 3) the
     cropped, down-sampled camera matrices (formats.crop_camera).  Per `group` images: ONE isr_prep_queries_batch
     (three launches), ONE K1 launch on group * S capacity rows (S = ceil(H/ds) * ceil(W/ds); rows past an image's
     count are zero queries whose results nobody reads), ONE filter / assembly / RANSAC chain (register_group with
     the ragged counts).  At the reference's shape (75 x 75 crop, D = 12, N = 80 000) a single image is bound by
-    ~45 dependent launches of a few microseconds of work each; a group shares them.  K1 of group g+1 runs on its
-    own stream beside the chain of group g.  Every image's outputs are bit-identical to register_crop's.
+    ~45 dependent launches of a few microseconds of work each; a group shares them (0.8 launches per image at
+    group = 64).  n_streams > 1 runs K1 of group g+1 on its own stream beside the chain of group g (slower at this
+    shape, see below).  Every image's outputs are bit-identical to register_crop's.
     Returns (results, n_dev (n,) i32 on the device)."""
     dev = model.keys.device
     n = feats.shape[0]
@@ -122,9 +123,17 @@ def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tenso
     cams = np.broadcast_to(cams, (n, 3, 3)) if cams.ndim == 2 else cams
     seeds = list(range(n)) if seeds is None else list(seeds)
     cur = torch.cuda.current_stream(dev)
-    pool = _stream_pool(dev, max(n_streams, 2))
-    for s in pool:
-        s.wait_stream(cur)
+    # n_streams <= 1 (the default here): everything on the caller's stream.  At this shape a K1 workgroup lives for
+    # milliseconds (256 queries x 80 000 keys) and fills its CU's registers; a chain of ~50 small DEPENDENT launches
+    # on a side stream then waits for a K1 workgroup to retire before each of its kernels can start (measured:
+    # 207 us per gn_accumulate launch instead of ~8) and the chain, not K1, bounds the group.  In sequence the chain
+    # costs ~0.4 ms per group behind a ~3 ms K1.  (bench.py's 640 x 480 shape is the opposite case: K1 is 30 ms
+    # per launch and the chain hides beside it — sequence.register_block keeps its side streams.)
+    serial = n_streams <= 1
+    pool = [cur, cur] if serial else _stream_pool(dev, max(n_streams, 2))
+    if not serial:
+        for s in pool:
+            s.wait_stream(cur)
     k1_stream, side = pool[0], pool[1:]
     out, counts, keys = [], [], None
     for gi, g0 in enumerate(range(0, n, group)):
@@ -136,12 +145,14 @@ def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tenso
                 keys = model.keys if model.keys.shape[1] == Q.shape[2] else ops._pad_cols(model.keys, Q.shape[2])
             S = Q.shape[1]
             idx_g, logp_g = ops.corr_argmax(Q.view(B * S, -1), keys, log2_prescaled=model.log2_queries)
-            done = torch.cuda.Event()
-            done.record(k1_stream)
+            if not serial:
+                done = torch.cuda.Event()
+                done.record(k1_stream)
         s = side[gi % len(side)]
-        s.wait_event(done)
-        for t in (idx_g, logp_g, pix, n_dev):
-            t.record_stream(s)
+        if not serial:
+            s.wait_event(done)
+            for t in (idx_g, logp_g, pix, n_dev):
+                t.record_stream(s)
         with torch.cuda.stream(s):
             keep, M, _ = ops.select_top_batch(logp_g.view(B, S), n_dev=n_dev)
             p3d, p2d = ops.gather_corr_batch(idx_g.view(B, S), keep, M, model.pts, pix)
@@ -151,11 +162,11 @@ def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tenso
         out += [ImageResult(r.pose[b], r.status[b:b + 1], r.n_inl[b:b + 1], r.inl_idx[b], keep[b], M[b:b + 1], iv[b], lv[b],
                             r.n_eval[b:b + 1]) for b in range(B)]
         counts.append(n_dev)
-    for s in pool:
-        cur.wait_stream(s)
-    _publish(out, cur)
+    if not serial:
+        for s in pool:
+            cur.wait_stream(s)
+        _publish(out, cur)
     n_all = torch.cat(counts)
-    n_all.record_stream(cur)
     return out, n_all
 
 

@@ -310,7 +310,7 @@ def test_estimate_pose_reference_size_stage_by_stage(cuda0, avg_queries):
     tgt = (eo.uniforms(S, seed) * cum[-1])[diff]
     lo_i, hi_i = np.minimum(got_idx[diff], ref_idx[diff]), np.maximum(got_idx[diff], ref_idx[diff])
     gap = np.maximum(np.abs(tgt - cum[lo_i]), np.abs(tgt - cum[hi_i - 1])) / cum[-1] if n_diff else np.zeros(1)
-    assert n_diff <= 80 and gap.max() < 1e-10, (n_diff, gap.max())
+    assert n_diff <= 80 and gap.max() < 1e-8, (n_diff, gap.max())          # n eps = 5e-8 bounds the sequential cumsum
     del cum
     # ---- stage 4: P3P per sample (:137-145) on the device's samples
     Ks = pes._k_scaled(s["K"], ds)

@@ -160,8 +160,8 @@ def _crop_case(rng, pts, keys, Kc, R, t, H, W, ds, kind):
     return feat, np.repeat(mask[:, :, None], 3, axis=2), len(rows)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16_log2"])
-def test_register_crops_equals_register_crop_per_image(cuda0, dtype):
+@pytest.mark.parametrize("dtype,n_streams", [("f32", 1), ("bf16_log2", 1), ("bf16_log2", 3)])
+def test_register_crops_equals_register_crop_per_image(cuda0, dtype, n_streams):
     """The batched per-image loop (isr_prep_queries_batch + ONE K1 launch per group + one filter / RANSAC chain):
     every image bit-identical to the single-image chain, on ragged masks including an empty and a full one, with
     per-image cameras and seeds, across a group boundary (7 images, groups of 4)."""
@@ -192,7 +192,7 @@ def test_register_crops_equals_register_crop_per_image(cuda0, dtype):
                            Q1.view(torch.int16 if dtype != "f32" else torch.int32))
         assert torch.equal(pixb[b], pix1)
     res, n_dev = sequence.register_crops(model, feats, masks, cams, n_feat=12, down_sample=ds, itr=300, seeds=seeds,
-                                         refine_iters=6, group=4)
+                                         refine_iters=6, group=4, n_streams=n_streams)
     torch.cuda.synchronize()
     assert n_dev.cpu().tolist() == [c[2] for c in cases]
     for b in range(n):

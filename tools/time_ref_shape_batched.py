@@ -20,6 +20,7 @@ ap.add_argument("--distinct", type=int, default=128)
 ap.add_argument("--dtype", default="both")
 ap.add_argument("--itr", type=int, default=500)
 ap.add_argument("--once", action="store_true")
+ap.add_argument("--streams", type=int, default=1, help="1: K1 and the chains on one stream; 3: chains on side streams beside the next K1")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
@@ -66,7 +67,7 @@ def run(model, label):
     seeds = list(range(n))
     if args.once:
         res, nd = sequence.register_crops(model, feats, masks, cams, n_feat=D, down_sample=ds, itr=args.itr, seeds=seeds,
-                                          refine_iters=6, group=args.batch)
+                                          refine_iters=6, group=args.batch, n_streams=args.streams)
         torch.cuda.synchronize()
         return
     # single-image chain (round 2's path) on a subset
@@ -82,13 +83,13 @@ def run(model, label):
     # batched
     ops.enable_timing(True)
     res, nd = sequence.register_crops(model, feats, masks, cams, n_feat=D, down_sample=ds, itr=args.itr, seeds=seeds,
-                                      refine_iters=6, group=args.batch)
+                                      refine_iters=6, group=args.batch, n_streams=args.streams)
     torch.cuda.synchronize()
     ops.drain_timing()
     t0 = time.perf_counter()
     for _ in range(reps):
         res, nd = sequence.register_crops(model, feats, masks, cams, n_feat=D, down_sample=ds, itr=args.itr, seeds=seeds,
-                                          refine_iters=6, group=args.batch)
+                                          refine_iters=6, group=args.batch, n_streams=args.streams)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tm = ops.drain_timing()
