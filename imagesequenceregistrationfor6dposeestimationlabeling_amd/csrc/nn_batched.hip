@@ -65,13 +65,24 @@ constexpr int kUnresolved = -2;   // part_idx of a query the grid search handed 
 // the new T is an upper bound that is almost always the answer, so almost nothing passes the filter.
 // unresolved != nullptr: second pass behind nn_grid_search_kernel (nsplit must be 1) — only blocks
 // that hold a query marked kUnresolved run, and only those queries are stored.
-template <int RQ, bool FILTER>
+// EXACT = true (the ICP loop, packed != nullptr): the lane also watches for NEAR TIES.  The search runs on f32-rounded
+// coordinates; with u = 2^-24 and delta = u (|q| + max |t|) (the rounding displacement of the two points) the f32 value
+// D32 of a pair differs from its exact squared distance by at most tol(D) = 6u D + 2 sqrt(D) delta + delta^2.  A target
+// other than the lane's winner whose D32 lies within  best + 2.5 tol(best)  may be the exact (f64) nearest neighbour —
+// Open3D's KD-tree (icp.py:96-103) searches doubles — so the lane raises amb[query]; icp_finalize_update_kernel then
+// decides that query over all targets in f64.  Any such target is seen: the slow path is entered on  m <= thx  (thx =
+// that widened bound, which only shrinks as best does) instead of  m < best, the filter's gate is built from thx, a
+// winner that displaces a near-tied predecessor raises the flag too, and so does the packed atomicMin when the value
+// it displaces (or fails to displace) — another target split's winner — is a near tie.  Cost in the fast path: none
+// (the comparisons are against thx instead of best).  On 20 000-point clouds one or two queries per pass are flagged.
+template <int RQ, bool FILTER, bool EXACT = false>
 __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     const float* __restrict__ qry, int Nq, const float* __restrict__ tgt, int Nt,
     const double* __restrict__ Tq, const double* __restrict__ Tt, int split_len, int nsplit,
     float* __restrict__ part_d2, int32_t* __restrict__ part_idx, const int32_t* __restrict__ skip,
     const int32_t* __restrict__ unresolved, unsigned long long* __restrict__ packed = nullptr,
-    const int32_t* __restrict__ warm = nullptr) {
+    const int32_t* __restrict__ warm = nullptr, int32_t* __restrict__ amb = nullptr,
+    const float* __restrict__ t2_bound = nullptr) {
   __shared__ __attribute__((aligned(16))) float lds[2][FILTER ? 4 : 3][kTile];   // FILTER: -2x, -2y, -2z, |t|^2; else x, y, z
   __shared__ float tile_t2[2][kThreads / 64];                       // largest |t|^2 of a tile, per staging wave
   if (skip && *skip) return;  // device-side ICP loop: converged, later iterations are no-ops
@@ -94,6 +105,14 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
 
   float qx[RQ], qy[RQ], qz[RQ], q2[RQ], best[RQ], thr[RQ];
   int bidx[RQ];
+  // EXACT only: rounding displacement delta, widened bound thx, near-tie flag
+  float dlt[RQ], thx[RQ];
+  bool am[RQ];
+  constexpr float kU0 = 5.9604645e-8f;    // 2^-24
+  auto nearthr = [&](int r, float D) {    // D + 2.5 tol(D), inf for D = inf
+    const float tol = __builtin_fmaf(6.f * kU0, D, __builtin_fmaf(2.f * __builtin_sqrtf(D), dlt[r], dlt[r] * dlt[r]));
+    return __builtin_fmaf(2.5f, tol, D);
+  };
 #pragma unroll
   for (int r = 0; r < RQ; ++r) {
     int qi = (blockIdx.x * RQ + r) * kThreads + tid;
@@ -111,6 +130,11 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
       const float dx = qx[r] - (float)tx, dy = qy[r] - (float)ty, dz = qz[r] - (float)tz;
       best[r] = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
       bidx[r] = w;
+    }
+    if (EXACT) {
+      dlt[r] = 1.001f * kU0 * (__builtin_sqrtf(q2[r]) + __builtin_sqrtf(*t2_bound));
+      thx[r] = nearthr(r, best[r]);
+      am[r] = false;
     }
   }
 
@@ -150,7 +174,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     if ((tid & 63) == 0) tile_t2[buf][tid >> 6] = t2m;
   };
   auto threshold = [&](int r, float t2max) {
-    return __builtin_fmaf(64.f * kU, q2[r] + t2max, __builtin_fmaf(best[r], 1.f + 8.f * kU, -q2[r]));
+    return __builtin_fmaf(64.f * kU, q2[r] + t2max, __builtin_fmaf(EXACT ? thx[r] : best[r], 1.f + 8.f * kU, -q2[r]));
   };
 
   if (ntiles > 0) stage(0, 0);
@@ -183,10 +207,17 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
           // three v_min3 + one v_min (min-type ops issue at 0.6x the add rate: keep them few)
           const float m = fminf(fminf(fminf(d[3], d[4]), d[5]),
                                 fminf(fminf(d[6], d[7]), fminf(fminf(d[0], d[1]), d[2])));
-          if (__any(m < best[r])) {  // wave-uniform
+          if (EXACT ? __any(m <= thx[r]) : __any(m < best[r])) {  // wave-uniform
 #pragma unroll
             for (int v = 0; v < kGroup; ++v) {
               const bool up = d[v] < best[r];
+              if (EXACT) {
+                const int j = jbase + g + v;
+                const bool cand = (d[v] <= thx[r]) & (d[v] < 2.9e38f);          // 3e38: padding
+                const float nthr = up ? nearthr(r, d[v]) : thx[r];
+                am[r] |= cand & (up ? ((bidx[r] >= 0) & (best[r] <= nthr)) : (j != bidx[r]));
+                thx[r] = nthr;
+              }
               best[r] = up ? d[v] : best[r];
               bidx[r] = up ? (jbase + g + v) : bidx[r];
             }
@@ -231,8 +262,14 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
               const float dx = qx[r] + 0.5f * tx[v], dy = qy[r] + 0.5f * ty[v], dz = qz[r] + 0.5f * tz[v];
               const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
               const int j = jbase + g + v;
-              const bool up = (sc[v] <= th) & (sc[v] < 2.9e38f) &            // 3e38: padding
-                              ((d2 < best[r]) | ((d2 == best[r]) & (j < bidx[r])));
+              const bool pass = (sc[v] <= th) & (sc[v] < 2.9e38f);            // 3e38: padding
+              const bool up = pass & ((d2 < best[r]) | ((d2 == best[r]) & (j < bidx[r])));
+              if (EXACT) {
+                const bool cand = pass & (d2 <= thx[r]);
+                const float nthr = up ? nearthr(r, d2) : thx[r];
+                am[r] |= cand & (up ? ((bidx[r] >= 0) & (bidx[r] != j) & (best[r] <= nthr)) : (j != bidx[r]));
+                thx[r] = nthr;
+              }
               best[r] = up ? d2 : best[r];
               bidx[r] = up ? j : bidx[r];
             }
@@ -252,9 +289,18 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
         // one 64-bit atomic min per (query, target split) instead of per-split partial arrays: d2 >= 0, so
         // its bit pattern orders like the value, and equal distances keep the lower index — the very
         // winner the ascending merge of the partials picks, whatever order the atomics land in
-        if (bidx[r] >= 0)
-          atomicMin(&packed[(size_t)b * Nq + qi],
-                    ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned int)bidx[r]);
+        if (bidx[r] >= 0) {
+          const unsigned long long old = atomicMin(&packed[(size_t)b * Nq + qi],
+                                                   ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned int)bidx[r]);
+          if (EXACT) {
+            // the value this one displaced, or failed to displace, is another target split's winner: a near tie between
+            // the two is a near tie of the query (every pair of splits meets here through the slot's history)
+            const float od = __uint_as_float((unsigned int)(old >> 32));
+            const int oi = (int)(unsigned int)old;
+            if (old != ~0ull && oi != bidx[r]) am[r] |= fmaxf(od, best[r]) <= nearthr(r, fminf(od, best[r]));
+            if (am[r]) amb[(size_t)b * Nq + qi] = 1;
+          }
+        }
         continue;
       }
       const size_t o = ((size_t)b * nsplit + split) * Nq + qi;
@@ -520,29 +566,61 @@ __device__ void icp_reduce_and_update(const double* __restrict__ part_sums, int 
   for (int k = 0; k < 12; ++k) T[k] = Tn[k];
 }
 
-// the update as a launch of its own (behind nn_finalize_kernel: the grid-search variants of the loop)
-__global__ __launch_bounds__(kThreads) void icp_update_kernel(const double* __restrict__ part_sums, int nblk, int Ns,
-                                                              int max_iter, double rel_fitness, double rel_rmse,
-                                                              double* __restrict__ T, IcpState* __restrict__ st,
-                                                              double* __restrict__ result) {
-  if (st->done) return;
-  icp_reduce_and_update(part_sums, nblk, Ns, max_iter, rel_fitness, rel_rmse, T, st, result);
-}
-
 // Brute-force loop: the search left one packed (f32 d2 bits, index) minimum per source point.  Every
 // workgroup finishes its 256 points exactly as nn_finalize_kernel<true> does (f64 distance of the
 // winner, radius test, the 18 sums by the same fixed tree), re-arms the packed slots, and takes a
 // ticket; the LAST workgroup to arrive (agent-scope fences order the block sums before the ticket)
 // runs the update.  Two launches per ICP iteration, no partial arrays.
 __global__ __launch_bounds__(kThreads) void icp_finalize_update_kernel(
-    const float* __restrict__ src, int Ns, const float* __restrict__ tgt, double radius,
-    unsigned long long* __restrict__ packed, int32_t* __restrict__ prev_idx, double* __restrict__ part_sums, int max_iter,
+    const float* __restrict__ src, int Ns, const float* __restrict__ tgt, int Nt, double radius,
+    unsigned long long* __restrict__ packed, int32_t* __restrict__ prev_idx, int32_t* __restrict__ amb,
+    double* __restrict__ part_sums, int max_iter,
     double rel_fitness, double rel_rmse, double* __restrict__ T, IcpState* __restrict__ st, double* __restrict__ result) {
   __shared__ double red[kThreads / 64][kNV];
   __shared__ int last;
+  __shared__ int nflag, flist[kThreads];
+  __shared__ double wd[kThreads / 64];
+  __shared__ int wi[kThreads / 64];
   if (st->done) return;
   const int tid = threadIdx.x;
   const int qi = blockIdx.x * kThreads + tid;
+  // ---- near ties the search flagged (nn_search_kernel<.., EXACT>): the exact nearest neighbour over ALL targets in
+  // f64 — squared distance by the fma chain the sums below use, lowest index on exact ties — decided by the whole
+  // workgroup, one flagged point at a time (one or two points per pass on 20 000-point clouds, in one or two workgroups)
+  if (tid == 0) nflag = 0;
+  __syncthreads();
+  if (qi < Ns && amb[qi]) {
+    amb[qi] = 0;
+    flist[atomicAdd(&nflag, 1)] = qi;
+  }
+  __syncthreads();
+  const int nf = nflag;                             // block-uniform
+  for (int f = 0; f < nf; ++f) {
+    const int pq = flist[f];
+    double q0, q1, q2;
+    xform64(T, src[3 * (size_t)pq], src[3 * (size_t)pq + 1], src[3 * (size_t)pq + 2], q0, q1, q2);
+    double bd = __builtin_inf();
+    int bi = 0x7fffffff;
+    for (int j = tid; j < Nt; j += kThreads) {
+      const double ex = q0 - (double)tgt[3 * (size_t)j], ey = q1 - (double)tgt[3 * (size_t)j + 1], ez = q2 - (double)tgt[3 * (size_t)j + 2];
+      const double s2 = fma(ez, ez, fma(ey, ey, ex * ex));
+      if (s2 < bd) { bd = s2; bi = j; }             // ascending j per thread: ties keep the lower index
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double od = __shfl_xor(bd, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    }
+    if ((tid & 63) == 0) { wd[tid >> 6] = bd; wi[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < kThreads / 64; ++w)
+        if (wd[w] < bd || (wd[w] == bd && wi[w] < bi)) { bd = wd[w]; bi = wi[w]; }
+      packed[pq] = ((unsigned long long)__float_as_uint((float)bd) << 32) | (unsigned int)bi;
+    }
+    __syncthreads();
+  }
   double v[kNV];
 #pragma unroll
   for (int k = 0; k < kNV; ++k) v[k] = 0.0;
@@ -588,12 +666,27 @@ __global__ __launch_bounds__(kThreads) void icp_finalize_update_kernel(
   icp_reduce_and_update(part_sums, gridDim.x, Ns, max_iter, rel_fitness, rel_rmse, T, st, result);
 }
 
-__global__ void icp_init_kernel(IcpState* st, double* T, unsigned long long* packed, int Ns) {
+__global__ void icp_init_kernel(IcpState* st, double* T, unsigned long long* packed, int32_t* amb, int Ns) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (packed && i < Ns) packed[i] = ~0ull;
+  if (i < Ns) { packed[i] = ~0ull; amb[i] = 0; }
   if (i != 0) return;
   st->prev_fit = 0; st->prev_rmse = 0; st->iter = 0; st->done = 0; st->ticket = 0;
   T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+// max |t|^2 over the target cloud (f32, rounded up a little): the rounding-displacement bound of the EXACT search
+__global__ __launch_bounds__(kThreads) void cloud_r2max_kernel(const float* __restrict__ tgt, int Nt, float* __restrict__ out) {
+  __shared__ float red[kThreads / 64];
+  float m = 0.f;
+  for (int j = threadIdx.x; j < Nt; j += kThreads) {
+    const float x = tgt[3 * (size_t)j], y = tgt[3 * (size_t)j + 1], z = tgt[3 * (size_t)j + 2];
+    m = fmaxf(m, __builtin_fmaf(z, z, __builtin_fmaf(y, y, x * x)));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = 1.0001f * fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 struct NNPlan {
@@ -609,7 +702,7 @@ struct NNPlan {
 
 constexpr size_t kPartBudget = size_t(192) << 20;  // bytes of per-query partials per chunk
 
-NNPlan make_plan(int Nq, int Nt, int B) {
+NNPlan make_plan(int Nq, int Nt, int B, bool brute_only = false) {
   NNPlan p;
   p.rq = (Nq >= 4 * kThreads) ? 4 : 1;
   // tuning knobs (experiments only): ISR_TUNE_NN_PLAN_RQ / _BLOCKS
@@ -646,6 +739,7 @@ NNPlan make_plan(int Nq, int Nt, int B) {
   p.grid = false;
   p.tile = B >= 4 && Nq >= 1024 && Nt >= 4096 && (long)Nq * B >= (1L << 17);
   if (const int path = isr::tuning(ISR_TUNE_NN_PATH); path >= 0) { p.grid = path == 1; p.tile = path == 2; }
+  if (brute_only) p.grid = p.tile = false;
   if (p.grid || p.tile) {
     p.nsplit = 1;
     p.split_len = max_split * kTile;
@@ -664,7 +758,8 @@ NNPlan make_plan(int Nq, int Nt, int B) {
 constexpr int kFilterMinTiles = 4;
 void launch_search(const NNPlan& p, const dim3& grid, hipStream_t stream, const float* qry, int Nq, const float* tgt, int Nt,
                    const double* tq, const double* tt, float* part_d2, int32_t* part_idx, const int32_t* skip,
-                   const int32_t* unresolved, unsigned long long* packed, const int32_t* warm) {
+                   const int32_t* unresolved, unsigned long long* packed, const int32_t* warm, int32_t* amb = nullptr,
+                   const float* t2_bound = nullptr) {
   bool filter = warm != nullptr || p.split_len >= kFilterMinTiles * kTile;
   // tuning hook (experiments only) for cold searches; a warm start always takes the filter loop (its tie rule —
   // equal distance, lower index — is what makes a warm-started lane return the cold winner)
@@ -672,8 +767,17 @@ void launch_search(const NNPlan& p, const dim3& grid, hipStream_t stream, const 
 #define ISR_SEARCH(RQv, Fv)                                                                                              \
   nn_search_kernel<RQv, Fv><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len, p.nsplit, part_d2, part_idx, \
                                                            skip, unresolved, packed, warm)
+#define ISR_SEARCH_X(RQv, Fv)                                                                                            \
+  nn_search_kernel<RQv, Fv, true><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len, p.nsplit, part_d2, \
+                                                                 part_idx, skip, unresolved, packed, warm, amb, t2_bound)
+  if (amb) {       // the ICP loop: near ties are flagged for the exact decision (packed slots, no target transform)
+    if (p.rq == 4) { if (filter) ISR_SEARCH_X(4, true); else ISR_SEARCH_X(4, false); }
+    else { if (filter) ISR_SEARCH_X(1, true); else ISR_SEARCH_X(1, false); }
+    return;
+  }
   if (p.rq == 4) { if (filter) ISR_SEARCH(4, true); else ISR_SEARCH(4, false); }
   else { if (filter) ISR_SEARCH(1, true); else ISR_SEARCH(1, false); }
+#undef ISR_SEARCH_X
 #undef ISR_SEARCH
 }
 
@@ -774,8 +878,9 @@ extern "C" int isr_add_metric(const float* verts, int V, const double* Ta, const
 
 extern "C" size_t isr_icp_workspace_bytes(int Ns, int Nt) {
   if (Ns <= 0 || Nt <= 0) return 0;
-  // includes the grid when the plan uses one; + the packed minima of the brute-force loop
-  return isr_nn_batched_workspace_bytes(Ns, Nt, 1) + isr::align_up((size_t)Ns * 8, 256) + isr::align_up((size_t)Ns * 4, 256) + 1024;
+  const NNPlan p = make_plan(Ns, Nt, 1, true);
+  return isr::align_up((size_t)p.fblocks * kNV * sizeof(double), 256) + isr::align_up((size_t)Ns * 8, 256) +
+         2 * isr::align_up((size_t)Ns * 4, 256) + 2048;
 }
 
 extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt, int Nt, double threshold,
@@ -788,54 +893,30 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
     return ISR_ERR_WORKSPACE;
   }
   hipStream_t stream = isr::as_stream(stream_);
-  const NNPlan p = make_plan(Ns, Nt, 1);
+  // Always the brute-force search (the grid searches lose here: most source points have their neighbour 5-20 mm
+  // away and a 20 mm ball covers a large part of the object — 18 ms / 103 ms against 2.5 ms per loop, round 2), with
+  // near ties decided in f64: every pass returns the EXACT nearest neighbours, as a KD-tree on doubles does.
+  const NNPlan p = make_plan(Ns, Nt, 1, true);
   isr::Workspace w(ws, ws_bytes);
-  float* part_d2 = w.take<float>((size_t)p.nsplit * Ns);
-  int32_t* part_idx = w.take<int32_t>((size_t)p.nsplit * Ns);
   double* part_sums = w.take<double>((size_t)p.fblocks * kNV);
   IcpState* st = w.take<IcpState>(1);
-  const bool brute = !p.grid && !p.tile;
-  unsigned long long* packed = brute ? w.take<unsigned long long>(Ns) : nullptr;
-  int32_t* prev_idx = brute ? w.take<int32_t>(Ns) : nullptr;
+  unsigned long long* packed = w.take<unsigned long long>(Ns);
+  int32_t* prev_idx = w.take<int32_t>(Ns);
+  int32_t* amb = w.take<int32_t>(Ns);
+  float* t2_bound = w.take<float>(1);
   const bool warm = isr::tuning(ISR_TUNE_ICP_WARM) != 0;          // tuning knob: 0 keeps every pass on the cold kernel
-  icp_init_kernel<<<brute ? (Ns + kThreads - 1) / kThreads : 1, kThreads, 0, stream>>>(st, T_io, packed, Ns);
-  GridWs gw{};
-  TileWs tw{};
-  if (p.grid) {           // the target never moves: one grid serves every iteration
-    gw = take_grid(w, Nt);
-    build_grid(gw, tgt, Nt, stream);
-  }
-  if (p.tile) {           // neither does the source in its own frame
-    tw = take_tile(w, Ns, Nt);
-    build_tile(tw, src, Ns, tgt, Nt, stream);
-  }
-  const float stop_radius = (float)(threshold * (1.0 + 1e-6));
-  const dim3 grid(p.qblocks, p.nsplit, 1), fgrid(p.fblocks, 1);
+  icp_init_kernel<<<(Ns + kThreads - 1) / kThreads, kThreads, 0, stream>>>(st, T_io, packed, amb, Ns);
+  cloud_r2max_kernel<<<1, kThreads, 0, stream>>>(tgt, Nt, t2_bound);
+  const dim3 grid(p.qblocks, p.nsplit, 1);
   for (int it = 0; it <= max_iter; ++it) {
-    if (brute) {
-      // two launches per pass: search with one packed atomic min per (point, target split), then the
-      // finalize whose last workgroup runs the update
-      // (from the second pass on: the warm-started filter search, bounded by the previous pass's neighbour)
-      const int32_t* w_idx = (it > 0 && warm) ? prev_idx : nullptr;
-      launch_search(p, grid, stream, src, Ns, tgt, Nt, T_io, nullptr, nullptr, nullptr, &st->done, nullptr, packed, w_idx);
-      icp_finalize_update_kernel<<<p.fblocks, kThreads, 0, stream>>>(src, Ns, tgt, threshold, packed, prev_idx, part_sums,
-                                                                     max_iter, rel_fitness, rel_rmse, T_io, st, result);
-      continue;
-    }
-    if (p.tile) {
-      launch_tile_search(tw, Ns, Nt, T_io, nullptr, 1, stop_radius, part_d2, part_idx, &st->done, stream);
-    } else {
-      // per-lane grid: a point whose ring walk ends before the ring covers the radius is left to the
-      // brute-force pass (nsplit is 1 on this plan), as in isr_nn_batched
-      nn_grid_search_kernel<<<dim3(p.fblocks, 1), kThreads, 0, stream>>>(src, Ns, gw.desc, gw.start, gw.sorted, T_io,
-                                                                         nullptr, stop_radius, part_d2, part_idx,
-                                                                         gw.unresolved, &st->done);
-      launch_search(p, grid, stream, src, Ns, tgt, Nt, T_io, nullptr, part_d2, part_idx, &st->done, gw.unresolved, nullptr,
-                    nullptr);
-    }
-    nn_finalize_kernel<true><<<fgrid, kThreads, 0, stream>>>(src, Ns, tgt, T_io, nullptr, p.nsplit, threshold, part_d2,
-                                                             part_idx, 0, nullptr, nullptr, part_sums, &st->done);
-    icp_update_kernel<<<1, kThreads, 0, stream>>>(part_sums, p.fblocks, Ns, max_iter, rel_fitness, rel_rmse, T_io, st, result);
+    // two launches per pass: search with one packed atomic min per (point, target split), then the
+    // finalize whose last workgroup runs the update
+    // (from the second pass on: the warm-started filter search, bounded by the previous pass's neighbour)
+    const int32_t* w_idx = (it > 0 && warm) ? prev_idx : nullptr;
+    launch_search(p, grid, stream, src, Ns, tgt, Nt, T_io, nullptr, nullptr, nullptr, &st->done, nullptr, packed, w_idx, amb,
+                  t2_bound);
+    icp_finalize_update_kernel<<<p.fblocks, kThreads, 0, stream>>>(src, Ns, tgt, Nt, threshold, packed, prev_idx, amb, part_sums,
+                                                                   max_iter, rel_fitness, rel_rmse, T_io, st, result);
   }
   ISR_CHECK_LAUNCH("icp kernels");
   return ISR_OK;

@@ -4,8 +4,8 @@ pair Chamfer pick over 63 pairs of 20 000 x 20 000 points (BASELINE configs[1]) 
 neighbours against the C oracle through every NN path, and the ICP loop (warm-started filter passes) + final Chamfer at
 20 000 / 20 000 / 5 000 points against the Kabsch oracle loop.
 Tolerances: Chamfer values 1e-4 mm absolute with the same first minimum (verfication.py:105-106); neighbours and f64
-distances bit-exact; ICP 1e-9 rad / 1e-6 mm against the loop with the device's neighbour definition, 1e-5 rad /
-1e-3 mm against the loop with exact f64 neighbours (north_star asks for 1e-4 rad / 1e-3 mm)."""
+distances bit-exact; ICP 1e-9 rad / 1e-6 mm against the loop with exact f64 neighbours (north_star asks for 1e-4 rad /
+1e-3 mm)."""
 import numpy as np
 import pytest
 import torch
@@ -113,23 +113,19 @@ def test_icp_and_final_chamfer_at_bench_size(reg, ro):
         rf, rr, _, _ = ro.evaluate_registration(src, lower, 20, init)
         assert abs(f - rf) < 1e-12 and abs(r - rr) < 1e-9
         T, fit, rmse = reg.icp_point_to_point(src, lower, 20, init)
-        # (1) the oracle loop with the DEVICE's neighbour definition (search on f32-rounded coordinates with f32
-        # squared distances, lowest index on ties; distances, sums and Kabsch in f64): every pass picks the same
-        # neighbours, the trajectories agree to rounding
-        Tr, rfit, rrmse, traj = ro.icp_point_to_point(src, lower, 20, init, search="f32")
+        # The oracle loop with EXACT f64 neighbours (cKDTree; what Open3D's KD-tree on doubles returns, as far as is
+        # known).  The device searches on f32-rounded coordinates, flags every near tie and decides those in f64
+        # (nn_search_kernel<.., EXACT>): each pass returns the exact neighbours, and the 30-pass trajectories agree to
+        # rounding.  (Round 2's loop kept the f32 winner: on these dense clouds one or two points per pass have two
+        # targets equidistant to f32 rounding, and the trajectories separated by up to 6e-6 rad / 4e-3 mm —
+        # profiles/r03_icp_bench_size_vs_oracle.txt.)
+        Tr, rfit, rrmse, traj = ro.icp_point_to_point(src, lower, 20, init, search="f64")
         assert len(traj) > 3                                   # several warm-started passes ran
         assert synth.rot_angle(T[:3, :3], Tr[:3, :3]) < 1e-9
         assert np.linalg.norm(T[:3, 3] - Tr[:3, 3]) < 1e-6
         assert abs(fit - rfit) < 1e-12 and abs(rmse - rrmse) < 1e-9
         c = reg.final_chamfer(src, lower, T, cad)
         assert abs(c - ro.final_chamfer(src, lower, Tr, cad)) < 1e-6
-        # (2) the oracle loop with EXACT f64 neighbours (cKDTree; Open3D's definition as far as is known).  On these
-        # dense clouds a few source points per pass have two targets equidistant to f32 rounding; from some pass on the
-        # two definitions pick different ones and the trajectories separate by ~1e-7 rad (measured:
-        # profiles/r03_icp_bench_size_vs_oracle.txt: 7.3e-7 rad / 5.2e-4 mm after 30 passes) — inside north_star's
-        # 1e-4 rad / 1e-3 mm.  The translation is referred to the camera origin, ~700 mm from the object.
-        T64, f64_, r64, _ = ro.icp_point_to_point(src, lower, 20, init, search="f64")
-        assert synth.rot_angle(T[:3, :3], T64[:3, :3]) < 1e-5
-        assert np.linalg.norm(T[:3, 3] - T64[:3, 3]) < 1e-3
-        assert abs(fit - f64_) < 1e-3 and abs(rmse - r64) < 1e-6
-        assert abs(c - ro.final_chamfer(src, lower, T64, cad)) < 1e-6
+        # the f32-winner definition (oracle search="f32") is the one that drifts away now
+        T32, _, _, _ = ro.icp_point_to_point(src, lower, 20, init, search="f32")
+        assert synth.rot_angle(T[:3, :3], T32[:3, :3]) < 1e-4
