@@ -52,7 +52,9 @@ SIGNATURES = {
     "isr_corr_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_corr_argmax_recheck_count": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_corr_argmax_clock_mhz": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
-    "isr_corr_logsoftmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "isr_corr_logsoftmax_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "isr_corr_logsoftmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp, _sz, _vp]),
+    "isr_ep_corr_matrices": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "isr_mask_bbox": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "isr_crop_normalize": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "isr_select_top_workspace_bytes": (_sz, [_i]),

@@ -2,10 +2,19 @@
 //
 // Replaces  corr_matrix_log = torch.log_softmax(queries @ obj_keys.T, dim=1)      poseEstSurf.py:70
 //           and getCors(leaves > 1), whose caller then runs topk on the matrix    inference.py:143-145
-// The estimate_pose path keeps the (n x m) matrix resident (it max-pools and samples it), so this
-// variant writes it: one workgroup per query row, three sweeps over the keys (max, sum, write) with
-// the logit recomputed each time as a k-ordered f32 fmaf chain (bf16 inputs are widened exactly).
-// HBM-bound on the P*N*4-byte output; the keys (N*D elements) stay L2-resident.
+// The estimate_pose path keeps the (n x m) matrix resident (it max-pools and samples it), so this variant
+// writes it.  f32 descriptors (what poseEstSurf.py feeds it), D <= 128 — round 3:
+//   1. the row log-sum-exps come from K1's exact-f32 path (isr_corr_argmax, `lse` output: the same k-ordered
+//      fmaf-chain logits, sums merged in f64) — 0.3 ms at n = 5 476, m = 80 000, e = 12;
+//   2. corr_rows_kernel writes out[p][k] = <q_p, key_k> - lse[p]: thread = key (its D values in registers for the
+//      whole workgroup's life), the workgroup's query rows in LDS (broadcast reads), stores coalesced along k.
+//      HBM-bound on the 4 n m output bytes.  With POOL the same pass also writes the 3 x 3 spatially max-pooled
+//      matrix of poseEstSurf.py:97-107: a workgroup owns one image row y of the res x res grid, computes the logits of
+//      rows y - 1, y, y + 1 for its keys column by column and keeps a 3 x 3 window of column maxima in registers —
+//      27 extra fma per element instead of a second pass that re-reads the matrix nine times (round 2:
+//      logsoftmax_rows_kernel 9.1 ms + ep_pool_corr_kernel 3.7 ms of the 16.5 ms estimate_pose call).
+// bf16 inputs (getCors with leaves > 1 on bf16 descriptors; no call site in the reference) keep the one-workgroup-
+// per-row kernel below: three sweeps over the keys (max, sum, write).
 #include "isr_common.hpp"
 
 namespace {
@@ -57,14 +66,161 @@ __global__ __launch_bounds__(kThreads) void logsoftmax_rows_kernel(const T* __re
   for (int n = threadIdx.x; n < N; n += kThreads) o[n] = logit(n) - lse;
 }
 
+constexpr int kRowBlock = 64;    // query rows per workgroup of the plain (un-pooled) matrix kernel
+
+// POOL = false: rows [blockIdx.y * kRowBlock, ...) x keys [blockIdx.x * 256, ...): out_raw = logit - lse.
+// POOL = true : image row y = blockIdx.y of a res x res pixel grid (P = res^2): out_raw as above and
+//               out_pool[y, x][k] = max over the 3 x 3 pixel neighbourhood (inside the grid) of (logit - lse).
+template <int DP, bool POOL>
+__global__ __launch_bounds__(kThreads) void corr_rows_kernel(const float* __restrict__ Q, const float* __restrict__ K, int P,
+                                                             int N, int D, int ldq, int ldk, const float* __restrict__ lse,
+                                                             int res, float* __restrict__ out_raw,
+                                                             float* __restrict__ out_pool, int64_t ldo) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];     // query rows (stride DP) then their lse
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x * kThreads + tid;
+  // the rows this workgroup needs: POOL: image rows y-1 .. y+1 (clipped), else one block of kRowBlock rows
+  const int y = blockIdx.y;
+  const int r_lo = POOL ? max(0, y - 1) * res : y * kRowBlock;
+  const int r_hi = POOL ? min(res, y + 2) * res : min(P, (y + 1) * kRowBlock);
+  const int nrows = r_hi - r_lo;
+  float* qs = smem;
+  float* ls = smem + (size_t)nrows * DP;
+  for (int i = tid; i < nrows * DP; i += kThreads) {
+    const int r = i / DP, d = i % DP;
+    qs[i] = d < D ? Q[(size_t)(r_lo + r) * ldq + d] : 0.f;
+  }
+  for (int i = tid; i < nrows; i += kThreads) ls[i] = lse[r_lo + i];
+  float k[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) k[d] = (n < N && d < D) ? K[(size_t)n * ldk + d] : 0.f;
+  __syncthreads();
+  // logit of local row r for this thread's key: the k-ordered fmaf chain from 0 (K1's exact-f32 logit, bit for bit)
+  auto val = [&](int r) {
+    const float4* q4 = reinterpret_cast<const float4*>(qs + (size_t)r * DP);
+    float acc = 0.f;
+#pragma unroll
+    for (int d4 = 0; d4 < DP / 4; ++d4) {
+      const float4 q = q4[d4];
+      acc = __builtin_fmaf(q.x, k[4 * d4], acc);
+      acc = __builtin_fmaf(q.y, k[4 * d4 + 1], acc);
+      acc = __builtin_fmaf(q.z, k[4 * d4 + 2], acc);
+      acc = __builtin_fmaf(q.w, k[4 * d4 + 3], acc);
+    }
+    return acc - ls[r];
+  };
+  if (!POOL) {
+    if (n >= N) return;
+    for (int r = 0; r < nrows; ++r) out_raw[(size_t)(r_lo + r) * ldo + n] = val(r);
+    return;
+  }
+  // local row index of pixel (yy, x); rows outside the grid contribute -inf (F.max_pool2d pads with -inf)
+  const float ninf = -__builtin_inff();
+  const int base_m = (y - 1 >= 0) ? 0 : -1;                         // is image row y-1 present?  its local offset
+  const int off_c = (y - 1 >= 0) ? res : 0;                         // local offset of image row y
+  const bool has_p = y + 1 < res;
+  auto column = [&](int x, float& centre) {                         // max over the (up to) three rows of column x
+    float c0 = ninf, c2 = ninf;
+    if (base_m == 0) c0 = val(x);
+    centre = val(off_c + x);
+    if (has_p) c2 = val(off_c + res + x);
+    return fmaxf(fmaxf(c0, centre), c2);
+  };
+  float cen = 0.f, cen_next = 0.f;
+  float left = ninf, mid = column(0, cen), right = ninf;
+  for (int x = 0; x < res; ++x) {
+    right = (x + 1 < res) ? column(x + 1, cen_next) : ninf;
+    if (n < N) {
+      const size_t o = (size_t)(y * res + x) * ldo + n;
+      out_raw[o] = cen;
+      out_pool[o] = fmaxf(fmaxf(left, mid), right);
+    }
+    left = mid; mid = right; cen = cen_next;
+  }
+}
+
+template <bool POOL>
+int launch_rows(const float* Q, const float* K, int P, int N, int D, int ldq, int ldk, const float* lse, int res, float* raw,
+                float* pool, int64_t ldo, hipStream_t stream) {
+  const int rows_per_block = POOL ? 3 * res : kRowBlock;
+  const dim3 grid((N + kThreads - 1) / kThreads, POOL ? res : (P + kRowBlock - 1) / kRowBlock);
+#define ISR_ROWS(DPv)                                                                                                   \
+  do {                                                                                                                  \
+    const size_t sh = ((size_t)rows_per_block * DPv + rows_per_block) * sizeof(float);                                  \
+    if (sh > 64 * 1024) { isr::set_error("isr_corr_logsoftmax: %zu B of LDS (res=%d, D=%d)", sh, res, D); return ISR_ERR_UNSUPPORTED; } \
+    corr_rows_kernel<DPv, POOL><<<grid, kThreads, sh, stream>>>(Q, K, P, N, D, ldq, ldk, lse, res, raw, pool, ldo);      \
+  } while (0)
+  if (D <= 16) ISR_ROWS(16);
+  else if (D <= 32) ISR_ROWS(32);
+  else if (D <= 64) ISR_ROWS(64);
+  else ISR_ROWS(128);
+#undef ISR_ROWS
+  return ISR_OK;
+}
+
+// the row log-sum-exps through K1's exact-f32 path; carves idx / lse / K1 scratch from ws
+int row_lse(const float* Q, const float* K, int P, int N, int D, int ldq, int ldk, void* ws, size_t ws_bytes, float** lse_out,
+            isr_stream_t stream) {
+  isr::Workspace w(ws, ws_bytes);
+  int32_t* idx = w.take<int32_t>(P);
+  float* lse = w.take<float>(P);
+  void* k1 = w.take<char>(0);
+  const size_t used = (size_t)(static_cast<char*>(k1) - static_cast<char*>(ws));
+  *lse_out = lse;
+  return isr_corr_argmax(Q, K, P, N, D, ldq, ldk, ISR_DTYPE_F32, idx, nullptr, lse, k1, ws_bytes - used, stream);
+}
+
 }  // namespace
 
+extern "C" size_t isr_corr_logsoftmax_workspace_bytes(int P, int N, int D, int dtype) {
+  if (P <= 0 || N <= 0 || D <= 0) return 0;
+  if (dtype != ISR_DTYPE_F32 || D > 128) return 256;       // the three-sweep kernel needs no scratch
+  return isr::align_up((size_t)P * 4, 256) * 2 + isr_corr_argmax_workspace_bytes(P, N, D, ISR_DTYPE_F32) + 512;
+}
+
+extern "C" int isr_ep_corr_matrices(const float* queries, const float* keys, int res, int m, int e, float* corr_raw,
+                                    float* corr_pool, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(queries && keys && corr_raw, "isr_ep_corr_matrices: null pointer");
+  ISR_REQUIRE(res > 0 && m > 0 && e > 0 && e <= 128, "isr_ep_corr_matrices: res=%d m=%d e=%d (e <= 128)", res, m, e);
+  const int n = res * res;
+  if (!ws || ws_bytes < isr_corr_logsoftmax_workspace_bytes(n, m, e, ISR_DTYPE_F32)) {
+    isr::set_error("isr_ep_corr_matrices: workspace %zu < %zu", ws_bytes, isr_corr_logsoftmax_workspace_bytes(n, m, e, ISR_DTYPE_F32));
+    return ISR_ERR_WORKSPACE;
+  }
+  float* lse = nullptr;
+  int rc = row_lse(queries, keys, n, m, e, e, e, ws, ws_bytes, &lse, stream_);
+  if (rc != ISR_OK) return rc;
+  hipStream_t stream = isr::as_stream(stream_);
+  const int DP = e <= 16 ? 16 : e <= 32 ? 32 : e <= 64 ? 64 : 128;
+  const bool fused = corr_pool && (size_t)3 * res * (DP + 1) * sizeof(float) <= 64 * 1024;   // three image rows of queries in LDS
+  rc = fused ? launch_rows<true>(queries, keys, n, m, e, e, e, lse, res, corr_raw, corr_pool, m, stream)
+             : launch_rows<false>(queries, keys, n, m, e, e, e, lse, res, corr_raw, nullptr, m, stream);
+  if (rc != ISR_OK) return rc;
+  ISR_CHECK_LAUNCH("corr_rows_kernel");
+  if (corr_pool && !fused) return isr_ep_pool_corr(corr_raw, res, m, corr_pool, stream_);     // wide descriptors / large crops
+  return ISR_OK;
+}
+
 extern "C" int isr_corr_logsoftmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
-                                   int dtype, float* out, int64_t ldo, isr_stream_t stream_) {
+                                   int dtype, float* out, int64_t ldo, void* ws, size_t ws_bytes, isr_stream_t stream_) {
   ISR_REQUIRE(Q && K && out, "isr_corr_logsoftmax: null pointer");
   ISR_REQUIRE(P > 0 && N > 0 && D > 0 && D <= kMaxD, "isr_corr_logsoftmax: P=%d N=%d D=%d (D <= %d)", P, N, D, kMaxD);
   ISR_REQUIRE(ldq >= D && ldk >= D && ldo >= N, "isr_corr_logsoftmax: leading dimensions too small");
   hipStream_t stream = isr::as_stream(stream_);
+  if (dtype == ISR_DTYPE_F32 && D <= 128) {
+    if (!ws || ws_bytes < isr_corr_logsoftmax_workspace_bytes(P, N, D, dtype)) {
+      isr::set_error("isr_corr_logsoftmax: workspace %zu < %zu", ws_bytes, isr_corr_logsoftmax_workspace_bytes(P, N, D, dtype));
+      return ISR_ERR_WORKSPACE;
+    }
+    float* lse = nullptr;
+    int rc = row_lse(static_cast<const float*>(Q), static_cast<const float*>(K), P, N, D, ldq, ldk, ws, ws_bytes, &lse, stream_);
+    if (rc != ISR_OK) return rc;
+    rc = launch_rows<false>(static_cast<const float*>(Q), static_cast<const float*>(K), P, N, D, ldq, ldk, lse, 0, out, nullptr,
+                            ldo, stream);
+    if (rc != ISR_OK) return rc;
+    ISR_CHECK_LAUNCH("corr_rows_kernel");
+    return ISR_OK;
+  }
   if (dtype == ISR_DTYPE_BF16)
     logsoftmax_rows_kernel<uint16_t><<<P, kThreads, 0, stream>>>(static_cast<const uint16_t*>(Q),
                                                                  static_cast<const uint16_t*>(K), N, D, ldq, ldk, out, ldo);

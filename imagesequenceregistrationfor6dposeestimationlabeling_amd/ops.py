@@ -636,7 +636,9 @@ def corr_logsoftmax(queries: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
     P, D = q.shape
     N = k.shape[0]
     out = torch.empty((P, N), dtype=torch.float32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_corr_logsoftmax_workspace_bytes(P, N, D, dtype), "corr_lsm")
     with torch.cuda.device(dev):
-        rc = lib().isr_corr_logsoftmax(ptr(q), ptr(k), P, N, D, D, D, dtype, ptr(out), N, current_stream(dev))
+        rc = L.isr_corr_logsoftmax(ptr(q), ptr(k), P, N, D, D, D, dtype, ptr(out), N, ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_corr_logsoftmax")
     return out

@@ -65,6 +65,25 @@ def pool_corr(corr_log: torch.Tensor, res: int) -> torch.Tensor:
     return out
 
 
+def corr_matrices(queries: torch.Tensor, obj_keys: torch.Tensor, res: int, max_pool: bool = True):
+    """isr_ep_corr_matrices (avg_queries=True, poseEstSurf.py:70, 97-107): the (n, m) log-softmax matrix and — in the
+    same pass over the output — its 3 x 3 spatially max-pooled twin (None when max_pool is False)."""
+    dev = require_cuda(queries, obj_keys)
+    q, k = queries.to(torch.float32).contiguous(), obj_keys.to(torch.float32).contiguous()
+    n, e = q.shape
+    m = k.shape[0]
+    if n != res * res:
+        raise ValueError(f"corr_matrices: {n} query rows for a {res} x {res} grid")
+    raw = torch.empty((n, m), dtype=torch.float32, device=dev)
+    pooled = torch.empty((n, m), dtype=torch.float32, device=dev) if max_pool else None
+    L = lib()
+    ws = ops.workspace(dev, L.isr_corr_logsoftmax_workspace_bytes(n, m, e, 1), "corr_lsm")
+    with torch.cuda.device(dev):
+        rc = L.isr_ep_corr_matrices(ptr(q), ptr(k), int(res), m, e, ptr(raw), ptr(pooled), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_ep_corr_matrices")
+    return raw, pooled
+
+
 def patch_corr(query_img: torch.Tensor, obj_keys: torch.Tensor, scale: int = 3):
     """isr_ep_patch_corr (avg_queries=False, poseEstSurf.py:72-96) -> corr_centre (n, m), corr_blockmax (n, m), res."""
     dev = require_cuda(query_img, obj_keys)
@@ -163,12 +182,13 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     Ks = _k_scaled(K, down_sample_scale)
     mlp, nmlp, mprob, queries, res = prepare(mask_lgts, query_img, down_sample_scale, max_pool)
     if avg_queries:
-        corr_raw = ops.corr_logsoftmax(queries, obj_keys_d)                    # (n, m) f32, :70
-        corr_blk = corr_raw
+        corr_raw, corr_log = corr_matrices(queries, obj_keys_d, res, max_pool)   # (n, m) f32 each, :70 and :97-107, one pass
+        if corr_log is None:
+            corr_log = corr_raw
     else:
         # :72-96: per-pixel log-softmax; block-centre values feed the sampler, block maxima the scores
         corr_raw, corr_blk, _ = patch_corr(query_img, obj_keys_d, down_sample_scale)
-    corr_log = pool_corr(corr_blk, res) if max_pool else corr_blk
+        corr_log = pool_corr(corr_blk, res) if max_pool else corr_blk
     dist_2d = size_mask = normals_mask = None
     p3dCp = p2dCp = None
     if poses is None:

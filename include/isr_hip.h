@@ -97,9 +97,12 @@ int isr_corr_argmax_clock_mhz(const void* ws, size_t ws_bytes, int P, int N, int
                               isr_stream_t stream);
 
 /* K1 materialising variant for small P: out (P, N) f32 = log_softmax(Q K^T) row-wise.
- * replaces poseEstSurf.py:70 (corr_matrix_log) and getCors with leaves > 1 (caller runs topk). */
+ * replaces poseEstSurf.py:70 (corr_matrix_log) and getCors with leaves > 1 (caller runs topk).
+ * f32, D <= 128: the row log-sum-exps come from isr_corr_argmax's exact-f32 path, then one pass writes
+ * logit - lse (HBM-bound on the 4 P N output bytes); ws from isr_corr_logsoftmax_workspace_bytes. */
+size_t isr_corr_logsoftmax_workspace_bytes(int P, int N, int D, int dtype);
 int isr_corr_logsoftmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
-                        int dtype, float* out, int64_t ldo, isr_stream_t stream);
+                        int dtype, float* out, int64_t ldo, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * hand-off from the descriptor network to K1
@@ -289,6 +292,13 @@ int isr_ep_prepare(const float* mask_lgts, const float* query_img, int r, int e,
                    float* mask_log_prob, float* neg_mask_log_prob, float* mask_prob, float* queries,
                    void* ws, size_t ws_bytes, isr_stream_t stream);
 int isr_ep_pool_corr(const float* corr_log, int res, int m, float* pooled, isr_stream_t stream);
+/* isr_ep_corr_matrices :70, :97-107 (avg_queries = True) in ONE pass over the output: corr_raw (n, m) =
+ *                  log_softmax(queries @ keys^T) (n = res^2 pooled query pixels, e <= 128) and, when corr_pool is
+ *                  not NULL, corr_pool (n, m) = its 3 x 3 spatial max-pool — the logits of the three image rows a
+ *                  workgroup needs are recomputed in registers instead of re-reading the matrix nine times.
+ *                  ws from isr_corr_logsoftmax_workspace_bytes(n, m, e, ISR_DTYPE_F32). */
+int isr_ep_corr_matrices(const float* queries, const float* keys, int res, int m, int e, float* corr_raw,
+                         float* corr_pool, void* ws, size_t ws_bytes, isr_stream_t stream);
 /* isr_ep_patch_corr :72-96 (avg_queries = False): per-PIXEL log_softmax(query_img[y, x] . obj_keys) pooled per
  *                  scale x scale block without ever forming the (r^2 x m) matrix: corr_centre (n, m) = the value at
  *                  the block's centre pixel (offset scale // 2: the sampling matrix before exp), corr_blockmax (n, m) =

@@ -283,13 +283,17 @@ def test_estimate_pose_reference_size_stage_by_stage(cuda0, avg_queries):
         np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), atol=2e-6, rtol=1e-6)
     # ---- stage 2: the (n x m) log-softmax matrices (:70-107) — 1.75 GB each
     if avg_queries:
-        corr_raw = ops.corr_logsoftmax(queries, keys_d)
-        corr_blk = corr_raw
+        # one pass writes the matrix and its 3 x 3 pooled twin (isr_ep_corr_matrices); the two-step route
+        # (isr_corr_logsoftmax, isr_ep_pool_corr) must give the same bits
+        corr_raw, corr_log = pes.corr_matrices(queries, keys_d, res, True)
+        two_step = ops.corr_logsoftmax(queries, keys_d)
+        assert torch.equal(corr_raw, two_step) and torch.equal(corr_log, pes.pool_corr(two_step, res))
+        del two_step
         rcorr_log, rcorr_raw = eo.corr_matrices(rqueries, keys_h, rmprob, res, True)
     else:
         corr_raw, corr_blk, _ = pes.patch_corr(q_d, keys_d, ds)
         rcorr_log, rcorr_raw = eo.corr_matrices_patch(q_h, keys_h, res, ds, True)
-    corr_log = pes.pool_corr(corr_blk, res)
+        corr_log = pes.pool_corr(corr_blk, res)
     assert corr_raw.shape == (res * res, m)
     d_raw = (corr_raw.cpu() - rcorr_raw).abs().max().item()
     d_log = (corr_log.cpu() - rcorr_log).abs().max().item()

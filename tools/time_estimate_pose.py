@@ -47,5 +47,13 @@ for _ in range(10):
     p = pes.pool_corr(c, res)
 e1.record(); torch.cuda.synchronize()
 t = e0.elapsed_time(e1) / 10 * 1e-3
-print(f"isr_ep_pool_corr (3x3 spatial max-pool of the matrix): {t * 1e3:.3f} ms, {2 * byts / t * 1e-12:.2f} TB/s (read + write) = "
-      f"{2 * byts / t / 8e12:.3f} of 8 TB/s")
+print(f"isr_ep_pool_corr (3x3 spatial max-pool of the matrix, the two-step route): {t * 1e3:.3f} ms, {2 * byts / t * 1e-12:.2f} TB/s "
+      f"(read + write) = {2 * byts / t / 8e12:.3f} of 8 TB/s")
+pes.corr_matrices(q, a[4], res, True); torch.cuda.synchronize()
+e0.record()
+for _ in range(10):
+    raw, pooled = pes.corr_matrices(q, a[4], res, True)
+e1.record(); torch.cuda.synchronize()
+t = e0.elapsed_time(e1) / 10 * 1e-3
+print(f"isr_ep_corr_matrices (matrix + pooled twin in one pass, incl. the K1 lse launch): {t * 1e3:.3f} ms, {2 * byts / t * 1e-12:.2f} TB/s "
+      f"written = {2 * byts / t / 8e12:.3f} of 8 TB/s ({2 * byts * 1e-9:.2f} GB algorithmic)")
