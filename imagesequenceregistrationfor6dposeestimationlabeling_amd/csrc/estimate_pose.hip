@@ -193,7 +193,7 @@ __global__ void ep_chunk_sums_kernel(const float* __restrict__ corr_log, const f
 }
 
 // one thread per row: row sum (chunks in order); then thread 0 of block 0 is NOT used for the
-// row cumulative — a second tiny kernel does the serial inclusive scan over rows.
+// row cumulative — ep_row_scan_kernel does the inclusive scan over rows.
 __global__ void ep_row_sums_kernel(const double* __restrict__ chunk_sums, int n, int nchunk, double* __restrict__ row_sums) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= n) return;
@@ -202,10 +202,26 @@ __global__ void ep_row_sums_kernel(const double* __restrict__ chunk_sums, int n,
   row_sums[o] = s;
 }
 
-__global__ void ep_row_scan_kernel(const double* __restrict__ row_sums, int n, double* __restrict__ row_cum) {
-  if (blockIdx.x || threadIdx.x) return;
+// inclusive scan of the row sums by ONE workgroup of 1024 threads: thread t adds its contiguous slice of rows in order,
+// the slice totals are scanned across the block (Hillis-Steele in LDS), each thread then rewrites its slice.  (Round 2
+// scanned the 5 476 rows with one thread: 375 us per estimate_pose call.)  A fixed shape: run-to-run reproducible.
+__global__ __launch_bounds__(1024) void ep_row_scan_kernel(const double* __restrict__ row_sums, int n, double* __restrict__ row_cum) {
+  __shared__ double tot[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int lo = t * per, hi = min(n, lo + per);
   double s = 0.0;
-  for (int o = 0; o < n; ++o) { s += row_sums[o]; row_cum[o] = s; }
+  for (int o = lo; o < hi; ++o) s += row_sums[o];
+  tot[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const double v = (t >= off) ? tot[t - off] : 0.0;
+    __syncthreads();
+    tot[t] += v;
+    __syncthreads();
+  }
+  double run = (t > 0) ? tot[t - 1] : 0.0;
+  for (int o = lo; o < hi; ++o) { run += row_sums[o]; row_cum[o] = run; }
 }
 
 // sample (s, j): u = (x + 0.5) / 2^32 of Philox(counter = (s,1,0,0)); index = first flat position
@@ -558,7 +574,7 @@ extern "C" int isr_ep_sample(const float* corr_log, const float* mask_prob, int 
   double* row_cum = w.take<double>(n);
   ep_chunk_sums_kernel<<<dim3(nchunk, n), 256, 0, stream>>>(corr_log, mask_prob, m, nchunk, alpha, chunk_sums);
   ep_row_sums_kernel<<<(n + 255) / 256, 256, 0, stream>>>(chunk_sums, n, nchunk, row_sums);
-  ep_row_scan_kernel<<<1, 64, 0, stream>>>(row_sums, n, row_cum);
+  ep_row_scan_kernel<<<1, 1024, 0, stream>>>(row_sums, n, row_cum);
   ep_sample_kernel<<<(n_samples * 4 + 255) / 256, 256, 0, stream>>>(corr_log, mask_prob, n, m, nchunk, alpha, chunk_sums,
                                                                    row_sums, row_cum, n_samples, (uint32_t)seed,
                                                                    (uint32_t)(seed >> 32), corr_idx);
