@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
   // EXACT only: rounding displacement delta, widened bound thx, near-tie flag
   float dlt[RQ], thx[RQ];
   bool am[RQ];
+  int widx[RQ];                           // the warm-start neighbour (-1: none)
   constexpr float kU0 = 5.9604645e-8f;    // 2^-24
   auto nearthr = [&](int r, float D) {    // D + 2.5 tol(D), inf for D = inf
     const float tol = __builtin_fmaf(6.f * kU0, D, __builtin_fmaf(2.f * __builtin_sqrtf(D), dlt[r], dlt[r] * dlt[r]));
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     best[r] = __builtin_inff();
     bidx[r] = -1;
     const int w = warm ? warm[(size_t)b * Nq + qi] : -1;
+    widx[r] = (w >= 0 && w < Nt) ? w : -1;
     if (w >= 0 && w < Nt) {
       double tx, ty, tz;
       xform64(tt, tgt[3 * (size_t)w], tgt[3 * (size_t)w + 1], tgt[3 * (size_t)w + 2], tx, ty, tz);
@@ -281,28 +283,45 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     __syncthreads();
   }
 
+  if (packed) {
+    // one 64-bit atomic min per (query, target split) instead of per-split partial arrays: d2 >= 0, so its bit
+    // pattern orders like the value, and equal distances keep the lower index — the very winner the ascending merge
+    // of the partials picks, whatever order the atomics land in.  A warm-started lane that found nothing better than
+    // its starting neighbour w posts only from the split that owns w: every other split would post the same word
+    // (30 of 31 ICP passes: ~1 atomic per point instead of one per split).  The atomics of a lane's RQ queries are
+    // issued together and their returned words examined afterwards (EXACT).
+    unsigned long long old[RQ];
+    bool posted[RQ];
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) {
+      const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+      const bool own = widx[r] < 0 || bidx[r] != widx[r] || (widx[r] >= t0 && widx[r] < t1);
+      posted[r] = qi < Nq && bidx[r] >= 0 && own;
+      old[r] = ~0ull;
+      if (posted[r]) {
+        const unsigned long long mine = ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned int)bidx[r];
+        if (EXACT) old[r] = atomicMin(&packed[(size_t)b * Nq + qi], mine);
+        else atomicMin(&packed[(size_t)b * Nq + qi], mine);
+      }
+    }
+    if (EXACT) {
+#pragma unroll
+      for (int r = 0; r < RQ; ++r) {
+        const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+        // the value this one displaced, or failed to displace, is another target split's winner: a near tie between
+        // the two is a near tie of the query (every pair of posting splits meets here through the slot's history)
+        const float od = __uint_as_float((unsigned int)(old[r] >> 32));
+        const int oi = (int)(unsigned int)old[r];
+        if (posted[r] && old[r] != ~0ull && oi != bidx[r]) am[r] |= fmaxf(od, best[r]) <= nearthr(r, fminf(od, best[r]));
+        if (qi < Nq && am[r]) amb[(size_t)b * Nq + qi] = 1;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < RQ; ++r) {
     const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
     if (qi < Nq) {
-      if (packed) {
-        // one 64-bit atomic min per (query, target split) instead of per-split partial arrays: d2 >= 0, so
-        // its bit pattern orders like the value, and equal distances keep the lower index — the very
-        // winner the ascending merge of the partials picks, whatever order the atomics land in
-        if (bidx[r] >= 0) {
-          const unsigned long long old = atomicMin(&packed[(size_t)b * Nq + qi],
-                                                   ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned int)bidx[r]);
-          if (EXACT) {
-            // the value this one displaced, or failed to displace, is another target split's winner: a near tie between
-            // the two is a near tie of the query (every pair of splits meets here through the slot's history)
-            const float od = __uint_as_float((unsigned int)(old >> 32));
-            const int oi = (int)(unsigned int)old;
-            if (old != ~0ull && oi != bidx[r]) am[r] |= fmaxf(od, best[r]) <= nearthr(r, fminf(od, best[r]));
-            if (am[r]) amb[(size_t)b * Nq + qi] = 1;
-          }
-        }
-        continue;
-      }
       const size_t o = ((size_t)b * nsplit + split) * Nq + qi;
       if (unresolved && part_idx[o] != kUnresolved) continue;
       part_d2[o] = best[r];
