@@ -2,7 +2,7 @@
 three exact NN searches: python tools/time_icp.py.  Also one ICP evaluation pass and one ADD-S."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, registration, synth
 rng = np.random.default_rng(20240)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
