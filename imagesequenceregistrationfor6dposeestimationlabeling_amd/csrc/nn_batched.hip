@@ -210,18 +210,22 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
           const float m = fminf(fminf(fminf(d[3], d[4]), d[5]),
                                 fminf(fminf(d[6], d[7]), fminf(fminf(d[0], d[1]), d[2])));
           if (EXACT ? __any(m <= thx[r]) : __any(m < best[r])) {  // wave-uniform
+            const float best0 = best[r];
+            const int bidx0 = bidx[r];
 #pragma unroll
             for (int v = 0; v < kGroup; ++v) {
               const bool up = d[v] < best[r];
-              if (EXACT) {
-                const int j = jbase + g + v;
-                const bool cand = (d[v] <= thx[r]) & (d[v] < 2.9e38f);          // 3e38: padding
-                const float nthr = up ? nearthr(r, d[v]) : thx[r];
-                am[r] |= cand & (up ? ((bidx[r] >= 0) & (best[r] <= nthr)) : (j != bidx[r]));
-                thx[r] = nthr;
-              }
               best[r] = up ? d[v] : best[r];
               bidx[r] = up ? (jbase + g + v) : bidx[r];
+            }
+            if (EXACT) {
+              // near ties of the group against its outcome: the bound only shrinks with best, so one bound — that of the
+              // new best — decides for every entry and for the displaced best (one sqrt per group, not per entry)
+              thx[r] = nearthr(r, best[r]);
+              bool t = (bidx0 >= 0) & (bidx0 != bidx[r]) & (best0 <= thx[r]);
+#pragma unroll
+              for (int v = 0; v < kGroup; ++v) t |= (d[v] <= thx[r]) & (d[v] < 2.9e38f) & (jbase + g + v != bidx[r]);
+              am[r] |= t;
             }
           }
         }
@@ -257,8 +261,12 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
                               fminf(fminf(sc[6], sc[7]), fminf(fminf(sc[0], sc[1]), sc[2])));
         if (__any(m <= thr[r])) {  // wave-uniform
           const float th = thr[r];   // the group's candidates against ONE threshold: a lowered best only prunes more
+          const float best0 = best[r];
+          const int bidx0 = bidx[r];
+          float dd[kGroup];          // EXACT: the exact values of the entries that passed on this lane (inf otherwise)
 #pragma unroll
           for (int v = 0; v < kGroup; ++v) {
+            if (EXACT) dd[v] = __builtin_inff();
             if (__any(sc[v] <= th)) {           // wave-uniform per entry: typically one or two of the eight
               // -0.5 * (-2 t) = t exactly: the same differences as dx = qx - tx
               const float dx = qx[r] + 0.5f * tx[v], dy = qy[r] + 0.5f * ty[v], dz = qz[r] + 0.5f * tz[v];
@@ -266,15 +274,17 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
               const int j = jbase + g + v;
               const bool pass = (sc[v] <= th) & (sc[v] < 2.9e38f);            // 3e38: padding
               const bool up = pass & ((d2 < best[r]) | ((d2 == best[r]) & (j < bidx[r])));
-              if (EXACT) {
-                const bool cand = pass & (d2 <= thx[r]);
-                const float nthr = up ? nearthr(r, d2) : thx[r];
-                am[r] |= cand & (up ? ((bidx[r] >= 0) & (bidx[r] != j) & (best[r] <= nthr)) : (j != bidx[r]));
-                thx[r] = nthr;
-              }
+              if (EXACT) dd[v] = pass ? d2 : dd[v];
               best[r] = up ? d2 : best[r];
               bidx[r] = up ? j : bidx[r];
             }
+          }
+          if (EXACT) {               // as in the plain loop: one bound, that of the group's outcome
+            thx[r] = nearthr(r, best[r]);
+            bool t = (bidx0 >= 0) & (bidx0 != bidx[r]) & (best0 <= thx[r]);
+#pragma unroll
+            for (int v = 0; v < kGroup; ++v) t |= (dd[v] <= thx[r]) & (jbase + g + v != bidx[r]);
+            am[r] |= t;
           }
           thr[r] = threshold(r, t2max);
         }
@@ -598,8 +608,8 @@ __global__ __launch_bounds__(kThreads) void icp_finalize_update_kernel(
   __shared__ double red[kThreads / 64][kNV];
   __shared__ int last;
   __shared__ int nflag, flist[kThreads];
-  __shared__ double wd[kThreads / 64];
-  __shared__ int wi[kThreads / 64];
+  __shared__ double wd[4][kThreads / 64];
+  __shared__ int wi[4][kThreads / 64];
   if (st->done) return;
   const int tid = threadIdx.x;
   const int qi = blockIdx.x * kThreads + tid;
@@ -614,29 +624,46 @@ __global__ __launch_bounds__(kThreads) void icp_finalize_update_kernel(
   }
   __syncthreads();
   const int nf = nflag;                             // block-uniform
-  for (int f = 0; f < nf; ++f) {
-    const int pq = flist[f];
-    double q0, q1, q2;
-    xform64(T, src[3 * (size_t)pq], src[3 * (size_t)pq + 1], src[3 * (size_t)pq + 2], q0, q1, q2);
-    double bd = __builtin_inf();
-    int bi = 0x7fffffff;
+  // up to kRes flagged points per sweep over the targets: a target is loaded once and tried against each of them
+  // (the sweep is bound by load latency — round 3's first version resolved one point per sweep, ~35 us each)
+  constexpr int kRes = 4;
+  for (int f0 = 0; f0 < nf; f0 += kRes) {
+    double qx[kRes], qy[kRes], qz[kRes], bd[kRes];
+    int bi[kRes];
+#pragma unroll
+    for (int k = 0; k < kRes; ++k) {
+      const int pq = flist[min(f0 + k, nf - 1)];
+      xform64(T, src[3 * (size_t)pq], src[3 * (size_t)pq + 1], src[3 * (size_t)pq + 2], qx[k], qy[k], qz[k]);
+      bd[k] = __builtin_inf();
+      bi[k] = 0x7fffffff;
+    }
+#pragma unroll 4
     for (int j = tid; j < Nt; j += kThreads) {
-      const double ex = q0 - (double)tgt[3 * (size_t)j], ey = q1 - (double)tgt[3 * (size_t)j + 1], ez = q2 - (double)tgt[3 * (size_t)j + 2];
-      const double s2 = fma(ez, ez, fma(ey, ey, ex * ex));
-      if (s2 < bd) { bd = s2; bi = j; }             // ascending j per thread: ties keep the lower index
+      const double tx = tgt[3 * (size_t)j], ty = tgt[3 * (size_t)j + 1], tz = tgt[3 * (size_t)j + 2];
+#pragma unroll
+      for (int k = 0; k < kRes; ++k) {
+        const double ex = qx[k] - tx, ey = qy[k] - ty, ez = qz[k] - tz;
+        const double s2 = fma(ez, ez, fma(ey, ey, ex * ex));
+        if (s2 < bd[k]) { bd[k] = s2; bi[k] = j; }  // ascending j per thread: ties keep the lower index
+      }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const double od = __shfl_xor(bd, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      if (od < bd || (od == bd && oi < bi)) { bd = od; bi = oi; }
+    for (int k = 0; k < kRes; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double od = __shfl_xor(bd[k], off, 64);
+        const int oi = __shfl_xor(bi[k], off, 64);
+        if (od < bd[k] || (od == bd[k] && oi < bi[k])) { bd[k] = od; bi[k] = oi; }
+      }
+      if ((tid & 63) == 0) { wd[k][tid >> 6] = bd[k]; wi[k][tid >> 6] = bi[k]; }
     }
-    if ((tid & 63) == 0) { wd[tid >> 6] = bd; wi[tid >> 6] = bi; }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < kRes && f0 + tid < nf) {
+      double d = wd[tid][0];
+      int i = wi[tid][0];
       for (int w = 1; w < kThreads / 64; ++w)
-        if (wd[w] < bd || (wd[w] == bd && wi[w] < bi)) { bd = wd[w]; bi = wi[w]; }
-      packed[pq] = ((unsigned long long)__float_as_uint((float)bd) << 32) | (unsigned int)bi;
+        if (wd[tid][w] < d || (wd[tid][w] == d && wi[tid][w] < i)) { d = wd[tid][w]; i = wi[tid][w]; }
+      packed[flist[f0 + tid]] = ((unsigned long long)__float_as_uint((float)d) << 32) | (unsigned int)i;
     }
     __syncthreads();
   }
