@@ -557,6 +557,111 @@ __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
   gn_solve(partial, (int)gridDim.x, const_cast<double*>(Rt), state);
 }
 
+// ------------------------------------------------------------------- refit, small correspondence sets
+// The whole refit of an image — Gauss-Newton over the RANSAC inliers, the local-optimisation round (inliers of the
+// refitted pose, refit again) and the final mask under the returned pose — by ONE workgroup in ONE launch, for
+// capacities up to kSmallM (the reference's 75 x 75 crops: <= 5 625 correspondences).  The multi-launch route
+// (12 gn_accumulate + 2 refined_proj + 2 best_mask launches per group) spends, at that size, 86 us per launch on
+// fences, tickets and a serial solve; here the pose and the convergence flag live in LDS, thread t owns the
+// correspondences m = t + 256 i, the 29 sums go through the same shuffle tree + wave order as a block of the
+// multi-launch route (capacity-independent: a crop registered alone or in a group gives the same bits), and
+// gn_solve runs on the LDS copy.  Same per-correspondence arithmetic as gn_accumulate_kernel / best_mask_kernel.
+constexpr int kSmallM = 8192;
+
+__global__ __launch_bounds__(kRefThreads) void gn_small_kernel(
+    const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev, int M_cap,
+    uint32_t* __restrict__ mask, int mask_words, const ImgDev* __restrict__ ib, int iters, float reperr,
+    double* __restrict__ pose, const int32_t* __restrict__ status_dev) {
+  __shared__ double red[kRefThreads / 64][kNAcc];
+  __shared__ double part[kNAcc];
+  __shared__ double Ts[12];
+  __shared__ float Pm[12];
+  __shared__ int32_t st[2];
+  const int img = blockIdx.x, tid = threadIdx.x;
+  if (status_dev && status_dev[img] == 0) return;          // no pose: nothing to refit (block-uniform)
+  const Cam& cam = ib[img].cam;
+  p3d += (size_t)img * M_cap * 3; p2d += (size_t)img * M_cap * 2;
+  mask += (size_t)img * mask_words; pose += (size_t)img * 12;
+  const int M = M_dev[img];
+  if (tid < 12) Ts[tid] = pose[tid];
+  __syncthreads();
+  // the inlier mask of the pose in Ts (best_mask_kernel with one matrix per image)
+  auto remask = [&]() {
+    if (tid < 12) {
+      const int r = tid / 4, c = tid % 4;
+      Pm[tid] = (float)fma(cam.k[3 * r + 2], Ts[8 + c], fma(cam.k[3 * r + 1], Ts[4 + c], cam.k[3 * r] * Ts[c]));
+    }
+    __syncthreads();
+    for (int m0 = 0; m0 < M_cap; m0 += kRefThreads) {
+      const int m = m0 + tid;
+      bool in = false;
+      if (m < M)
+        in = inlier_f32(Pm, p3d[3 * (size_t)m], p3d[3 * (size_t)m + 1], p3d[3 * (size_t)m + 2], p2d[2 * (size_t)m],
+                        p2d[2 * (size_t)m + 1], reperr);
+      const unsigned long long bal = __ballot(in);
+      const int lane = tid & 63, w = m >> 5;
+      if ((lane == 0 || lane == 32) && w < (M_cap + 31) / 32) mask[w] = (lane == 0) ? (uint32_t)bal : (uint32_t)(bal >> 32);
+    }
+    __syncthreads();
+  };
+  for (int round = 0; round < 2; ++round) {
+    if (round == 1) remask();                               // local optimisation: the inliers of the refitted pose
+    if (tid == 0) { st[0] = 0; st[1] = 0; }
+    __syncthreads();
+    for (int it = 0; it < iters; ++it) {
+      if (st[0]) break;                                     // converged (block-uniform: LDS flag read after a barrier)
+      double acc[kNAcc];
+#pragma unroll
+      for (int i = 0; i < kNAcc; ++i) acc[i] = 0.0;
+      double T[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) T[i] = Ts[i];
+      for (int m = tid; m < M; m += kRefThreads) {
+        if (!((mask[m >> 5] >> (m & 31)) & 1u)) continue;
+        const double X = p3d[3 * (size_t)m], Y = p3d[3 * (size_t)m + 1], Z = p3d[3 * (size_t)m + 2];
+        const double xc = T[0] * X + T[1] * Y + T[2] * Z + T[3];
+        const double yc = T[4] * X + T[5] * Y + T[6] * Z + T[7];
+        const double zc = T[8] * X + T[9] * Y + T[10] * Z + T[11];
+        const double px = cam.k[0] * xc + cam.k[1] * yc + cam.k[2] * zc;
+        const double py = cam.k[3] * xc + cam.k[4] * yc + cam.k[5] * zc;
+        const double pz = cam.k[6] * xc + cam.k[7] * yc + cam.k[8] * zc;
+        const double ipz = 1.0 / pz;
+        const double u = px * ipz, v = py * ipz;
+        const double ru = u - (double)p2d[2 * (size_t)m], rv = v - (double)p2d[2 * (size_t)m + 1];
+        const double a0 = (cam.k[0] - u * cam.k[6]) * ipz, a1 = (cam.k[1] - u * cam.k[7]) * ipz, a2 = (cam.k[2] - u * cam.k[8]) * ipz;
+        const double b0 = (cam.k[3] - v * cam.k[6]) * ipz, b1 = (cam.k[4] - v * cam.k[7]) * ipz, b2 = (cam.k[5] - v * cam.k[8]) * ipz;
+        const double Ju[6] = {a2 * yc - a1 * zc, a0 * zc - a2 * xc, a1 * xc - a0 * yc, a0, a1, a2};
+        const double Jv[6] = {b2 * yc - b1 * zc, b0 * zc - b2 * xc, b1 * xc - b0 * yc, b0, b1, b2};
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) acc[k++] += Ju[i] * Ju[j] + Jv[i] * Jv[j];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[21 + i] += Ju[i] * ru + Jv[i] * rv;
+        acc[27] += ru * ru + rv * rv;
+        acc[28] += 1.0;
+      }
+      const int wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+      for (int i = 0; i < kNAcc; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][i] = v;
+      }
+      __syncthreads();
+      if (tid < kNAcc) part[tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+      __syncthreads();
+      gn_solve(part, 1, Ts, st);                            // thread 0 solves on the LDS pose; ends with thread 0 only
+      __syncthreads();
+    }
+    __syncthreads();
+  }
+  remask();                                                 // the reported inliers are those of the returned pose
+  if (tid < 12) pose[tid] = Ts[tid];
+}
+
 // ------------------------------------------------------------------------------ compaction
 // Bitmask -> ascending indices: per-block popcounts, a one-block scan of the block totals, then
 // every word scatters its set bits at its exclusive prefix.  kCompBlock words per block.
@@ -825,6 +930,12 @@ static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev
   int rc = score_impl(p3d, p2d, M_dev, M_cap, B, ib, b.Rt, b.ok, H, confidence, reperr, b.Pm, b.n_inl, b.best, b.mask,
                       status_dev, pose_dev, b.state, n_eval_dev, stream);
   if (rc != ISR_OK) return rc;
+  if (refine_iters > 0 && M_cap <= kSmallM) {
+    // small correspondence sets: both refit rounds and the final mask in one launch, one workgroup per image
+    gn_small_kernel<<<B, kRefThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, b.mask, mask_words_of(M_cap), ib, refine_iters, reperr,
+                                                   pose_dev, status_dev);
+    ISR_CHECK_LAUNCH("gn_small_kernel");
+  } else {
   rc = refine_impl(p3d, p2d, M_dev, M_cap, B, b.mask, ib, refine_iters, pose_dev, status_dev, b.partial, b.state, stream);
   if (rc != ISR_OK) return rc;
   if (refine_iters > 0) {   // local optimisation: inliers of the refitted pose, refit on them (b.Pm's first B rows are free now)
@@ -837,6 +948,7 @@ static int ransac_chain(const float* p3d, const float* p2d, const int32_t* M_dev
     refined_proj_kernel<<<B, 64, 0, stream>>>(pose_dev, ib, b.Pm, b.state);
     best_mask_kernel<<<dim3((M_cap + 255) / 256, 1, B), 256, 0, stream>>>(p3d, p2d, M_dev, M_cap, 1, b.Pm, nullptr, reperr,
                                                                           b.mask, mask_words_of(M_cap));
+  }
   }
   const int cb = comp_blocks_of(M_cap), mw = mask_words_of(M_cap);
   mask_count_kernel<<<dim3(cb, 1, B), kCompBlock, 0, stream>>>(b.mask, mw, M_dev, status_dev, b.cblocks);
