@@ -100,7 +100,7 @@ def register_frame(model: SequenceModel, rgb, mask, camparams, encoder, n_feat: 
 
 def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tensor, cams, c0: int = 0,
                    n_feat: int | None = None, down_sample: int = 3, itr: int = 500, reperr: float = 2.0,
-                   seeds=None, refine_iters: int = 10, confidence: float = 0.99, group: int = 64,
+                   seeds=None, refine_iters: int = 10, confidence: float = 0.99, group: int = 128,
                    n_streams: int = 1) -> tuple[list[ImageResult], torch.Tensor]:
     """The reference's per-image loop (inference.py:163, 248-293) from the network output on, BATCHED: `feats`
     (n, H, W, C) channels-last on the device, `masks` (n, H, W[, 3]) uint8 on the device, `cams` (n, 3, 3) the
@@ -108,8 +108,8 @@ def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tenso
     (three launches), ONE K1 launch on group * S capacity rows (S = ceil(H/ds) * ceil(W/ds); rows past an image's
     count are zero queries whose results nobody reads), ONE filter / assembly / RANSAC chain (register_group with
     the ragged counts).  At the reference's shape (75 x 75 crop, D = 12, N = 80 000) a single image is bound by
-    ~45 dependent launches of a few microseconds of work each; a group shares them (0.8 launches per image at
-    group = 64).  n_streams > 1 runs K1 of group g+1 on its own stream beside the chain of group g (slower at this
+    ~45 dependent launches of a few microseconds of work each; a group shares them (0.6 launches per image at
+    group = 64; 128-256 crops per group fill the chip best: K1's ~9 working workgroups per crop against 768 slots).  n_streams > 1 runs K1 of group g+1 on its own stream beside the chain of group g (slower at this
     shape, see below).  Every image's outputs are bit-identical to register_crop's.
     Returns (results, n_dev (n,) i32 on the device)."""
     dev = model.keys.device
@@ -172,7 +172,7 @@ def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tenso
 
 def register_frames(model: SequenceModel, rgbs, masks, camparams, encoder, n_feat: int = 12, down_sample: int = 3,
                     itr: int = 500, reperr: float = 2.0, seeds=None, refine_iters: int = 10, confidence: float = 0.99,
-                    useMask: bool = True, group: int = 64):
+                    useMask: bool = True, group: int = 128):
     """The reference's per-image loop, inference.py:163-293, for a block of frames: the crop front end of every
     frame on the device in two launches (registration.crop_inputs: mask boxes, crop affines + camera matrices,
     warps, useMask blanking, normalize), ONE call of `encoder` on the (n, 3, 224, 224) batch (the caller's network,

@@ -6,6 +6,7 @@ python bench.py --steps 10 --keys 50000 --itr 4096 --no-cpu-baseline > gpurun_ou
 ISR_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 4 --images 16 --no-cpu-baseline > gpurun_out/r03_bench_gloo2.json 2> gpurun_out/r03_bench_gloo2.err
 ISR_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29521 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 python bench.py --steps 6 --no-cpu-baseline > gpurun_out/r03_bench_rccl1.json 2> gpurun_out/r03_bench_rccl1.err
 for b in 64 128; do python tools/time_ref_shape_batched.py --batch $b > gpurun_out/r03_ref_shape_b$b.log 2>&1; done
+python tools/time_ref_shape_batched.py --distinct 256 --batch 256 > gpurun_out/r03_ref_shape_b256.log 2>&1
 python tools/time_ref_shape_batched.py --batch 64 --streams 3 > gpurun_out/r03_ref_shape_b64_s3.log 2>&1
 python tools/time_estimate_pose.py > gpurun_out/r03_ep_time.log 2>&1
 python tools/time_estimate_pose.py --avg-queries 0 >> gpurun_out/r03_ep_time.log 2>&1
