@@ -178,8 +178,11 @@ __device__ __forceinline__ double ep_weight(float cl, double mpa, double alpha) 
 __global__ void ep_chunk_sums_kernel(const float* __restrict__ corr_log, const float* __restrict__ mask_prob, int m,
                                      int nchunk, double alpha, double* __restrict__ chunk_sums) {
   __shared__ double red[4];
+  __shared__ double mpa_s;
   const int o = blockIdx.y, c = blockIdx.x;
-  const double mpa = pow((double)mask_prob[o], alpha);
+  if (threadIdx.x == 0) mpa_s = pow((double)mask_prob[o], alpha);     // once per workgroup (round 2: an f64 pow per thread)
+  __syncthreads();
+  const double mpa = mpa_s;
   double s = 0.0;
   for (int j = threadIdx.x; j < kChunk; j += 256) {
     const int k = c * kChunk + j;
