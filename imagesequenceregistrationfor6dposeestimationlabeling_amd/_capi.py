@@ -82,7 +82,9 @@ SIGNATURES = {
                             _sz, _vp]),
     "isr_ep_prepare": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_ep_pool_corr": (_i, [_vp, _i, _i, _vp, _vp]),
-    "isr_ep_patch_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "isr_ep_patch_corr_workspace_bytes": (_sz, [_i, _i, _i]),
+    "isr_ep_patch_corr": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "isr_ep_patch_corr_cells": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "isr_ep_sample_workspace_bytes": (_sz, [_i, _i]),
     "isr_ep_sample": (_i, [_vp, _vp, _i, _i, _d, _i, _u64, _vp, _vp, _sz, _vp]),
     "isr_ep_p3p": (_i, [_vp, _i, _i, _vp, _vp, _i, _u64, _vp, _vp, _vp]),

@@ -139,6 +139,61 @@ __global__ __launch_bounds__(kThreads) void corr_rows_kernel(const float* __rest
   }
 }
 
+// avg_queries = False (poseEstSurf.py:72-96): per-PIXEL log-softmax, pooled per scale x scale block.  A workgroup owns
+// one row y of output cells: the `scale` pixel rows it needs sit in LDS with their log-sum-exps (from K1, one row per
+// pixel of the r x r crop), thread = key; per cell the scale^2 logits are formed in registers, the centre pixel's value
+// goes to corr_centre (the sampling matrix), the block maximum to corr_blockmax (the scoring matrix before the 3 x 3
+// pool) — the 15.8 GB full-resolution matrix is never formed, and the keys are read once per cell row instead of
+// three times per cell (round 2's one-workgroup-per-cell kernel: 45 ms of a 52 ms call).
+template <int DP>
+__global__ __launch_bounds__(kThreads) void corr_patch_kernel(const float* __restrict__ Qimg, const float* __restrict__ K, int r,
+                                                              int res, int scale, int N, int D, const float* __restrict__ lse,
+                                                              float* __restrict__ out_centre, float* __restrict__ out_bmax) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int n = blockIdx.x * kThreads + tid;
+  const int y = blockIdx.y;
+  const int wpix = res * scale;                     // pixel columns used (r // scale * scale)
+  const int nrows = scale * wpix;
+  float* qs = smem;
+  float* ls = smem + (size_t)nrows * DP;
+  for (int i = tid; i < nrows * DP; i += kThreads) {
+    const int rr = i / DP, d = i % DP;
+    const int py = y * scale + rr / wpix, px = rr % wpix;
+    qs[i] = d < D ? Qimg[((size_t)py * r + px) * D + d] : 0.f;
+  }
+  for (int i = tid; i < nrows; i += kThreads) ls[i] = lse[(size_t)(y * scale + i / wpix) * r + i % wpix];
+  float k[DP];
+#pragma unroll
+  for (int d = 0; d < DP; ++d) k[d] = (n < N && d < D) ? K[(size_t)n * D + d] : 0.f;
+  __syncthreads();
+  if (n >= N) return;
+  const int cy = scale / 2, cx = scale / 2;
+  for (int x = 0; x < res; ++x) {
+    float best = -__builtin_inff(), cen = 0.f;
+    for (int py = 0; py < scale; ++py)
+      for (int px = 0; px < scale; ++px) {
+        const int rr = py * wpix + x * scale + px;
+        const float4* q4 = reinterpret_cast<const float4*>(qs + (size_t)rr * DP);
+        float acc = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < DP / 4; ++d4) {
+          const float4 q = q4[d4];
+          acc = __builtin_fmaf(q.x, k[4 * d4], acc);
+          acc = __builtin_fmaf(q.y, k[4 * d4 + 1], acc);
+          acc = __builtin_fmaf(q.z, k[4 * d4 + 2], acc);
+          acc = __builtin_fmaf(q.w, k[4 * d4 + 3], acc);
+        }
+        const float v = acc - ls[rr];
+        best = fmaxf(best, v);
+        if (py == cy && px == cx) cen = v;
+      }
+    const size_t o = (size_t)(y * res + x) * N + n;
+    out_centre[o] = cen;
+    out_bmax[o] = best;
+  }
+}
+
 template <bool POOL>
 int launch_rows(const float* Q, const float* K, int P, int N, int D, int ldq, int ldk, const float* lse, int res, float* raw,
                 float* pool, int64_t ldo, hipStream_t stream) {
@@ -198,6 +253,36 @@ extern "C" int isr_ep_corr_matrices(const float* queries, const float* keys, int
   if (rc != ISR_OK) return rc;
   ISR_CHECK_LAUNCH("corr_rows_kernel");
   if (corr_pool && !fused) return isr_ep_pool_corr(corr_raw, res, m, corr_pool, stream_);     // wide descriptors / large crops
+  return ISR_OK;
+}
+
+extern "C" int isr_ep_patch_corr_cells(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
+                                       float* corr_centre, float* corr_blockmax, isr_stream_t stream);
+
+extern "C" size_t isr_ep_patch_corr_workspace_bytes(int r, int m, int e) {
+  if (r <= 0 || m <= 0 || e <= 0) return 0;
+  return isr_corr_logsoftmax_workspace_bytes(r * r, m, e, ISR_DTYPE_F32);
+}
+
+extern "C" int isr_ep_patch_corr(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
+                                 float* corr_centre, float* corr_blockmax, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(query_img && obj_keys && corr_centre && corr_blockmax, "isr_ep_patch_corr: null pointer");
+  ISR_REQUIRE(r > 0 && m > 0 && e > 0 && scale >= 1 && r / scale > 0, "isr_ep_patch_corr: r=%d e=%d scale=%d m=%d", r, e, scale, m);
+  const int res = r / scale;
+  const int DP = e <= 16 ? 16 : e <= 32 ? 32 : e <= 64 ? 64 : 128;
+  const size_t sh = (size_t)scale * res * scale * (DP + 1) * sizeof(float);
+  if (e > 128 || sh > 64 * 1024 || !ws || ws_bytes < isr_ep_patch_corr_workspace_bytes(r, m, e))
+    return isr_ep_patch_corr_cells(query_img, obj_keys, r, e, scale, m, corr_centre, corr_blockmax, stream_);   // one workgroup per cell
+  float* lse = nullptr;
+  const int rc = row_lse(query_img, obj_keys, r * r, m, e, e, e, ws, ws_bytes, &lse, stream_);     // one row per pixel of the crop
+  if (rc != ISR_OK) return rc;
+  hipStream_t stream = isr::as_stream(stream_);
+  const dim3 grid((m + kThreads - 1) / kThreads, res);
+  if (DP == 16) corr_patch_kernel<16><<<grid, kThreads, sh, stream>>>(query_img, obj_keys, r, res, scale, m, e, lse, corr_centre, corr_blockmax);
+  else if (DP == 32) corr_patch_kernel<32><<<grid, kThreads, sh, stream>>>(query_img, obj_keys, r, res, scale, m, e, lse, corr_centre, corr_blockmax);
+  else if (DP == 64) corr_patch_kernel<64><<<grid, kThreads, sh, stream>>>(query_img, obj_keys, r, res, scale, m, e, lse, corr_centre, corr_blockmax);
+  else corr_patch_kernel<128><<<grid, kThreads, sh, stream>>>(query_img, obj_keys, r, res, scale, m, e, lse, corr_centre, corr_blockmax);
+  ISR_CHECK_LAUNCH("corr_patch_kernel");
   return ISR_OK;
 }
 

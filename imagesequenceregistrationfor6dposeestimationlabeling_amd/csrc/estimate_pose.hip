@@ -543,8 +543,8 @@ extern "C" int isr_ep_prune(const int64_t* corr_idx, const double* poses, const 
   return ISR_OK;
 }
 
-extern "C" int isr_ep_patch_corr(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
-                                 float* corr_centre, float* corr_blockmax, isr_stream_t stream) {
+extern "C" int isr_ep_patch_corr_cells(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
+                                       float* corr_centre, float* corr_blockmax, isr_stream_t stream) {
   ISR_REQUIRE(query_img && obj_keys && corr_centre && corr_blockmax, "isr_ep_patch_corr: null pointer");
   ISR_REQUIRE(r > 0 && m > 0 && e > 0 && e <= kMaxE && scale >= 1 && scale * scale <= kMaxBlockPix && r / scale > 0,
               "isr_ep_patch_corr: r=%d e=%d (<= %d) scale=%d (<= 4) m=%d", r, e, kMaxE, scale, m);

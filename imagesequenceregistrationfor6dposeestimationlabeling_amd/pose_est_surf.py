@@ -93,8 +93,11 @@ def patch_corr(query_img: torch.Tensor, obj_keys: torch.Tensor, scale: int = 3):
     res = r // scale
     centre = torch.empty((res * res, m), dtype=torch.float32, device=dev)
     bmax = torch.empty((res * res, m), dtype=torch.float32, device=dev)
+    L = lib()
+    ws = ops.workspace(dev, L.isr_ep_patch_corr_workspace_bytes(r, m, e), "corr_lsm")
     with torch.cuda.device(dev):
-        rc = lib().isr_ep_patch_corr(ptr(qi), ptr(ok), r, e, int(scale), m, ptr(centre), ptr(bmax), current_stream(dev))
+        rc = L.isr_ep_patch_corr(ptr(qi), ptr(ok), r, e, int(scale), m, ptr(centre), ptr(bmax), ptr(ws), ws.numel(),
+                                 current_stream(dev))
     check(rc, "isr_ep_patch_corr")
     return centre, bmax, res
 

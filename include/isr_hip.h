@@ -303,8 +303,15 @@ int isr_ep_corr_matrices(const float* queries, const float* keys, int res, int m
  *                  scale x scale block without ever forming the (r^2 x m) matrix: corr_centre (n, m) = the value at
  *                  the block's centre pixel (offset scale // 2: the sampling matrix before exp), corr_blockmax (n, m) =
  *                  the block maximum (the scoring matrix before the 3x3 pool).  query_img (r, r, e), obj_keys (m, e) f32. */
+/* Round 3: the per-pixel log-sum-exps come from isr_corr_argmax's exact-f32 path (one row per pixel of the crop), then
+ * one pass with thread = key and a workgroup per row of output cells writes both matrices (ws from
+ * isr_ep_patch_corr_workspace_bytes; without ws, or when `scale` pixel rows of descriptors do not fit 64 KB of LDS, it falls
+ * back to isr_ep_patch_corr_cells: one workgroup per cell, three sweeps over the keys, no scratch). */
+size_t isr_ep_patch_corr_workspace_bytes(int r, int m, int e);
 int isr_ep_patch_corr(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
-                      float* corr_centre, float* corr_blockmax, isr_stream_t stream);
+                      float* corr_centre, float* corr_blockmax, void* ws, size_t ws_bytes, isr_stream_t stream);
+int isr_ep_patch_corr_cells(const float* query_img, const float* obj_keys, int r, int e, int scale, int m,
+                            float* corr_centre, float* corr_blockmax, isr_stream_t stream);
 size_t isr_ep_sample_workspace_bytes(int n, int m);
 int isr_ep_sample(const float* corr_log, const float* mask_prob, int n, int m, double alpha, int n_samples,
                   uint64_t seed, int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream);

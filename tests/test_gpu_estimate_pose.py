@@ -388,3 +388,24 @@ def test_estimate_pose_reference_size_stage_by_stage(cuda0, avg_queries):
     o2 = pes.estimate_pose(ml_d, q_d, pts_d, s["normals"], keys_d, s["diameter"], s["K"], poses=given, avg_queries=avg_queries)
     # (a coarse estimate from 4-point samples on a 74-pixel grid: near the planted pose's score, not necessarily at it)
     assert float(ps.max()) >= float(o2[2][0]) - 0.25 and float(ps.max()) > float(ps.median())
+
+
+def test_patch_corr_row_kernel_equals_cell_kernel(cuda0):
+    """isr_ep_patch_corr (round 3: per-pixel log-sum-exps from K1, one pass with a workgroup per row of cells) against
+    isr_ep_patch_corr_cells (round 2: one workgroup per cell, three sweeps): the same logits (k-ordered fmaf chains), the
+    log-sum-exp once merged in f64 and once summed in f32 -> 2e-6; odd sizes (r not a multiple of scale, m not of 256)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import pose_est_surf as pes
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd._capi import lib, ptr, current_stream, check
+    rng = np.random.default_rng(3)
+    r, e, m, scale = 50, 12, 1337, 3
+    q = torch.from_numpy(rng.normal(0, 1.0, (r, r, e)).astype(np.float32)).to(cuda0)
+    k = torch.from_numpy(rng.normal(0, 1.5, (m, e)).astype(np.float32)).to(cuda0)
+    centre, bmax, res = pes.patch_corr(q, k, scale)
+    c2, b2 = torch.empty_like(centre), torch.empty_like(bmax)
+    check(lib().isr_ep_patch_corr_cells(ptr(q), ptr(k), r, e, scale, m, ptr(c2), ptr(b2), current_stream(cuda0)), "cells")
+    torch.cuda.synchronize()
+    assert res == 16 and centre.shape == (256, m)
+    np.testing.assert_allclose(centre.cpu().numpy(), c2.cpu().numpy(), atol=2e-6, rtol=0)
+    np.testing.assert_allclose(bmax.cpu().numpy(), b2.cpu().numpy(), atol=2e-6, rtol=0)
+    # rows are log-probabilities: the block maximum dominates the centre value, exp sums to <= 1 per pixel
+    assert bool((bmax >= centre).all()) and float(torch.exp(centre).sum(dim=1).max()) <= 1.0 + 1e-4
