@@ -393,7 +393,7 @@ def test_estimate_pose_reference_size_stage_by_stage(cuda0, avg_queries):
 def test_patch_corr_row_kernel_equals_cell_kernel(cuda0):
     """isr_ep_patch_corr (round 3: per-pixel log-sum-exps from K1, one pass with a workgroup per row of cells) against
     isr_ep_patch_corr_cells (round 2: one workgroup per cell, three sweeps): the same logits (k-ordered fmaf chains), the
-    log-sum-exp once merged in f64 and once summed in f32 -> one f32 ulp of the value; odd sizes (r not a multiple of scale, m not of 256)."""
+    log-sum-exp once merged in f64 and once summed in f32 -> an f32 ulp or two of the logit; odd sizes (r not a multiple of scale, m not of 256)."""
     from imagesequenceregistrationfor6dposeestimationlabeling_amd import pose_est_surf as pes
     from imagesequenceregistrationfor6dposeestimationlabeling_amd._capi import lib, ptr, current_stream, check
     rng = np.random.default_rng(3)
@@ -405,7 +405,8 @@ def test_patch_corr_row_kernel_equals_cell_kernel(cuda0):
     check(lib().isr_ep_patch_corr_cells(ptr(q), ptr(k), r, e, scale, m, ptr(c2), ptr(b2), current_stream(cuda0)), "cells")
     torch.cuda.synchronize()
     assert res == 16 and centre.shape == (256, m)
-    np.testing.assert_allclose(centre.cpu().numpy(), c2.cpu().numpy(), atol=2e-6, rtol=3e-7)     # values of -20 .. -35: one f32 ulp
-    np.testing.assert_allclose(bmax.cpu().numpy(), b2.cpu().numpy(), atol=2e-6, rtol=3e-7)
+    # logit and log-sum-exp are both of magnitude 32 .. 64 (f32 ulp 3.8e-6) before they cancel: two ulps of THAT
+    np.testing.assert_allclose(centre.cpu().numpy(), c2.cpu().numpy(), atol=8e-6, rtol=0)
+    np.testing.assert_allclose(bmax.cpu().numpy(), b2.cpu().numpy(), atol=8e-6, rtol=0)
     # rows are log-probabilities: the block maximum dominates the centre value, exp sums to <= 1 per pixel
     assert bool((bmax >= centre).all()) and float(torch.exp(centre).sum(dim=1).max()) <= 1.0 + 1e-4
