@@ -772,7 +772,7 @@ NNPlan make_plan(int Nq, int Nt, int B, bool brute_only = false) {
   p.split_len = tiles_per_split * kTile;
   p.nsplit = (Nt + p.split_len - 1) / p.split_len;
   p.fblocks = (Nq + kThreads - 1) / kThreads;
-  // Three exact searches (tests compare them bit for bit; ISR_NN_GRID=0/1/2 forces one):
+  // Three exact searches (tests compare them bit for bit; the ISR_TUNE_NN_PATH knob forces one):
   //  0 brute force — the default for one or a few batch items (ICP steps, single ADD-S / Chamfer calls):
   //    at 20 000 points the launch is a few dozen microseconds and nothing is cheaper to set up;
   //  2 block-cooperative grid — the default for batches (the Chamfer pick, the n x n vote): measured
