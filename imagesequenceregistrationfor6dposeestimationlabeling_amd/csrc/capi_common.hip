@@ -24,13 +24,12 @@ namespace {
 struct Tuning {
   std::atomic<int> v[ISR_TUNE_COUNT];
   Tuning() {
-    const int defaults[ISR_TUNE_COUNT] = {-1, -1, 1, 0, 0, 0, 0, 0, 0};
+    const int defaults[ISR_TUNE_COUNT] = {-1, -1, 1, 0, 0, 0, 0, 0};
     for (int i = 0; i < ISR_TUNE_COUNT; ++i) v[i].store(defaults[i], std::memory_order_relaxed);
     // the environment is consulted here and nowhere else: once, before any entry point can run
     if (const char* e = getenv("ISR_NN_GRID")) { if (e[0] >= '0' && e[0] <= '2') v[ISR_TUNE_NN_PATH] = e[0] - '0'; }
     if (const char* e = getenv("ISR_NN_FILTER")) { if (e[0] == '0' || e[0] == '1') v[ISR_TUNE_NN_FILTER] = e[0] - '0'; }
     if (const char* e = getenv("ISR_ICP_WARM")) { if (e[0] == '0') v[ISR_TUNE_ICP_WARM] = 0; }
-    if (const char* e = getenv("ISR_K1_F32_PLAIN")) { if (e[0] == '1') v[ISR_TUNE_K1_F32_PLAIN] = 1; }
     if (const char* e = getenv("ISR_NN_PLAN")) {
       int rq = 0; long want = 0;
       if (sscanf(e, "%d,%ld", &rq, &want) >= 1) {

@@ -469,242 +469,6 @@ __global__ __launch_bounds__(kThreads) void corr_f32_kernel(
   }
 }
 
-// ---- exact f32, software-pipelined (round 3).  The same arithmetic as corr_f32_kernel — per canonical chunk the lane
-// state restarts; logits are the k-ordered fmaf chains of v_mfma_f32_32x32x2_f32; the chunk sum is relative to
-// M2 = ceil(m log2 e) of the running maximum and rescaled by exact powers of two — with two changes of FORM:
-//   * the running-maximum update is branch-free: M2n = ceil(max(m, t) log2 e) and l *= 2^(M2 - M2n) every tile (x 1.0
-//     when the maximum did not move: the same bits), only the TILE of the maximum is recorded (tb); its row is recovered
-//     once per chunk by recomputing that tile's 16 logits as fmaf chains — the chunk-restarted maximum is young, some
-//     lane of the wave moved it in 85 % of the tiles, and the row search inside that wave-uniform branch was a third of
-//     the kernel's 92 VALU instructions per tile (profiles/r03_k1_f32_pmc.txt);
-//   * with no branch in it, the epilogue of item w (a 32 x 32 tile of one query block) is interleaved with the MFMA
-//     chain of item w + 1 (sched_group_barrier, as corr_bf16_direct_kernel): the PMC run showed MFMA busy 0.46 + VALU
-//     active 0.55 = 1.0 — the two never overlapped.
-// The partial stage that ends a key range keeps the plain form (mask + consume); every stage ends on a barrier.
-template <int DP>
-__global__ __launch_bounds__(kThreads) void corr_f32_pipe_kernel(
-    const float* __restrict__ Q, const float* __restrict__ K, int P, int N, int D, int ldq, int ldk,
-    int range_chunks, CorrWs ws) {
-  constexpr int KS = DP / 2;
-  constexpr int LD = DP + 1;
-  constexpr int TKF = kTK;
-  static_assert(DP <= 64, "one 128-key stage of f32 rows must fit the LDS twice");
-  __shared__ float lds[2][TKF * LD];
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int r = lane & 31, h = lane >> 5;
-  const int split = blockIdx.y;
-  const int q0 = (blockIdx.x * kWaves + wave) * (kQB * 32);
-
-  float bq[kQB][KS];
-#pragma unroll
-  for (int qb = 0; qb < kQB; ++qb) {
-    int row = q0 + qb * 32 + r;
-    row = row < P ? row : P - 1;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int col = 2 * s + h;
-      bq[qb][s] = col < D ? Q[(size_t)row * ldq + col] : 0.f;
-    }
-  }
-  const int c0 = split * range_chunks;
-  const int cend = min((N + kChunk - 1) / kChunk, c0 + range_chunks);
-  bool nonzero = false;
-#pragma unroll
-  for (int qb = 0; qb < kQB; ++qb)
-#pragma unroll
-    for (int s = 0; s < KS; ++s) nonzero |= bq[qb][s] != 0.f;
-  if (!__syncthreads_or(nonzero ? 1 : 0)) {          // all-zero workgroup: see corr_f32_kernel
-#pragma unroll
-    for (int qb = 0; qb < kQB; ++qb) {
-      const int q = q0 + qb * 32 + r;
-      if (h != 0 || q >= P) continue;
-      for (int c = c0; c < cend; ++c) {
-        ws.pmc[(size_t)c * P + q] = 0.f;
-        ws.plc[(size_t)c * P + q] = (float)(min(N, (c + 1) * kChunk) - c * kChunk);
-      }
-      ws.pm[(size_t)split * P + q] = 0.f;
-      ws.pbi[(size_t)split * P + q] = c0 * kChunk;
-    }
-    return;
-  }
-
-  struct PS { float m, M2, l; int tb; };
-  PS st[kQB];
-  float gm[kQB];
-  int gbi[kQB];
-#pragma unroll
-  for (int qb = 0; qb < kQB; ++qb) { gm[qb] = -__builtin_inff(); gbi[qb] = 0; }
-
-  constexpr int NEL = (TKF * DP + kThreads - 1) / kThreads;
-  float stg[NEL];
-  // branch-free epilogue of one full tile (rows kb + 4h + (i & 3) + 8 (i >> 2) of this lane's query)
-  auto epilogue = [&](const f32x16& acc, int kb, PS& s) {
-    const float x0 = max3(acc[0], acc[1], acc[2]), x1 = max3(acc[3], acc[4], acc[5]),
-                x2 = max3(acc[6], acc[7], acc[8]), x3 = max3(acc[9], acc[10], acc[11]),
-                x4 = max3(acc[12], acc[13], acc[14]);
-    const float t = fmaxf(max3(x0, x1, x2), max3(x3, x4, acc[15]));
-    s.tb = (t > s.m) ? kb : s.tb;                    // strict: the first tile to reach the maximum keeps it
-    const float mn = fmaxf(s.m, t);
-    const float M2n = ceilf(mn * kLog2e);
-    float l = s.l * __builtin_amdgcn_exp2f(s.M2 - M2n);          // an exact power of two; 1 when the maximum did not move
-    s.M2 = M2n;
-    s.m = mn;
-    const float nM2 = -M2n;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) l += __builtin_amdgcn_exp2f(__builtin_fmaf(acc[i], kLog2e, nM2));
-    s.l = l;
-  };
-
-  for (int c = c0; c < cend; ++c) {
-    const int k0 = c * kChunk;
-    const int k1 = min(N, k0 + kChunk);
-    const int nstage = (k1 - k0 + TKF - 1) / TKF;
-    const int nfull = (k1 - k0) / TKF;
-#pragma unroll
-    for (int qb = 0; qb < kQB; ++qb) { st[qb].m = -__builtin_inff(); st[qb].M2 = kNoM2; st[qb].l = 0.f; st[qb].tb = k0; }
-    auto gload = [&](int stage) {
-#pragma unroll
-      for (int i = 0; i < NEL; ++i) {
-        const int e = tid + i * kThreads;
-        const int row = e / DP, col = e % DP;
-        const int key = k0 + stage * TKF + row;
-        stg[i] = (e < TKF * DP && key < k1 && col < D) ? K[(size_t)key * ldk + col] : 0.f;
-      }
-    };
-    auto lwrite = [&](int buf) {
-#pragma unroll
-      for (int i = 0; i < NEL; ++i) {
-        const int e = tid + i * kThreads;
-        if (e < TKF * DP) lds[buf][(e / DP) * LD + (e % DP)] = stg[i];
-      }
-    };
-    __syncthreads();                    // the previous chunk's last reads are done
-    gload(0);
-    lwrite(0);
-    __syncthreads();
-    for (int stage = 0; stage < nstage; ++stage) {
-      const int buf = stage & 1;
-      if (stage + 1 < nstage) gload(stage + 1);
-      if (stage < nfull) {
-        // ---- eight items (sub-tile, query block); item w + 1's MFMA chain carries item w's epilogue
-        constexpr int NW = (TKF / 32) * kQB;
-        f32x16 acc[2];
-        float a[KS];
-        auto load_a = [&](int sub) {
-          const float* arow = &lds[buf][(sub * 32 + r) * LD + h];
-#pragma unroll
-          for (int s = 0; s < KS; ++s) a[s] = arow[2 * s];
-        };
-        load_a(0);
-        acc[0] = splat16(0.f);
-#pragma unroll
-        for (int s = 0; s < KS; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[0][s], acc[0], 0, 0, 0);
-#pragma unroll
-        for (int w = 0; w < NW; ++w) {
-          const int sub = w / kQB, qb = w % kQB;
-          const int kb = k0 + stage * TKF + sub * 32;
-          if (w + 1 < NW) {
-            const int qbn = (w + 1) % kQB;
-            if (qbn == 0) load_a((w + 1) / kQB);       // the previous sub-tile's last chain has been issued
-            f32x16& nxt = acc[(w + 1) & 1];
-            nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bq[qbn][0], splat16(0.f), 0, 0, 0);
-#pragma unroll
-            for (int s = 1; s < KS; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bq[qbn][s], nxt, 0, 0, 0);
-          }
-          epilogue(acc[w & 1], kb + 4 * h, st[qb]);
-          if (w + 1 < NW) {
-            // 66 VALU instructions spread behind the KS MFMAs of the next item
-            constexpr int G = (66 + KS - 1) / KS;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-              __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
-            }
-            asm volatile("" : "+v"(acc[(w + 1) & 1]), "+v"(st[qb].l), "+v"(st[qb].m), "+v"(st[qb].M2), "+v"(st[qb].tb));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      } else {
-        // ---- the partial stage that ends the key range: plain form
-#pragma unroll
-        for (int sub = 0; sub < TKF / 32; ++sub) {
-          const int kb = k0 + stage * TKF + sub * 32;
-          if (kb < k1) {
-            const float* arow = &lds[buf][(sub * 32 + r) * LD + h];
-            f32x16 acc[kQB];
-#pragma unroll
-            for (int qb = 0; qb < kQB; ++qb) acc[qb] = splat16(0.f);
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-              const float av = arow[2 * s];
-#pragma unroll
-              for (int qb = 0; qb < kQB; ++qb)
-                acc[qb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bq[qb][s], acc[qb], 0, 0, 0);
-            }
-            if (kb + 32 > k1) {
-#pragma unroll
-              for (int qb = 0; qb < kQB; ++qb) mask_tail(acc[qb], kb + 4 * h, k1);
-            }
-#pragma unroll
-            for (int qb = 0; qb < kQB; ++qb) epilogue(acc[qb], kb + 4 * h, st[qb]);
-          }
-        }
-      }
-      if (stage + 1 < nstage) lwrite(buf ^ 1);
-      __syncthreads();
-    }
-    // ---- chunk end: the row of the lane's maximum inside tile tb, by recomputing its 16 logits (k-ordered fmaf
-    // chains from 0: what the MFMA produced, bit for bit); rows at or beyond k1 were masked and cannot be it
-#pragma unroll
-    for (int qb = 0; qb < kQB; ++qb) {
-      int qrow = q0 + qb * 32 + r;
-      qrow = qrow < P ? qrow : P - 1;
-      const int tb = st[qb].tb;                        // = (first key of the tile) + 4 h
-      float lg[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) lg[i] = 0.f;
-      for (int d = 0; d < D; ++d) {
-        const float qv = Q[(size_t)qrow * ldq + d];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          int key = tb + (i & 3) + 8 * (i >> 2);
-          key = key < k1 ? key : k1 - 1;
-          lg[i] = __builtin_fmaf(qv, K[(size_t)key * ldk + d], lg[i]);
-        }
-      }
-      int bi = tb;
-      bool found = false;
-#pragma unroll
-      for (int i = 15; i >= 0; --i) {
-        const int key = tb + (i & 3) + 8 * (i >> 2);
-        const bool hit = (key < k1) & (lg[i] == st[qb].m);
-        bi = hit ? key : bi;                           // descending i: the lowest key wins
-        found |= hit;
-      }
-      (void)found;
-      // the two lanes (h = 0, 1) of the query -> one (m, M2, l, bi)
-      LaneState a{st[qb].m, st[qb].M2, st[qb].l, bi};
-      const LaneState mgd = merged_with_other_half(a);
-      const int q = q0 + qb * 32 + r;
-      if (h == 0 && q < P) {
-        ws.pmc[(size_t)c * P + q] = mgd.m;
-        ws.plc[(size_t)c * P + q] = mgd.l;
-      }
-      if (mgd.m > gm[qb]) { gm[qb] = mgd.m; gbi[qb] = mgd.bi; }   // ascending chunks: ties keep the lower key
-    }
-  }
-#pragma unroll
-  for (int qb = 0; qb < kQB; ++qb) {
-    const int q = q0 + qb * 32 + r;
-    if (h == 0 && q < P) {
-      const size_t off = (size_t)split * P + q;
-      ws.pm[off] = gm[qb];
-      ws.pbi[off] = gbi[qb];
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------ key norms
 // max_n |k_n|^2 for the error bound of the margin test, one partial per block; block 0 also zeroes
 // the recheck counter of this call.
@@ -1021,21 +785,12 @@ int resident_slots(Kern kern) {
   return cus * per_cu;
 }
 
-constexpr int kPipeMaxD = 32;     // corr_f32_pipe_kernel: wider descriptors spill (256 VGPRs at D = 64)
-
 int slots_for(int dtype, int D) {
   // cached per (kernel family, padded D): the occupancy query costs tens of microseconds
-  static int cache[4][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+  static int cache[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   int v = 0;
   if (dtype != ISR_DTYPE_F32) v = (D <= 16) ? 0 : (D <= 32) ? 1 : (D <= 64) ? 2 : 3;
   else v = (D <= 8) ? 0 : (D <= 16) ? 1 : (D <= 32) ? 2 : (D <= 64) ? 3 : 4;
-  if (dtype == ISR_DTYPE_F32 && D <= kPipeMaxD && isr::tuning(ISR_TUNE_K1_F32_PLAIN) == 0) {
-    int& cp = cache[3][v];
-    if (cp == 0)
-      cp = v == 0 ? resident_slots(corr_f32_pipe_kernel<8>) : v == 1 ? resident_slots(corr_f32_pipe_kernel<16>)
-                  : resident_slots(corr_f32_pipe_kernel<32>);
-    return cp;
-  }
   int& c = cache[dtype == ISR_DTYPE_F32 ? 1 : dtype == ISR_DTYPE_BF16_LOG2 ? 2 : 0][v];
   if (c == 0) {
     if (dtype == ISR_DTYPE_BF16_LOG2) {
@@ -1199,20 +954,12 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     ISR_REQUIRE(D <= 128, "isr_corr_argmax(f32): D=%d > 128", D);
     const float* q = static_cast<const float*>(Q);
     const float* k = static_cast<const float*>(K);
-    const bool plain = isr::tuning(ISR_TUNE_K1_F32_PLAIN) != 0;     // tuning knob: the un-pipelined kernel (A/B, tests)
-    if (plain || D > kPipeMaxD) {
-      if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-      else if (D <= 12) corr_f32_kernel<12><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);   // the reference's 12-D descriptors: 6 k-steps, not 8
-      else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-      else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-      else if (D <= 64) corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-      else corr_f32_kernel<128><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-    } else {
-      if (D <= 8) corr_f32_pipe_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-      else if (D <= 12) corr_f32_pipe_kernel<12><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-      else if (D <= 16) corr_f32_pipe_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-      else corr_f32_pipe_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-    }
+    if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 12) corr_f32_kernel<12><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);   // the reference's 12-D descriptors: 6 k-steps, not 8
+    else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 64) corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else corr_f32_kernel<128><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
     corr_finalize_kernel<0><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
     ISR_CHECK_LAUNCH("corr f32 kernels");
   }

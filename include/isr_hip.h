@@ -61,8 +61,7 @@ int isr_device_count(void);
 #define ISR_TUNE_NN_TILE_ST 5    /* 0 default | target cell scale x 1000                                    ISR_NN_TILE="st,sq,tb" */
 #define ISR_TUNE_NN_TILE_SQ 6    /* 0 default | query cell scale x 1000 */
 #define ISR_TUNE_NN_TILE_TB 7    /* 0 default | 64 | 128 | 256 threads per workgroup */
-#define ISR_TUNE_K1_F32_PLAIN 8  /* 0 software-pipelined exact-f32 K1 (default, D <= 64) | 1 the plain kernel      ISR_K1_F32_PLAIN */
-#define ISR_TUNE_COUNT 9
+#define ISR_TUNE_COUNT 8
 int isr_tuning_set(int knob, int value);
 int isr_tuning_get(int knob);
 
