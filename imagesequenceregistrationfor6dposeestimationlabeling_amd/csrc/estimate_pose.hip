@@ -169,40 +169,174 @@ __global__ void ep_pool_corr_kernel(const float* __restrict__ in, int res, int m
 }
 
 // ------------------------------------------------------------------------ inversion sampling
-// weight of (pixel o, key k): (exp(corr_log) * mask_prob)^alpha, evaluated in f64 from the f32
-// inputs as exp(alpha * corr_log) * mask_prob^alpha so that a CPU restatement agrees to ~1e-16.
+// weight of (pixel o, key k): (exp(corr_log) * mask_prob)^alpha, evaluated in f64 from the f32 inputs as
+// exp(alpha * corr_log) * mask_prob^alpha so that a CPU restatement agrees to an ulp.  Two providers of corr_log[o][k]:
+//   matrix  the (n x m) array isr_corr_logsoftmax / isr_ep_corr_matrices wrote (isr_ep_sample);
+//   direct  <Q[g(o)], keys[k]> (k-ordered fmaf chain from 0) - lse[g(o)], formed in registers: the same bits as the matrix
+//           element, and the matrix never exists (isr_ep_sample_direct).
+// Both add a row's weights in ONE order — groups of kGroup consecutive keys sequentially, a chunk's kChunk / kGroup group
+// sums sequentially, chunks in order per row, rows in a fixed-shape scan — so the two providers return identical indices,
+// and the sampler can rebuild any chunk's partial sums with a wave (lane = group).
 constexpr int kChunk = 512;
+constexpr int kGroup = 8;            // kChunk / kGroup = 64 groups: one per lane of the sampler's wave
+constexpr int kRowsPerBlock = 256;
 
-__device__ __forceinline__ double ep_weight(float cl, double mpa, double alpha) { return exp(alpha * (double)cl) * mpa; }
-
-__global__ void ep_chunk_sums_kernel(const float* __restrict__ corr_log, const float* __restrict__ mask_prob, int m,
-                                     int nchunk, double alpha, double* __restrict__ chunk_sums) {
-  __shared__ double red[4];
-  __shared__ double mpa_s;
-  const int o = blockIdx.y, c = blockIdx.x;
-  if (threadIdx.x == 0) mpa_s = pow((double)mask_prob[o], alpha);     // once per workgroup (round 2: an f64 pow per thread)
-  __syncthreads();
-  const double mpa = mpa_s;
-  double s = 0.0;
-  for (int j = threadIdx.x; j < kChunk; j += 256) {
-    const int k = c * kChunk + j;
-    if (k < m) s += ep_weight(corr_log[(size_t)o * m + k], mpa, alpha);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) chunk_sums[(size_t)o * nchunk + c] = ((red[0] + red[1]) + red[2]) + red[3];
+// exp(x) in f64 for the sampler's arguments (x = alpha * log-probability <= ~0): round-to-nearest argument reduction by
+// ln 2 (hi/lo), degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18), one v_ldexp_f64.  About 20 f64
+// instructions against ~3x that for the library exp with its special cases; below -708 (subnormal results) it returns 0.
+__device__ __forceinline__ double ep_exp(double x) {
+  if (!(x >= -708.0)) return 0.0;
+  const double nf = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(nf, -6.93147180369123816490e-01, x);
+  r = __builtin_fma(nf, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;                      // 1/13!
+  p = __builtin_fma(p, r, 2.08767569878680989792e-09);    // 1/12!
+  p = __builtin_fma(p, r, 2.50521083854417187751e-08);    // 1/11!
+  p = __builtin_fma(p, r, 2.75573192239858906526e-07);    // 1/10!
+  p = __builtin_fma(p, r, 2.75573192239858906526e-06);    // 1/9!
+  p = __builtin_fma(p, r, 2.48015873015873015873e-05);    // 1/8!
+  p = __builtin_fma(p, r, 1.98412698412698412698e-04);    // 1/7!
+  p = __builtin_fma(p, r, 1.38888888888888888889e-03);    // 1/6!
+  p = __builtin_fma(p, r, 8.33333333333333333333e-03);    // 1/5!
+  p = __builtin_fma(p, r, 4.16666666666666666667e-02);    // 1/4!
+  p = __builtin_fma(p, r, 1.66666666666666666667e-01);    // 1/3!
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)nf);
 }
 
-// one thread per row: row sum (chunks in order); then thread 0 of block 0 is NOT used for the
-// row cumulative — ep_row_scan_kernel does the inclusive scan over rows.
-__global__ void ep_row_sums_kernel(const double* __restrict__ chunk_sums, int n, int nchunk, double* __restrict__ row_sums) {
+// explicit roundings: no fused multiply-add across the weight and the running sum (the oracle multiplies, then adds)
+__device__ __forceinline__ double ep_weight(float cl, double mpa, double alpha) {
+  return __dmul_rn(ep_exp(__dmul_rn(alpha, (double)cl)), mpa);
+}
+
+__global__ void ep_mpa_kernel(const float* __restrict__ mask_prob, int n, double alpha, double* __restrict__ mpa) {
   const int o = blockIdx.x * blockDim.x + threadIdx.x;
+  if (o < n) mpa[o] = pow((double)mask_prob[o], alpha);
+}
+
+// test / validation aid: the weights themselves
+__global__ void ep_weights_kernel(const float* __restrict__ corr_log, const double* __restrict__ mpa, int n, int m,
+                                  double alpha, double* __restrict__ w) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)n * m) w[i] = ep_weight(corr_log[i], mpa[i / m], alpha);
+}
+
+// matrix provider: workgroup = 256 rows x one chunk.  The chunk is walked in 32-key slices: the slice of every row is
+// read coalesced (half a wave per row), parked in LDS, then thread t adds row t's 32 weights in key order.
+__global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_kernel(const float* __restrict__ corr_log,
+                                                                      const double* __restrict__ mpa_all, int n, int m, int nchunk,
+                                                                      double alpha, double* __restrict__ chunk_sums) {
+  __shared__ float tile[kRowsPerBlock][33];
+  const int tid = threadIdx.x, c = blockIdx.x, o0 = blockIdx.y * kRowsPerBlock;
+  const int o = o0 + tid;
+  const double mpa = o < n ? mpa_all[o] : 0.0;
+  const int k0 = c * kChunk, kend = min(m, k0 + kChunk);
+  double s = 0.0;
+  for (int kb = k0; kb < kend; kb += 32) {
+    __syncthreads();
+    for (int i = tid; i < kRowsPerBlock * 32; i += kRowsPerBlock) {
+      const int rr = i >> 5, kk = i & 31;
+      tile[rr][kk] = (o0 + rr < n && kb + kk < kend) ? corr_log[(size_t)(o0 + rr) * m + kb + kk] : 0.f;
+    }
+    __syncthreads();
+    const int cnt = min(32, kend - kb);
+    for (int j0 = 0; j0 < cnt; j0 += kGroup) {
+      double s8 = 0.0;
+      for (int j = j0; j < min(cnt, j0 + kGroup); ++j) s8 = __dadd_rn(s8, ep_weight(tile[tid][j], mpa, alpha));
+      s = __dadd_rn(s, s8);
+    }
+  }
+  if (o < n) chunk_sums[(size_t)o * nchunk + c] = s;
+}
+
+// the grid of descriptors a direct provider reads: output pixel o = (oy, ox) of the res x res grid takes its query from grid
+// pixel g(o) = oy * sy + ox * sx + off (avg_queries: the pooled queries themselves, sy = res, sx = 1, off = 0; per-pixel
+// queries: the centre pixel of the scale x scale block of the r x r crop, sy = scale * r, sx = scale, off = (scale/2)(r+1))
+struct QGrid {
+  const float* q;      // (grid pixels, e)
+  const float* lse;    // (grid pixels): log-sum-exp of the pixel's logits over all keys (K1)
+  int e, res, sy, sx, off;
+  __device__ __forceinline__ int pixel(int o) const { return (o / res) * sy + (o % res) * sx + off; }
+};
+
+template <int DP>
+__device__ __forceinline__ void load_query(const QGrid& g, int o, float (&q)[DP], float* lse) {
+  const int px = g.pixel(o);
+#pragma unroll
+  for (int d = 0; d < DP; ++d) q[d] = d < g.e ? g.q[(size_t)px * g.e + d] : 0.f;
+  *lse = g.lse[px];
+}
+
+// direct provider: workgroup = 256 rows (thread = row, its query in registers) x one chunk of keys, staged through LDS in
+// slices of 8192 / DP keys and read back as broadcasts; per (row, key): DP fma, one subtraction, the f64 weight, one add.
+template <int DP>
+__global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_direct_kernel(QGrid g, const double* __restrict__ mpa_all,
+                                                                             const float* __restrict__ keys, int n, int m,
+                                                                             int nchunk, double alpha,
+                                                                             double* __restrict__ chunk_sums) {
+  constexpr int kSlice = 8192 / DP;
+  __shared__ __attribute__((aligned(16))) float ks[kSlice * DP];
+  const int tid = threadIdx.x, c = blockIdx.x;
+  const int o = blockIdx.y * kRowsPerBlock + tid;
+  float q[DP], lse = 0.f;
+  if (o < n) load_query<DP>(g, o, q, &lse);
+  else {
+#pragma unroll
+    for (int d = 0; d < DP; ++d) q[d] = 0.f;
+  }
+  const double mpa = o < n ? mpa_all[o] : 0.0;
+  const int k0 = c * kChunk, kend = min(m, k0 + kChunk);
+  double s = 0.0;
+  for (int kb = k0; kb < kend; kb += kSlice) {
+    __syncthreads();
+    for (int i = tid; i < kSlice * DP; i += kRowsPerBlock) {
+      const int kk = i / DP, d = i % DP;
+      ks[i] = (kb + kk < kend && d < g.e) ? keys[(size_t)(kb + kk) * g.e + d] : 0.f;
+    }
+    __syncthreads();
+    const int cnt = min(kSlice, kend - kb);
+    for (int j0 = 0; j0 < cnt; j0 += kGroup) {
+      double s8 = 0.0;
+      const int j1 = min(cnt, j0 + kGroup);
+      for (int j = j0; j < j1; ++j) {
+        const float4* k4 = reinterpret_cast<const float4*>(ks + j * DP);
+        float acc = 0.f;
+#pragma unroll
+        for (int d4 = 0; d4 < DP / 4; ++d4) {
+          const float4 kk = k4[d4];
+          acc = __builtin_fmaf(q[4 * d4], kk.x, acc);
+          acc = __builtin_fmaf(q[4 * d4 + 1], kk.y, acc);
+          acc = __builtin_fmaf(q[4 * d4 + 2], kk.z, acc);
+          acc = __builtin_fmaf(q[4 * d4 + 3], kk.w, acc);
+        }
+        s8 = __dadd_rn(s8, ep_weight(acc - lse, mpa, alpha));
+      }
+      s = __dadd_rn(s, s8);
+    }
+  }
+  if (o < n) chunk_sums[(size_t)o * nchunk + c] = s;
+}
+
+// a wave per row: the row's chunk sums are read coalesced, then added in chunk order (every lane runs the same chain on
+// broadcast values); ep_row_scan_kernel does the inclusive scan over rows.
+__device__ __forceinline__ double bcast_f64(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(256) void ep_row_sums_kernel(const double* __restrict__ chunk_sums, int n, int nchunk,
+                                                          double* __restrict__ row_sums) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (o >= n) return;
   double s = 0.0;
-  for (int c = 0; c < nchunk; ++c) s += chunk_sums[(size_t)o * nchunk + c];
-  row_sums[o] = s;
+  for (int base = 0; base < nchunk; base += 64) {
+    const double v = base + lane < nchunk ? chunk_sums[(size_t)o * nchunk + base + lane] : 0.0;
+    const int cnt = min(64, nchunk - base);
+    for (int i = 0; i < cnt; ++i) s += bcast_f64(v, i);
+  }
+  if (lane == 0) row_sums[o] = s;
 }
 
 // inclusive scan of the row sums by ONE workgroup of 1024 threads: thread t adds its contiguous slice of rows in order,
@@ -227,20 +361,25 @@ __global__ __launch_bounds__(1024) void ep_row_scan_kernel(const double* __restr
   for (int o = lo; o < hi; ++o) { run += row_sums[o]; row_cum[o] = run; }
 }
 
-// sample (s, j): u = (x + 0.5) / 2^32 of Philox(counter = (s,1,0,0)); index = first flat position
-// whose inclusive cumulative weight reaches u * total (np.searchsorted, side='left').
-__global__ void ep_sample_kernel(const float* __restrict__ corr_log, const float* __restrict__ mask_prob, int n, int m,
-                                 int nchunk, double alpha, const double* __restrict__ chunk_sums,
-                                 const double* __restrict__ row_sums, const double* __restrict__ row_cum, int n_samples,
-                                 uint32_t seed_lo, uint32_t seed_hi, int64_t* __restrict__ corr_idx) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// sample (s, j): u = (x + 0.5) / 2^32 of Philox(counter = (s,1,0,0)); index = first flat position whose inclusive
+// cumulative weight reaches u * total (np.searchsorted, side='left').  One WAVE per draw: every lane bisects the row scan
+// (uniform), the row's chunk sums are read 64 at a time and walked in order, then lane l rebuilds group l of the chunk
+// (its kGroup weights: the only expensive part, done 64-wide), the group sums are walked, and the winning group's weights.
+// DP = 0: the matrix provider (corr_log), else the direct one.  (Round 3, one THREAD per draw: 0.46 ms of dependent
+// 500-cycle steps for 40 000 draws.)
+template <int DP>
+__global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict__ corr_log, QGrid g,
+                                                        const float* __restrict__ keys, const double* __restrict__ mpa_all, int n,
+                                                        int m, int nchunk, double alpha, const double* __restrict__ chunk_sums,
+                                                        const double* __restrict__ row_cum, int n_samples, uint32_t seed_lo,
+                                                        uint32_t seed_hi, int64_t* __restrict__ corr_idx) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= n_samples * 4) return;
-  const int s = t >> 2, j = t & 3;
+  const int smp = t >> 2, j = t & 3;
   uint32_t rnd[4];
-  philox4x32_10((uint32_t)s, 1u, 0u, 0u, seed_lo, seed_hi, rnd);
+  philox4x32_10((uint32_t)smp, 1u, 0u, 0u, seed_lo, seed_hi, rnd);
   const double u = ((double)rnd[j] + 0.5) * (1.0 / 4294967296.0);
   const double target = u * row_cum[n - 1];
-  // row: first o with row_cum[o] >= target
   int lo = 0, hi = n - 1;
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -248,24 +387,77 @@ __global__ void ep_sample_kernel(const float* __restrict__ corr_log, const float
   }
   const int o = lo;
   double rem = target - (o ? row_cum[o - 1] : 0.0);
-  // chunk: first c whose inclusive in-row cumulative reaches rem
-  int c = 0;
-  double acc = 0.0;
-  for (; c < nchunk - 1; ++c) {
-    const double nx = acc + chunk_sums[(size_t)o * nchunk + c];
-    if (nx >= rem) break;
-    acc = nx;
+  // chunk: first c whose inclusive in-row cumulative reaches rem (the last one otherwise)
+  int c = nchunk - 1;
+  {
+    double acc = 0.0;
+    bool found = false;
+    for (int base = 0; base < nchunk && !found; base += 64) {
+      const double v = base + lane < nchunk ? chunk_sums[(size_t)o * nchunk + base + lane] : 0.0;
+      const int cnt = min(64, nchunk - base);
+      for (int i = 0; i < cnt; ++i) {
+        if (base + i == nchunk - 1) { found = true; break; }
+        const double nx = acc + bcast_f64(v, i);
+        if (nx >= rem) { c = base + i; found = true; break; }
+        acc = nx;
+      }
+    }
+    rem -= acc;
   }
-  rem -= acc;
-  const double mpa = pow((double)mask_prob[o], alpha);
-  int k = c * kChunk;
-  const int kend = min(m, k + kChunk);
-  double a2 = 0.0;
-  for (; k < kend - 1; ++k) {
-    a2 += ep_weight(corr_log[(size_t)o * m + k], mpa, alpha);
-    if (a2 >= rem) break;
+  // this lane's group of the chunk
+  const double mpa = mpa_all[o];
+  const int k0 = c * kChunk, kend = min(m, k0 + kChunk);
+  const int ngroups = (kend - k0 + kGroup - 1) / kGroup;
+  const int kg = k0 + lane * kGroup;
+  double w[kGroup];
+  if constexpr (DP == 0) {
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) w[i] = kg + i < kend ? ep_weight(corr_log[(size_t)o * m + kg + i], mpa, alpha) : 0.0;
+  } else {
+    constexpr int DQ = DP ? DP : 4;
+    float q[DQ], lse;
+    load_query<DQ>(g, o, q, &lse);
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+      float acc = 0.f;
+      if (kg + i < kend) {
+        const float* kr = keys + (size_t)(kg + i) * g.e;
+#pragma unroll
+        for (int d = 0; d < DQ; ++d) acc = __builtin_fmaf(q[d], d < g.e ? kr[d] : 0.f, acc);
+      }
+      w[i] = kg + i < kend ? ep_weight(acc - lse, mpa, alpha) : 0.0;
+    }
   }
-  corr_idx[t] = (int64_t)o * m + k;
+  double s8 = 0.0;
+#pragma unroll
+  for (int i = 0; i < kGroup; ++i)
+    if (kg + i < kend) s8 = __dadd_rn(s8, w[i]);
+  // group: first whose inclusive in-chunk cumulative reaches rem (the last non-empty one otherwise)
+  int gi = ngroups - 1;
+  {
+    double acc = 0.0;
+    for (int i = 0; i < ngroups - 1; ++i) {
+      const double nx = __dadd_rn(acc, bcast_f64(s8, i));
+      if (nx >= rem) { gi = i; break; }
+      acc = nx;
+    }
+    rem -= acc;
+  }
+  // key inside the group (the last valid one otherwise)
+  const int cnt = min(kGroup, kend - (k0 + gi * kGroup));
+  int kk = cnt - 1;
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < kGroup; ++i) {
+      const double wi = bcast_f64(w[i], gi);
+      if (i < cnt - 1 && kk == cnt - 1) {
+        acc = __dadd_rn(acc, wi);
+        if (acc >= rem) kk = i;
+      }
+    }
+  }
+  if (lane == 0) corr_idx[t] = (int64_t)o * m + k0 + gi * kGroup + kk;
 }
 
 // ------------------------------------------------------------------------------------- P3P
@@ -340,6 +532,7 @@ __device__ __forceinline__ float unordered_f32(uint32_t u) {
 }
 
 struct K9f { float k[9]; };
+constexpr size_t kFusedLdsMax = 144 * 1024;      // of gfx950's 160 KB per workgroup: res <= 110 with the fused z-buffer
 
 __global__ void zbuf_project_kernel(const float* __restrict__ pts, int m, const float* __restrict__ Rt, int B, K9f K,
                                     int res, unsigned long long* __restrict__ zbuf) {
@@ -359,6 +552,8 @@ __global__ void zbuf_project_kernel(const float* __restrict__ pts, int m, const 
   if (!(ux >= 0.f) || !(ux < (float)res) || !(uy >= 0.f) || !(uy < (float)res)) return;  // ignore bin (NaN too)
   const int pix = (int)uy * res + (int)ux;
   const unsigned long long key = ((unsigned long long)ordered_u32(cz) << 32) | (unsigned)v;
+  // (a read-and-compare in front of the atomic was measured in round 3: 1.63 ms against 0.5 ms — the returning load costs
+  // more than the fire-and-forget atomic it saves)
   atomicMin(&zbuf[(size_t)b * res * res + pix], key);
 }
 
@@ -394,6 +589,161 @@ __global__ __launch_bounds__(256) void zbuf_score_kernel(const unsigned long lon
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    const double tm = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    const double tc = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    const double tn = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+    const float ms = (float)(tm / (double)n / 0.6931471805599453);
+    const float cs = tn > 0.0 ? (float)(tc / tn / log((double)m)) : -__builtin_inff();
+    mask_score[b] = ms;
+    coord_score[b] = cs;
+    pose_score[b] = ms + cs;
+  }
+}
+
+// the same scores with corr_log[pixel, vertex] formed on the spot (no matrix): the pooled log-correspondence of output pixel
+// (py, px) and key v is the maximum, over the grid pixels of its window, of <q_g, key_v> (k-ordered fmaf chain) - lse_g —
+// window = the output pixels (py-1..py+1, px-1..px+1) inside the res x res grid when `pool` (F.max_pool2d pads with -inf),
+// else the pixel itself, each output pixel standing for win x win grid pixels (1: pooled queries, scale: per-pixel queries).
+// The elements are the ones isr_ep_corr_matrices / isr_ep_patch_corr + isr_ep_pool_corr write, bit for bit.
+template <int DP>
+__global__ __launch_bounds__(256) void zbuf_score_direct_kernel(const unsigned long long* __restrict__ zbuf, int res, int m,
+                                                                const float* __restrict__ mlp, const float* __restrict__ nmlp,
+                                                                const float* __restrict__ qgrid, const float* __restrict__ lse_grid,
+                                                                int g_pitch, int e, int win, int pool,
+                                                                const float* __restrict__ keys, float* __restrict__ pose_score,
+                                                                float* __restrict__ mask_score, float* __restrict__ coord_score) {
+  __shared__ double red[3][4];
+  const int b = blockIdx.x, n = res * res;
+  double sm = 0.0, sc = 0.0, cnt = 0.0;
+  for (int pix = threadIdx.x; pix < n; pix += 256) {
+    const unsigned long long key = zbuf[(size_t)b * n + pix];
+    bool hit = false;
+    if (key != ~0ull) {
+      const float z = unordered_f32((uint32_t)(key >> 32));
+      if (z > 0.f) {
+        hit = true;
+        const float* kr = keys + (size_t)(uint32_t)key * e;
+        float k[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) k[d] = d < e ? kr[d] : 0.f;
+        const int py = pix / res, px = pix % res;
+        const int y0 = (pool ? max(0, py - 1) : py) * win, y1 = (pool ? min(res, py + 2) : py + 1) * win;
+        const int x0 = (pool ? max(0, px - 1) : px) * win, x1 = (pool ? min(res, px + 2) : px + 1) * win;
+        float best = -__builtin_inff();
+        for (int gy = y0; gy < y1; ++gy)
+          for (int gx = x0; gx < x1; ++gx) {
+            const size_t gp = (size_t)gy * g_pitch + gx;
+            const float* qr = qgrid + gp * e;
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) acc = __builtin_fmaf(d < e ? qr[d] : 0.f, k[d], acc);
+            best = fmaxf(best, acc - lse_grid[gp]);
+          }
+        sc += (double)best;
+        cnt += 1.0;
+      }
+    }
+    sm += (double)(hit ? mlp[pix] : nmlp[pix]);
+  }
+  double v[3] = {sm, sc, cnt};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double s = v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tm = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+    const double tc = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+    const double tn = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
+    const float ms = (float)(tm / (double)n / 0.6931471805599453);
+    const float cs = tn > 0.0 ? (float)(tc / tn / log((double)m)) : -__builtin_inff();
+    mask_score[b] = ms;
+    coord_score[b] = cs;
+    pose_score[b] = ms + cs;
+  }
+}
+
+// The direct scorer, fused with its z-buffer: one workgroup of 1024 threads per pose keeps the res x res buffer of packed
+// (ordered z, vertex) words in LDS (43.8 KB at res = 74), projects all m vertices into it with LDS atomics, evaluates the
+// pooled log-correspondence of every hit pixel 1024-wide into a second LDS array, and its first 256 threads then add the
+// pixels in exactly zbuf_score_kernel's order (thread t: pixels t, t + 256, ... in f64; 64-lane tree; four wave partials).
+// No global z-buffer, no memset, no global atomics: round 3's zbuf_project_kernel was 0.5 ms per 224 poses (4.4 ms per
+// 1 000) of L2 atomics on ~50 vertices per covered pixel.
+template <int DP>
+__global__ __launch_bounds__(1024) void zbuf_fused_direct_kernel(const float* __restrict__ pts, int m, const float* __restrict__ Rt,
+                                                                 K9f K, int res, const float* __restrict__ mlp,
+                                                                 const float* __restrict__ nmlp, const float* __restrict__ qgrid,
+                                                                 const float* __restrict__ lse_grid, int g_pitch, int e, int win,
+                                                                 int pool, const float* __restrict__ keys,
+                                                                 float* __restrict__ pose_score, float* __restrict__ mask_score,
+                                                                 float* __restrict__ coord_score) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long zb[];     // n words, then n floats
+  __shared__ double red[3][4];
+  const int b = blockIdx.x, n = res * res, tid = threadIdx.x;
+  float* val = reinterpret_cast<float*>(zb + n);
+  for (int i = tid; i < n; i += 1024) zb[i] = ~0ull;
+  __syncthreads();
+  const float* T = Rt + 12 * (size_t)b;
+  for (int v = tid; v < m; v += 1024) {
+    const float x = pts[3 * (size_t)v], y = pts[3 * (size_t)v + 1], z = pts[3 * (size_t)v + 2];
+    const float cx = x * T[0] + y * T[1] + z * T[2] + T[3];
+    const float cy = x * T[4] + y * T[5] + z * T[6] + T[7];
+    const float cz = x * T[8] + y * T[9] + z * T[10] + T[11];
+    const float ix = cx * K.k[0] + cy * K.k[1] + cz * K.k[2];
+    const float iy = cx * K.k[3] + cy * K.k[4] + cz * K.k[5];
+    const float iz = cx * K.k[6] + cy * K.k[7] + cz * K.k[8];
+    const float ux = rintf(ix / iz), uy = rintf(iy / iz);
+    if (!(ux >= 0.f) || !(ux < (float)res) || !(uy >= 0.f) || !(uy < (float)res)) continue;
+    atomicMin(&zb[(int)uy * res + (int)ux], ((unsigned long long)ordered_u32(cz) << 32) | (unsigned)v);
+  }
+  __syncthreads();
+  for (int pix = tid; pix < n; pix += 1024) {
+    const unsigned long long key = zb[pix];
+    float best = 0.f;
+    if (key != ~0ull && unordered_f32((uint32_t)(key >> 32)) > 0.f) {
+      const float* kr = keys + (size_t)(uint32_t)key * e;
+      float k[DP];
+#pragma unroll
+      for (int d = 0; d < DP; ++d) k[d] = d < e ? kr[d] : 0.f;
+      const int py = pix / res, px = pix % res;
+      const int y0 = (pool ? max(0, py - 1) : py) * win, y1 = (pool ? min(res, py + 2) : py + 1) * win;
+      const int x0 = (pool ? max(0, px - 1) : px) * win, x1 = (pool ? min(res, px + 2) : px + 1) * win;
+      best = -__builtin_inff();
+      for (int gy = y0; gy < y1; ++gy)
+        for (int gx = x0; gx < x1; ++gx) {
+          const size_t gp = (size_t)gy * g_pitch + gx;
+          const float* qr = qgrid + gp * e;
+          float acc = 0.f;
+#pragma unroll
+          for (int d = 0; d < DP; ++d) acc = __builtin_fmaf(d < e ? qr[d] : 0.f, k[d], acc);
+          best = fmaxf(best, acc - lse_grid[gp]);
+        }
+    }
+    val[pix] = best;
+  }
+  __syncthreads();
+  double sm = 0.0, sc = 0.0, cnt = 0.0;
+  if (tid < 256) {
+    for (int pix = tid; pix < n; pix += 256) {
+      const unsigned long long key = zb[pix];
+      const bool hit = key != ~0ull && unordered_f32((uint32_t)(key >> 32)) > 0.f;
+      if (hit) { sc += (double)val[pix]; cnt += 1.0; }
+      sm += (double)(hit ? mlp[pix] : nmlp[pix]);
+    }
+    double v3[3] = {sm, sc, cnt};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double s = v3[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+      if ((tid & 63) == 0) red[i][tid >> 6] = s;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
     const double tm = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
     const double tc = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
     const double tn = ((red[2][0] + red[2][1]) + red[2][2]) + red[2][3];
@@ -558,30 +908,95 @@ extern "C" int isr_ep_patch_corr_cells(const float* query_img, const float* obj_
 extern "C" size_t isr_ep_sample_workspace_bytes(int n, int m) {
   if (n <= 0 || m <= 0) return 0;
   const size_t nchunk = ((size_t)m + kChunk - 1) / kChunk;
-  return isr::align_up(sizeof(double) * n * nchunk, 256) + 2 * isr::align_up(sizeof(double) * n, 256) + 512;
+  return isr::align_up(sizeof(double) * n * nchunk, 256) + 3 * isr::align_up(sizeof(double) * n, 256) + 512;
 }
+
+namespace {
+
+struct SampleWs { double *chunk_sums, *row_sums, *row_cum, *mpa; int nchunk; };
+
+int sample_ws(const char* who, const float* mask_prob, int n, int m, double alpha, void* ws, size_t ws_bytes, hipStream_t stream,
+              SampleWs* out) {
+  if (!ws || ws_bytes < isr_ep_sample_workspace_bytes(n, m)) {
+    isr::set_error("%s: workspace %zu < %zu", who, ws_bytes, isr_ep_sample_workspace_bytes(n, m));
+    return ISR_ERR_WORKSPACE;
+  }
+  isr::Workspace w(ws, ws_bytes);
+  out->nchunk = (m + kChunk - 1) / kChunk;
+  out->chunk_sums = w.take<double>((size_t)n * out->nchunk);
+  out->row_sums = w.take<double>(n);
+  out->row_cum = w.take<double>(n);
+  out->mpa = w.take<double>(n);
+  ep_mpa_kernel<<<(n + 255) / 256, 256, 0, stream>>>(mask_prob, n, alpha, out->mpa);
+  return ISR_OK;
+}
+
+void sample_rows(const SampleWs& sw, int n, hipStream_t stream) {
+  ep_row_sums_kernel<<<(n + 3) / 4, 256, 0, stream>>>(sw.chunk_sums, n, sw.nchunk, sw.row_sums);
+  ep_row_scan_kernel<<<1, 1024, 0, stream>>>(sw.row_sums, n, sw.row_cum);
+}
+
+}  // namespace
 
 extern "C" int isr_ep_sample(const float* corr_log, const float* mask_prob, int n, int m, double alpha, int n_samples,
                              uint64_t seed, int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream_) {
   ISR_REQUIRE(corr_log && mask_prob && corr_idx, "isr_ep_sample: null pointer");
-  ISR_REQUIRE(n > 0 && m > 0 && n_samples > 0 && n <= 65535, "isr_ep_sample: n=%d m=%d n_samples=%d", n, m, n_samples);
-  if (!ws || ws_bytes < isr_ep_sample_workspace_bytes(n, m)) {
-    isr::set_error("isr_ep_sample: workspace %zu < %zu", ws_bytes, isr_ep_sample_workspace_bytes(n, m));
-    return ISR_ERR_WORKSPACE;
-  }
+  ISR_REQUIRE(n > 0 && m > 0 && n_samples > 0, "isr_ep_sample: n=%d m=%d n_samples=%d", n, m, n_samples);
   hipStream_t stream = isr::as_stream(stream_);
-  const int nchunk = (m + kChunk - 1) / kChunk;
-  isr::Workspace w(ws, ws_bytes);
-  double* chunk_sums = w.take<double>((size_t)n * nchunk);
-  double* row_sums = w.take<double>(n);
-  double* row_cum = w.take<double>(n);
-  ep_chunk_sums_kernel<<<dim3(nchunk, n), 256, 0, stream>>>(corr_log, mask_prob, m, nchunk, alpha, chunk_sums);
-  ep_row_sums_kernel<<<(n + 255) / 256, 256, 0, stream>>>(chunk_sums, n, nchunk, row_sums);
-  ep_row_scan_kernel<<<1, 1024, 0, stream>>>(row_sums, n, row_cum);
-  ep_sample_kernel<<<(n_samples * 4 + 255) / 256, 256, 0, stream>>>(corr_log, mask_prob, n, m, nchunk, alpha, chunk_sums,
-                                                                   row_sums, row_cum, n_samples, (uint32_t)seed,
-                                                                   (uint32_t)(seed >> 32), corr_idx);
+  SampleWs sw;
+  const int rc = sample_ws("isr_ep_sample", mask_prob, n, m, alpha, ws, ws_bytes, stream, &sw);
+  if (rc != ISR_OK) return rc;
+  ep_chunk_sums_kernel<<<dim3(sw.nchunk, (n + kRowsPerBlock - 1) / kRowsPerBlock), kRowsPerBlock, 0, stream>>>(
+      corr_log, sw.mpa, n, m, sw.nchunk, alpha, sw.chunk_sums);
+  sample_rows(sw, n, stream);
+  ep_sample_kernel<0><<<n_samples, 256, 0, stream>>>(corr_log, QGrid{}, nullptr, sw.mpa, n, m, sw.nchunk, alpha, sw.chunk_sums,
+                                                     sw.row_cum, n_samples, (uint32_t)seed, (uint32_t)(seed >> 32), corr_idx);
   ISR_CHECK_LAUNCH("ep_sample kernels");
+  return ISR_OK;
+}
+
+extern "C" int isr_ep_sample_direct(const float* qgrid, const float* lse_grid, int g_pitch, int e, int win, int res,
+                                    const float* mask_prob, const float* keys, int m, double alpha, int n_samples,
+                                    uint64_t seed, int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(qgrid && lse_grid && mask_prob && keys && corr_idx, "isr_ep_sample_direct: null pointer");
+  ISR_REQUIRE(res > 0 && m > 0 && n_samples > 0 && e > 0 && e <= 128 && win >= 1 && g_pitch >= res * win,
+              "isr_ep_sample_direct: res=%d m=%d n_samples=%d e=%d (<= 128) win=%d g_pitch=%d (>= res * win)", res, m, n_samples,
+              e, win, g_pitch);
+  hipStream_t stream = isr::as_stream(stream_);
+  const int n = res * res;
+  SampleWs sw;
+  const int rc = sample_ws("isr_ep_sample_direct", mask_prob, n, m, alpha, ws, ws_bytes, stream, &sw);
+  if (rc != ISR_OK) return rc;
+  const QGrid g{qgrid, lse_grid, e, res, win * g_pitch, win, (win / 2) * (g_pitch + 1)};
+  const dim3 grid(sw.nchunk, (n + kRowsPerBlock - 1) / kRowsPerBlock);
+  const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+#define ISR_EP_DIRECT(DPv)                                                                                                    \
+  do {                                                                                                                        \
+    ep_chunk_sums_direct_kernel<DPv><<<grid, kRowsPerBlock, 0, stream>>>(g, sw.mpa, keys, n, m, sw.nchunk, alpha, sw.chunk_sums); \
+    sample_rows(sw, n, stream);                                                                                               \
+    ep_sample_kernel<DPv><<<n_samples, 256, 0, stream>>>(nullptr, g, keys, sw.mpa, n, m, sw.nchunk, alpha, sw.chunk_sums,       \
+                                                         sw.row_cum, n_samples, slo, shi, corr_idx);                          \
+  } while (0)
+  if (e <= 16) ISR_EP_DIRECT(16);
+  else if (e <= 32) ISR_EP_DIRECT(32);
+  else if (e <= 64) ISR_EP_DIRECT(64);
+  else ISR_EP_DIRECT(128);
+#undef ISR_EP_DIRECT
+  ISR_CHECK_LAUNCH("ep_sample_direct kernels");
+  return ISR_OK;
+}
+
+extern "C" int isr_ep_sample_weights(const float* corr_log, const float* mask_prob, int n, int m, double alpha, double* weights,
+                                     void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(corr_log && mask_prob && weights, "isr_ep_sample_weights: null pointer");
+  ISR_REQUIRE(n > 0 && m > 0, "isr_ep_sample_weights: n=%d m=%d", n, m);
+  hipStream_t stream = isr::as_stream(stream_);
+  SampleWs sw;
+  const int rc = sample_ws("isr_ep_sample_weights", mask_prob, n, m, alpha, ws, ws_bytes, stream, &sw);
+  if (rc != ISR_OK) return rc;
+  const size_t tot = (size_t)n * m;
+  ep_weights_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, stream>>>(corr_log, sw.mpa, n, m, alpha, weights);
+  ISR_CHECK_LAUNCH("ep_weights_kernel");
   return ISR_OK;
 }
 
@@ -624,5 +1039,49 @@ extern "C" int isr_zbuf_score(const float* obj_pts, int m, const float* Rt, int 
   zbuf_score_kernel<<<B, 256, 0, stream>>>(zbuf, n, m, mask_log_prob, neg_mask_log_prob, corr_log, pose_score, mask_score,
                                            coord_score);
   ISR_CHECK_LAUNCH("zbuf kernels");
+  return ISR_OK;
+}
+
+extern "C" int isr_zbuf_score_direct(const float* obj_pts, int m, const float* Rt, int B, const double* Kcam, int res,
+                                     const float* mask_log_prob, const float* neg_mask_log_prob, const float* qgrid,
+                                     const float* lse_grid, int g_pitch, int e, int win, int pool, const float* keys,
+                                     float* pose_score, float* mask_score, float* coord_score, void* ws, size_t ws_bytes,
+                                     isr_stream_t stream_) {
+  ISR_REQUIRE(obj_pts && Rt && Kcam && mask_log_prob && neg_mask_log_prob && qgrid && lse_grid && keys && pose_score &&
+                  mask_score && coord_score, "isr_zbuf_score_direct: null pointer");
+  ISR_REQUIRE(m > 0 && B > 0 && B <= 65535 && res > 0 && e > 0 && e <= 128 && win >= 1 && g_pitch >= res * win,
+              "isr_zbuf_score_direct: m=%d B=%d res=%d e=%d (<= 128) win=%d g_pitch=%d (>= res * win)", m, B, res, e, win, g_pitch);
+  hipStream_t stream = isr::as_stream(stream_);
+  const int n = res * res;
+  K9f K;
+  for (int i = 0; i < 9; ++i) K.k[i] = (float)Kcam[i];
+  const size_t lds = (size_t)n * (sizeof(unsigned long long) + sizeof(float));
+  if (lds <= kFusedLdsMax) {       // the z-buffer lives in LDS: one launch, no scratch
+#define ISR_ZB_FUSED(DPv)                                                                                                     \
+  do {                                                                                                                        \
+    if (lds > 64 * 1024)     /* per device, so not cached in a static */                                                      \
+      ISR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zbuf_fused_direct_kernel<DPv>),                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsMax));                     \
+    zbuf_fused_direct_kernel<DPv><<<B, 1024, lds, stream>>>(obj_pts, m, Rt, K, res, mask_log_prob, neg_mask_log_prob, qgrid,  \
+                                                            lse_grid, g_pitch, e, win, pool ? 1 : 0, keys, pose_score,        \
+                                                            mask_score, coord_score);                                         \
+  } while (0)
+    if (e <= 16) ISR_ZB_FUSED(16);
+    else if (e <= 32) ISR_ZB_FUSED(32);
+    else if (e <= 64) ISR_ZB_FUSED(64);
+    else ISR_ZB_FUSED(128);
+#undef ISR_ZB_FUSED
+    ISR_CHECK_LAUNCH("zbuf_fused_direct_kernel");
+    return ISR_OK;
+  }
+  if (!ws || ws_bytes < isr_zbuf_score_workspace_bytes(B, res)) {
+    isr::set_error("isr_zbuf_score_direct: workspace %zu < %zu", ws_bytes, isr_zbuf_score_workspace_bytes(B, res));
+    return ISR_ERR_WORKSPACE;
+  }
+  isr::Workspace w(ws, ws_bytes);
+  unsigned long long* zbuf = w.take<unsigned long long>((size_t)B * n);
+  ISR_CHECK_HIP(hipMemsetAsync(zbuf, 0xFF, sizeof(unsigned long long) * (size_t)B * n, stream));
+  zbuf_project_kernel<<<dim3((m + 255) / 256, B), 256, 0, stream>>>(obj_pts, m, Rt, B, K, res, zbuf);
+#define ISR_ZB_DIRECT  ISR_CHECK_LAUNCH("zbuf direct kernels");
   return ISR_OK;
 }

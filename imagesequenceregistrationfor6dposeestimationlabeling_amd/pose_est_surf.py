@@ -115,6 +115,60 @@ def sample(corr_log: torch.Tensor, mask_prob: torch.Tensor, alpha: float, n_samp
     return idx
 
 
+class DescriptorGrid:
+    """What the matrix-free stages read instead of an (n, m) matrix: the grid of query descriptors, the log-sum-exp of
+    each grid pixel's logits over all keys (K1's exact-f32 path) and the keys.  Element (grid pixel g, key k) =
+    <q[g], keys[k]> - lse[g], bit for bit the entry corr_matrices / patch_corr would have written.
+    avg_queries=True : the pooled queries, one grid pixel per output pixel (win = 1, poseEstSurf.py:70);
+    avg_queries=False: the crop's own pixels, win = scale grid pixels per output pixel (poseEstSurf.py:72-96)."""
+
+    def __init__(self, q: torch.Tensor, keys: torch.Tensor, res: int, pitch: int, win: int):
+        require_cuda(q, keys)
+        self.q = q.to(torch.float32).contiguous().view(-1, q.shape[-1])
+        self.keys = keys.to(torch.float32).contiguous()
+        self.res, self.pitch, self.win, self.e = int(res), int(pitch), int(win), int(self.q.shape[1])
+        if self.keys.shape[1] != self.e or self.pitch < self.res * self.win or self.q.shape[0] < self.pitch * (self.res * self.win - 1) + self.res * self.win:
+            raise ValueError(f"DescriptorGrid: q {tuple(self.q.shape)} keys {tuple(self.keys.shape)} res {res} pitch {pitch} win {win}")
+        _, _, self.lse = ops.corr_argmax(self.q, self.keys, want_lse=True)
+
+    @classmethod
+    def pooled(cls, queries: torch.Tensor, keys: torch.Tensor, res: int):
+        return cls(queries, keys, res, res, 1)
+
+    @classmethod
+    def per_pixel(cls, query_img: torch.Tensor, keys: torch.Tensor, scale: int):
+        return cls(query_img, keys, query_img.shape[0] // scale, query_img.shape[1], scale)
+
+
+def sample_direct(grid: DescriptorGrid, mask_prob: torch.Tensor, alpha: float, n_samples: int, seed: int) -> torch.Tensor:
+    """isr_ep_sample_direct: sample()'s indices without the matrix."""
+    dev = require_cuda(mask_prob)
+    n, m = grid.res * grid.res, grid.keys.shape[0]
+    idx = torch.empty((n_samples, 4), dtype=torch.int64, device=dev)
+    L = lib()
+    ws = ops.workspace(dev, L.isr_ep_sample_workspace_bytes(n, m), "ep_sample")
+    with torch.cuda.device(dev):
+        rc = L.isr_ep_sample_direct(ptr(grid.q), ptr(grid.lse), grid.pitch, grid.e, grid.win, grid.res, ptr(mask_prob),
+                                    ptr(grid.keys), m, float(alpha), int(n_samples), seed & 0xFFFFFFFFFFFFFFFF, ptr(idx),
+                                    ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_ep_sample_direct")
+    return idx
+
+
+def sample_weights(corr_log: torch.Tensor, mask_prob: torch.Tensor, alpha: float) -> torch.Tensor:
+    """isr_ep_sample_weights: the (n, m) f64 weights the sampler adds (validation aid)."""
+    dev = require_cuda(corr_log, mask_prob)
+    n, m = corr_log.shape
+    w = torch.empty((n, m), dtype=torch.float64, device=dev)
+    L = lib()
+    ws = ops.workspace(dev, L.isr_ep_sample_workspace_bytes(n, m), "ep_sample")
+    with torch.cuda.device(dev):
+        rc = L.isr_ep_sample_weights(ptr(corr_log.contiguous()), ptr(mask_prob), n, m, float(alpha), ptr(w), ptr(ws), ws.numel(),
+                                     current_stream(dev))
+    check(rc, "isr_ep_sample_weights")
+    return w
+
+
 def p3p_samples(corr_idx: torch.Tensor, res: int, m: int, obj_pts: torch.Tensor, K, seed: int):
     dev = require_cuda(corr_idx, obj_pts)
     S = corr_idx.shape[0]
@@ -167,14 +221,35 @@ def zbuf_score(obj_pts, R, t, K, res, mask_log_prob, neg_mask_log_prob, corr_log
     return out
 
 
+def zbuf_score_direct(obj_pts, R, t, K, res, mask_log_prob, neg_mask_log_prob, grid: DescriptorGrid, max_pool: bool = True):
+    """isr_zbuf_score_direct: zbuf_score()'s three scores on the [3x3 max-pooled] matrix, without the matrix."""
+    dev = require_cuda(obj_pts, R, t)
+    B, m = R.shape[0], obj_pts.shape[0]
+    Rt = torch.cat([R.to(torch.float32), t.to(torch.float32)[:, :, None]], dim=2).contiguous()
+    out = [torch.empty(B, dtype=torch.float32, device=dev) for _ in range(3)]
+    L = lib()
+    ws = ops.workspace(dev, L.isr_zbuf_score_workspace_bytes(B, res), "zbuf")
+    keep, kp = _kptr(K)
+    with torch.cuda.device(dev):
+        rc = L.isr_zbuf_score_direct(ptr(obj_pts), m, ptr(Rt), B, kp, res, ptr(mask_log_prob), ptr(neg_mask_log_prob),
+                                     ptr(grid.q), ptr(grid.lse), grid.pitch, grid.e, grid.win, int(bool(max_pool)),
+                                     ptr(grid.keys), ptr(out[0]), ptr(out[1]), ptr(out[2]), ptr(ws), ws.numel(),
+                                     current_stream(dev))
+    check(rc, "isr_zbuf_score_direct")
+    return out
+
+
 def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses=10000,
                   max_pose_evaluations=1000, down_sample_scale=3, alpha=1.5, dist_2d_min=0.1,
                   pnp_method=SOLVEPNP_AP3P, pose_batch_size=500, max_pool=True, avg_queries=True, do_prune=True,
-                  visualize=False, poses=None, debug=False, returnPoints=False, *, seed=0):
+                  visualize=False, poses=None, debug=False, returnPoints=False, *, seed=0, materialize=False):
     """poseEstSurf.py:11-261.  mask_lgts (r,r), query_img (r,r,e), obj_pts (m,3), obj_keys (m,e) on the
     device (host arrays are uploaded); obj_normals a NumPy (m,3) array as in the reference (:121).
     Returns R (n_poses,3,3) f32, t (n_poses,3) f32, pose_scores, mask_scores, coord_scores (device),
-    dist_2d, size_mask, normals_mask (NumPy, pre-prune length) [+ p3dCp, p2dCp if returnPoints]."""
+    dist_2d, size_mask, normals_mask (NumPy, pre-prune length) [+ p3dCp, p2dCp if returnPoints].
+    materialize=False (default): the (n, m) correspondence matrices of :70-107 are never formed — the sampler and the
+    scorer compute the elements they need from the descriptors (DescriptorGrid); True: the round-2/3 route through the
+    arrays (corr_matrices / patch_corr + pool_corr).  Both return the same bits."""
     del pnp_method
     if visualize:
         raise IsrError("estimate_pose(visualize=True) needs cv2.imshow; not available")
@@ -184,7 +259,11 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     m = obj_keys_d.shape[0]
     Ks = _k_scaled(K, down_sample_scale)
     mlp, nmlp, mprob, queries, res = prepare(mask_lgts, query_img, down_sample_scale, max_pool)
-    if avg_queries:
+    grid = None
+    if not materialize:
+        grid = (DescriptorGrid.pooled(queries, obj_keys_d, res) if avg_queries
+                else DescriptorGrid.per_pixel(query_img, obj_keys_d, down_sample_scale))
+    elif avg_queries:
         corr_raw, corr_log = corr_matrices(queries, obj_keys_d, res, max_pool)   # (n, m) f32 each, :70 and :97-107, one pass
         if corr_log is None:
             corr_log = corr_raw
@@ -195,7 +274,8 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     dist_2d = size_mask = normals_mask = None
     p3dCp = p2dCp = None
     if poses is None:
-        corr_idx = sample(corr_raw, mprob, alpha, max_poses, seed)
+        corr_idx = (sample_direct(grid, mprob, alpha, max_poses, seed) if grid is not None
+                    else sample(corr_raw, mprob, alpha, max_poses, seed))
         poses_d, ok = p3p_samples(corr_idx, res, m, obj_pts_d, Ks, seed)
         normals_d = _dev(np.asarray(obj_normals, np.float64))                      # normals_scaled.npy is float64 (:121)
         dist_d, sm_d, nm_d, keep_d, kidx_d, nk_d, Rt32 = prune(corr_idx, poses_d, ok, obj_pts_d, normals_d, res, m, Ks[0, 0],
@@ -224,7 +304,9 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     mask_scores = torch.empty(n_poses, device=dev)
     coord_scores = torch.empty(n_poses, device=dev)
     for l in range(0, n_poses, pose_batch_size):
-        ps, ms, cs = zbuf_score(obj_pts_d, R[l:l + pose_batch_size], t[l:l + pose_batch_size], Ks, res, mlp, nmlp, corr_log)
+        Rl, tl = R[l:l + pose_batch_size], t[l:l + pose_batch_size]
+        ps, ms, cs = (zbuf_score_direct(obj_pts_d, Rl, tl, Ks, res, mlp, nmlp, grid, max_pool) if grid is not None
+                      else zbuf_score(obj_pts_d, Rl, tl, Ks, res, mlp, nmlp, corr_log))
         pose_scores[l:l + pose_batch_size] = ps
         mask_scores[l:l + pose_batch_size] = ms
         coord_scores[l:l + pose_batch_size] = cs

@@ -315,6 +315,24 @@ int isr_ep_patch_corr_cells(const float* query_img, const float* obj_keys, int r
 size_t isr_ep_sample_workspace_bytes(int n, int m);
 int isr_ep_sample(const float* corr_log, const float* mask_prob, int n, int m, double alpha, int n_samples,
                   uint64_t seed, int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream);
+/* Matrix-free forms of :111-119 and :182-237 (round 3): estimate_pose never needs the (n x m) matrices as arrays, only
+ * (a) their weights summed in index order and (b) ~1e6 gathered elements, so both are formed on the spot from the
+ * descriptors.  The element for grid pixel g and key k is  <qgrid[g], keys[k]> (k-ordered fmaf chain from 0) - lse_grid[g]
+ * — bit for bit what isr_corr_logsoftmax / isr_ep_corr_matrices / isr_ep_patch_corr write — with lse_grid from
+ * isr_corr_argmax's `lse` output on the same rows.  The descriptor grid: qgrid (rows of g_pitch pixels, e floats each),
+ * lse_grid (same indexing); one output pixel of the res x res grid stands for win x win grid pixels:
+ *   avg_queries=True   qgrid = isr_ep_prepare's queries, g_pitch = res, win = 1;
+ *   avg_queries=False  qgrid = query_img (r, r, e), g_pitch = r, win = scale (sampling reads the block's centre pixel, offset
+ *                      win / 2, as corr_centre; scoring takes the block maximum, as corr_blockmax).
+ * isr_ep_sample_direct returns the indices isr_ep_sample returns on the materialised matrix (same weights, same order of
+ * f64 additions: per row and 512-key chunk sequentially in key order, chunks in order, rows by a fixed-shape scan);
+ * isr_zbuf_score_direct returns isr_zbuf_score's scores on the [3x3 max-pooled when `pool`] matrix.  ws as for the matrix forms.
+ * isr_ep_sample_weights writes the n*m f64 weights exp(alpha*corr_log)*mask_prob^alpha the sampler adds (a validation aid). */
+int isr_ep_sample_direct(const float* qgrid, const float* lse_grid, int g_pitch, int e, int win, int res,
+                         const float* mask_prob, const float* keys, int m, double alpha, int n_samples, uint64_t seed,
+                         int64_t* corr_idx, void* ws, size_t ws_bytes, isr_stream_t stream);
+int isr_ep_sample_weights(const float* corr_log, const float* mask_prob, int n, int m, double alpha, double* weights,
+                          void* ws, size_t ws_bytes, isr_stream_t stream);
 int isr_ep_p3p(const int64_t* corr_idx, int res, int m, const float* obj_pts, const double* Kcam, int S,
                uint64_t seed, double* poses, uint8_t* ok, isr_stream_t stream);
 /* isr_ep_prune      :147-177 per sample: dist_2d (S) f32 = largest pairwise pixel distance of the first three
@@ -332,6 +350,11 @@ int isr_zbuf_score(const float* obj_pts, int m, const float* Rt, int B, const do
                    const float* mask_log_prob, const float* neg_mask_log_prob, const float* corr_log,
                    float* pose_score, float* mask_score, float* coord_score, void* ws, size_t ws_bytes,
                    isr_stream_t stream);
+int isr_zbuf_score_direct(const float* obj_pts, int m, const float* Rt, int B, const double* Kcam, int res,
+                          const float* mask_log_prob, const float* neg_mask_log_prob, const float* qgrid,
+                          const float* lse_grid, int g_pitch, int e, int win, int pool, const float* keys,
+                          float* pose_score, float* mask_score, float* coord_score, void* ws, size_t ws_bytes,
+                          isr_stream_t stream);
 
 /* a16  refine_pose objective   pose_refine.py:58-91
  * out4 (device, 4 f64) = { score, d score / d t (3) } with

@@ -14,12 +14,14 @@ from test_gpu_estimate_pose import _scene_ref
 ap = argparse.ArgumentParser()
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--avg-queries", type=int, default=1)
+ap.add_argument("--materialize", type=int, default=0, help="1: the route through the (n, m) arrays; 0: matrix-free (the default of estimate_pose)")
+ap.add_argument("--only-call", action="store_true", help="skip the per-stage matrix timings")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 s = _scene_ref()
 a = [torch.from_numpy(s["mask_lgts"]).to(dev), torch.from_numpy(s["query"]).to(dev), torch.from_numpy(s["pts"]).to(dev),
      s["normals"], torch.from_numpy(s["keys"]).to(dev), s["diameter"], s["K"]]
-kw = dict(max_poses=10000, max_pose_evaluations=1000, avg_queries=bool(args.avg_queries), seed=3)
+kw = dict(max_poses=10000, max_pose_evaluations=1000, avg_queries=bool(args.avg_queries), seed=3, materialize=bool(args.materialize))
 out = pes.estimate_pose(*a, **kw)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -27,8 +29,10 @@ for _ in range(args.reps):
     out = pes.estimate_pose(*a, **kw)
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / args.reps * 1e3
-print(f"estimate_pose(avg_queries={bool(args.avg_queries)}) r=224 e=12 m=80000 max_poses=10000: {ms:.2f} ms per call; "
+print(f"estimate_pose(avg_queries={bool(args.avg_queries)}, materialize={bool(args.materialize)}) r=224 e=12 m=80000 max_poses=10000: {ms:.2f} ms per call; "
       f"{out[0].shape[0]} poses scored, best score {float(out[2].max()):.4f}")
+if args.only_call:
+    sys.exit(0)
 # the materialised log-softmax matrix alone: 4 n m bytes written (the reference keeps the same matrix resident)
 mlp, nmlp, mprob, q, res = pes.prepare(a[0], a[1], 3, True)
 n, m = q.shape[0], a[4].shape[0]
