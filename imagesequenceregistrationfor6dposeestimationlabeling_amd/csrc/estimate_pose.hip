@@ -182,24 +182,34 @@ constexpr int kGroup = 8;            // kChunk / kGroup = 64 groups: one per lan
 constexpr int kRowsPerBlock = 256;
 
 // exp(x) in f64 for the sampler's arguments (x = alpha * log-probability <= ~0): round-to-nearest argument reduction by
-// ln 2 (hi/lo), degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18), one v_ldexp_f64.  About 20 f64
-// instructions against ~3x that for the library exp with its special cases; below -708 (subnormal results) it returns 0.
+// ln 2 (hi/lo), degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18), one v_ldexp_f64 (gradual underflow below
+// e^-708, 0 below e^-745; the argument is clamped at -750 so that -inf gives 0, not NaN).  Branch-free, ~22 f64
+// instructions: a third of the library exp with its special cases.  The Horner steps are written as v_fma_f64 with the
+// coefficient in a scalar register pair — left alone the compiler keeps the coefficients in VGPRs and copies each one into
+// the destination of a v_fmac_f64 (13 extra moves per element in a loop bound by instruction issue); same operation,
+// same bits.
+__device__ __forceinline__ double fma_sc(double a, double b, double c_scalar) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_scalar));
+  return d;
+}
+
 __device__ __forceinline__ double ep_exp(double x) {
-  if (!(x >= -708.0)) return 0.0;
+  x = __builtin_fmax(x, -750.0);
   const double nf = __builtin_rint(x * 1.4426950408889634074);
   double r = __builtin_fma(nf, -6.93147180369123816490e-01, x);
   r = __builtin_fma(nf, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;                      // 1/13!
-  p = __builtin_fma(p, r, 2.08767569878680989792e-09);    // 1/12!
-  p = __builtin_fma(p, r, 2.50521083854417187751e-08);    // 1/11!
-  p = __builtin_fma(p, r, 2.75573192239858906526e-07);    // 1/10!
-  p = __builtin_fma(p, r, 2.75573192239858906526e-06);    // 1/9!
-  p = __builtin_fma(p, r, 2.48015873015873015873e-05);    // 1/8!
-  p = __builtin_fma(p, r, 1.98412698412698412698e-04);    // 1/7!
-  p = __builtin_fma(p, r, 1.38888888888888888889e-03);    // 1/6!
-  p = __builtin_fma(p, r, 8.33333333333333333333e-03);    // 1/5!
-  p = __builtin_fma(p, r, 4.16666666666666666667e-02);    // 1/4!
-  p = __builtin_fma(p, r, 1.66666666666666666667e-01);    // 1/3!
+  double p = 1.6059043836821613e-10;                 // 1/13!
+  p = fma_sc(p, r, 2.08767569878680989792e-09);      // 1/12!
+  p = fma_sc(p, r, 2.50521083854417187751e-08);      // 1/11!
+  p = fma_sc(p, r, 2.75573192239858906526e-07);      // 1/10!
+  p = fma_sc(p, r, 2.75573192239858906526e-06);      // 1/9!
+  p = fma_sc(p, r, 2.48015873015873015873e-05);      // 1/8!
+  p = fma_sc(p, r, 1.98412698412698412698e-04);      // 1/7!
+  p = fma_sc(p, r, 1.38888888888888888889e-03);      // 1/6!
+  p = fma_sc(p, r, 8.33333333333333333333e-03);      // 1/5!
+  p = fma_sc(p, r, 4.16666666666666666667e-02);      // 1/4!
+  p = fma_sc(p, r, 1.66666666666666666667e-01);      // 1/3!
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
@@ -261,11 +271,34 @@ struct QGrid {
   __device__ __forceinline__ int pixel(int o) const { return (o / res) * sy + (o % res) * sx + off; }
 };
 
+// row `i` of an (rows, e) f32 array into DP registers, zero past e; 16-byte loads when e is a multiple of 4
+template <int DP>
+__device__ __forceinline__ void load_row(const float* __restrict__ a, size_t i, int e, float (&v)[DP]) {
+  const float* r = a + i * e;
+  if ((e & 3) == 0) {
+#pragma unroll
+    for (int d4 = 0; d4 < DP / 4; ++d4) {
+      const float4 x = 4 * d4 < e ? reinterpret_cast<const float4*>(r)[d4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[4 * d4] = x.x; v[4 * d4 + 1] = x.y; v[4 * d4 + 2] = x.z; v[4 * d4 + 3] = x.w;
+    }
+  } else {
+#pragma unroll
+    for (int d = 0; d < DP; ++d) v[d] = d < e ? r[d] : 0.f;
+  }
+}
+
+template <int DP>
+__device__ __forceinline__ float chain(const float (&a)[DP], const float (&b)[DP]) {
+  float acc = 0.f;
+#pragma unroll
+  for (int d = 0; d < DP; ++d) acc = __builtin_fmaf(a[d], b[d], acc);
+  return acc;
+}
+
 template <int DP>
 __device__ __forceinline__ void load_query(const QGrid& g, int o, float (&q)[DP], float* lse) {
   const int px = g.pixel(o);
-#pragma unroll
-  for (int d = 0; d < DP; ++d) q[d] = d < g.e ? g.q[(size_t)px * g.e + d] : 0.f;
+  load_row<DP>(g.q, (size_t)px, g.e, q);
   *lse = g.lse[px];
 }
 
@@ -276,7 +309,7 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_direct_kernel(QGr
                                                                              const float* __restrict__ keys, int n, int m,
                                                                              int nchunk, double alpha,
                                                                              double* __restrict__ chunk_sums) {
-  constexpr int kSlice = 8192 / DP;
+  constexpr int kSlice = DP <= 16 ? kChunk : 8192 / DP;     // keys per LDS stage (a multiple of kGroup)
   __shared__ __attribute__((aligned(16))) float ks[kSlice * DP];
   const int tid = threadIdx.x, c = blockIdx.x;
   const int o = blockIdx.y * kRowsPerBlock + tid;
@@ -297,22 +330,32 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_direct_kernel(QGr
     }
     __syncthreads();
     const int cnt = min(kSlice, kend - kb);
-    for (int j0 = 0; j0 < cnt; j0 += kGroup) {
-      double s8 = 0.0;
-      const int j1 = min(cnt, j0 + kGroup);
-      for (int j = j0; j < j1; ++j) {
-        const float4* k4 = reinterpret_cast<const float4*>(ks + j * DP);
-        float acc = 0.f;
+    auto weight = [&](int j) {
+      const float4* k4 = reinterpret_cast<const float4*>(ks + j * DP);
+      float acc = 0.f;
 #pragma unroll
-        for (int d4 = 0; d4 < DP / 4; ++d4) {
-          const float4 kk = k4[d4];
-          acc = __builtin_fmaf(q[4 * d4], kk.x, acc);
-          acc = __builtin_fmaf(q[4 * d4 + 1], kk.y, acc);
-          acc = __builtin_fmaf(q[4 * d4 + 2], kk.z, acc);
-          acc = __builtin_fmaf(q[4 * d4 + 3], kk.w, acc);
-        }
-        s8 = __dadd_rn(s8, ep_weight(acc - lse, mpa, alpha));
+      for (int d4 = 0; d4 < DP / 4; ++d4) {
+        const float4 kk = k4[d4];
+        acc = __builtin_fmaf(q[4 * d4], kk.x, acc);
+        acc = __builtin_fmaf(q[4 * d4 + 1], kk.y, acc);
+        acc = __builtin_fmaf(q[4 * d4 + 2], kk.z, acc);
+        acc = __builtin_fmaf(q[4 * d4 + 3], kk.w, acc);
       }
+      return ep_weight(acc - lse, mpa, alpha);
+    };
+    int j0 = 0;
+    for (; j0 + kGroup <= cnt; j0 += kGroup) {        // full groups: eight independent weights, then their chain of adds
+      double w[kGroup];
+#pragma unroll
+      for (int i = 0; i < kGroup; ++i) w[i] = weight(j0 + i);
+      double s8 = 0.0;
+#pragma unroll
+      for (int i = 0; i < kGroup; ++i) s8 = __dadd_rn(s8, w[i]);
+      s = __dadd_rn(s, s8);
+    }
+    if (j0 < cnt) {
+      double s8 = 0.0;
+      for (int j = j0; j < cnt; ++j) s8 = __dadd_rn(s8, weight(j));
       s = __dadd_rn(s, s8);
     }
   }
@@ -373,17 +416,28 @@ __global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict_
                                                         int m, int nchunk, double alpha, const double* __restrict__ chunk_sums,
                                                         const double* __restrict__ row_cum, int n_samples, uint32_t seed_lo,
                                                         uint32_t seed_hi, int64_t* __restrict__ corr_idx) {
-  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (t >= n_samples * 4) return;
+  __shared__ double wbuf[4][kChunk];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = min(blockIdx.x * 4 + wave, n_samples * 4 - 1);       // 4 draws per sample: the grid is exact
   const int smp = t >> 2, j = t & 3;
   uint32_t rnd[4];
   philox4x32_10((uint32_t)smp, 1u, 0u, 0u, seed_lo, seed_hi, rnd);
   const double u = ((double)rnd[j] + 0.5) * (1.0 / 4294967296.0);
   const double target = u * row_cum[n - 1];
-  int lo = 0, hi = n - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (row_cum[mid] >= target) hi = mid; else lo = mid + 1;
+  // row: first o with row_cum[o] >= target — a 64-ary search (three dependent loads at n = 5 476 instead of thirteen)
+  int lo = 0, hi = n;
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) / 64;
+    const int idx = min(hi - 1, lo + (lane + 1) * step - 1);
+    const unsigned long long ge = __ballot(row_cum[idx] >= target);
+    const int f = ge ? __ffsll((long long)ge) - 1 : 63;
+    const int nlo = lo + f * step;
+    hi = min(hi, nlo + step);
+    lo = nlo;
+  }
+  {
+    const unsigned long long ge = __ballot(lo + lane < hi && row_cum[lo + lane] >= target);
+    lo = ge ? lo + __ffsll((long long)ge) - 1 : hi - 1;
   }
   const int o = lo;
   double rem = target - (o ? row_cum[o - 1] : 0.0);
@@ -404,30 +458,34 @@ __global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict_
     }
     rem -= acc;
   }
-  // this lane's group of the chunk
+  // the chunk's weights, 64 consecutive keys at a time (coalesced rows), parked in LDS
   const double mpa = mpa_all[o];
   const int k0 = c * kChunk, kend = min(m, k0 + kChunk);
-  const int ngroups = (kend - k0 + kGroup - 1) / kGroup;
-  const int kg = k0 + lane * kGroup;
-  double w[kGroup];
   if constexpr (DP == 0) {
 #pragma unroll
-    for (int i = 0; i < kGroup; ++i) w[i] = kg + i < kend ? ep_weight(corr_log[(size_t)o * m + kg + i], mpa, alpha) : 0.0;
+    for (int i = 0; i < kChunk / 64; ++i) {
+      const int k = k0 + i * 64 + lane;
+      wbuf[wave][i * 64 + lane] = k < kend ? ep_weight(corr_log[(size_t)o * m + k], mpa, alpha) : 0.0;
+    }
   } else {
     constexpr int DQ = DP ? DP : 4;
     float q[DQ], lse;
     load_query<DQ>(g, o, q, &lse);
 #pragma unroll
-    for (int i = 0; i < kGroup; ++i) {
-      float acc = 0.f;
-      if (kg + i < kend) {
-        const float* kr = keys + (size_t)(kg + i) * g.e;
-#pragma unroll
-        for (int d = 0; d < DQ; ++d) acc = __builtin_fmaf(q[d], d < g.e ? kr[d] : 0.f, acc);
-      }
-      w[i] = kg + i < kend ? ep_weight(acc - lse, mpa, alpha) : 0.0;
+    for (int i = 0; i < kChunk / 64; ++i) {
+      const int k = k0 + i * 64 + lane;
+      float kv[DQ];
+      load_row<DQ>(keys, (size_t)min(k, kend - 1), g.e, kv);
+      wbuf[wave][i * 64 + lane] = k < kend ? ep_weight(chain<DQ>(q, kv) - lse, mpa, alpha) : 0.0;
     }
   }
+  __syncthreads();
+  // lane = group: its kGroup weights and their sum
+  const int ngroups = (kend - k0 + kGroup - 1) / kGroup;
+  const int kg = k0 + lane * kGroup;
+  double w[kGroup];
+#pragma unroll
+  for (int i = 0; i < kGroup; ++i) w[i] = wbuf[wave][lane * kGroup + i];
   double s8 = 0.0;
 #pragma unroll
   for (int i = 0; i < kGroup; ++i)
@@ -457,7 +515,7 @@ __global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict_
       }
     }
   }
-  if (lane == 0) corr_idx[t] = (int64_t)o * m + k0 + gi * kGroup + kk;
+  if (lane == 0 && blockIdx.x * 4 + wave < n_samples * 4) corr_idx[t] = (int64_t)o * m + k0 + gi * kGroup + kk;
 }
 
 // ------------------------------------------------------------------------------------- P3P
@@ -622,10 +680,8 @@ __global__ __launch_bounds__(256) void zbuf_score_direct_kernel(const unsigned l
       const float z = unordered_f32((uint32_t)(key >> 32));
       if (z > 0.f) {
         hit = true;
-        const float* kr = keys + (size_t)(uint32_t)key * e;
         float k[DP];
-#pragma unroll
-        for (int d = 0; d < DP; ++d) k[d] = d < e ? kr[d] : 0.f;
+        load_row<DP>(keys, (size_t)(uint32_t)key, e, k);
         const int py = pix / res, px = pix % res;
         const int y0 = (pool ? max(0, py - 1) : py) * win, y1 = (pool ? min(res, py + 2) : py + 1) * win;
         const int x0 = (pool ? max(0, px - 1) : px) * win, x1 = (pool ? min(res, px + 2) : px + 1) * win;
@@ -633,11 +689,9 @@ __global__ __launch_bounds__(256) void zbuf_score_direct_kernel(const unsigned l
         for (int gy = y0; gy < y1; ++gy)
           for (int gx = x0; gx < x1; ++gx) {
             const size_t gp = (size_t)gy * g_pitch + gx;
-            const float* qr = qgrid + gp * e;
-            float acc = 0.f;
-#pragma unroll
-            for (int d = 0; d < DP; ++d) acc = __builtin_fmaf(d < e ? qr[d] : 0.f, k[d], acc);
-            best = fmaxf(best, acc - lse_grid[gp]);
+            float qv[DP];
+            load_row<DP>(qgrid, gp, e, qv);
+            best = fmaxf(best, chain<DP>(qv, k) - lse_grid[gp]);
           }
         sc += (double)best;
         cnt += 1.0;
@@ -704,10 +758,8 @@ __global__ __launch_bounds__(1024) void zbuf_fused_direct_kernel(const float* __
     const unsigned long long key = zb[pix];
     float best = 0.f;
     if (key != ~0ull && unordered_f32((uint32_t)(key >> 32)) > 0.f) {
-      const float* kr = keys + (size_t)(uint32_t)key * e;
       float k[DP];
-#pragma unroll
-      for (int d = 0; d < DP; ++d) k[d] = d < e ? kr[d] : 0.f;
+      load_row<DP>(keys, (size_t)(uint32_t)key, e, k);
       const int py = pix / res, px = pix % res;
       const int y0 = (pool ? max(0, py - 1) : py) * win, y1 = (pool ? min(res, py + 2) : py + 1) * win;
       const int x0 = (pool ? max(0, px - 1) : px) * win, x1 = (pool ? min(res, px + 2) : px + 1) * win;
@@ -715,11 +767,9 @@ __global__ __launch_bounds__(1024) void zbuf_fused_direct_kernel(const float* __
       for (int gy = y0; gy < y1; ++gy)
         for (int gx = x0; gx < x1; ++gx) {
           const size_t gp = (size_t)gy * g_pitch + gx;
-          const float* qr = qgrid + gp * e;
-          float acc = 0.f;
-#pragma unroll
-          for (int d = 0; d < DP; ++d) acc = __builtin_fmaf(d < e ? qr[d] : 0.f, k[d], acc);
-          best = fmaxf(best, acc - lse_grid[gp]);
+          float qv[DP];
+          load_row<DP>(qgrid, gp, e, qv);
+          best = fmaxf(best, chain<DP>(qv, k) - lse_grid[gp]);
         }
     }
     val[pix] = best;
@@ -977,7 +1027,8 @@ extern "C" int isr_ep_sample_direct(const float* qgrid, const float* lse_grid, i
     ep_sample_kernel<DPv><<<n_samples, 256, 0, stream>>>(nullptr, g, keys, sw.mpa, n, m, sw.nchunk, alpha, sw.chunk_sums,       \
                                                          sw.row_cum, n_samples, slo, shi, corr_idx);                          \
   } while (0)
-  if (e <= 16) ISR_EP_DIRECT(16);
+  if (e == 12) ISR_EP_DIRECT(12);          // the reference's descriptors (12 channels): no padded lanes in the chain
+  else if (e <= 16) ISR_EP_DIRECT(16);
   else if (e <= 32) ISR_EP_DIRECT(32);
   else if (e <= 64) ISR_EP_DIRECT(64);
   else ISR_EP_DIRECT(128);
@@ -1066,7 +1117,8 @@ extern "C" int isr_zbuf_score_direct(const float* obj_pts, int m, const float* R
                                                             lse_grid, g_pitch, e, win, pool ? 1 : 0, keys, pose_score,        \
                                                             mask_score, coord_score);                                         \
   } while (0)
-    if (e <= 16) ISR_ZB_FUSED(16);
+    if (e == 12) ISR_ZB_FUSED(12);
+    else if (e <= 16) ISR_ZB_FUSED(16);
     else if (e <= 32) ISR_ZB_FUSED(32);
     else if (e <= 64) ISR_ZB_FUSED(64);
     else ISR_ZB_FUSED(128);
