@@ -174,11 +174,15 @@ __global__ void ep_pool_corr_kernel(const float* __restrict__ in, int res, int m
 //   matrix  the (n x m) array isr_corr_logsoftmax / isr_ep_corr_matrices wrote (isr_ep_sample);
 //   direct  <Q[g(o)], keys[k]> (k-ordered fmaf chain from 0) - lse[g(o)], formed in registers: the same bits as the matrix
 //           element, and the matrix never exists (isr_ep_sample_direct).
-// Both add a row's weights in ONE order — groups of kGroup consecutive keys sequentially, a chunk's kChunk / kGroup group
-// sums sequentially, chunks in order per row, rows in a fixed-shape scan — so the two providers return identical indices,
-// and the sampler can rebuild any chunk's partial sums with a wave (lane = group).
+// Both add a row's weights in ONE order, an 8-ary tree over the key index: 8 consecutive keys sequentially (a group), 8 group
+// sums sequentially (a block of 64), 8 block sums (a chunk of 512: what is stored), 8 chunk sums (a super-chunk of 4 096),
+// the super-chunks of a row in order, rows in a fixed-shape scan — so the two providers return identical indices, and the
+// sampler descends that tree with a wave: 20 + 8 + 8 + 8 + 8 steps at m = 80 000 instead of a walk over 157 chunks and
+// 512 keys.
 constexpr int kChunk = 512;
 constexpr int kGroup = 8;            // kChunk / kGroup = 64 groups: one per lane of the sampler's wave
+constexpr int kBlock = 64;           // 8 groups
+constexpr int kSuper = 8;            // chunks per super-chunk
 constexpr int kRowsPerBlock = 256;
 
 // exp(x) in f64 for the sampler's arguments (x = alpha * log-probability <= ~0): round-to-nearest argument reduction by
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_kernel(const floa
   const int o = o0 + tid;
   const double mpa = o < n ? mpa_all[o] : 0.0;
   const int k0 = c * kChunk, kend = min(m, k0 + kChunk);
-  double s = 0.0;
+  double s = 0.0, s64 = 0.0;
   for (int kb = k0; kb < kend; kb += 32) {
     __syncthreads();
     for (int i = tid; i < kRowsPerBlock * 32; i += kRowsPerBlock) {
@@ -255,7 +259,11 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_kernel(const floa
     for (int j0 = 0; j0 < cnt; j0 += kGroup) {
       double s8 = 0.0;
       for (int j = j0; j < min(cnt, j0 + kGroup); ++j) s8 = __dadd_rn(s8, ep_weight(tile[tid][j], mpa, alpha));
-      s = __dadd_rn(s, s8);
+      s64 = __dadd_rn(s64, s8);
+    }
+    if (((kb - k0) & 32) || kb + 32 >= kend) {      // a block of 64 keys (two slices) is complete
+      s = __dadd_rn(s, s64);
+      s64 = 0.0;
     }
   }
   if (o < n) chunk_sums[(size_t)o * nchunk + c] = s;
@@ -343,20 +351,25 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_direct_kernel(QGr
       }
       return ep_weight(acc - lse, mpa, alpha);
     };
-    int j0 = 0;
-    for (; j0 + kGroup <= cnt; j0 += kGroup) {        // full groups: eight independent weights, then their chain of adds
-      double w[kGroup];
+    for (int jb = 0; jb < cnt; jb += kBlock) {          // kSlice is a multiple of kBlock: blocks do not straddle slices
+      const int je = min(cnt, jb + kBlock);
+      double s64 = 0.0;
+      int j0 = jb;
+      for (; j0 + kGroup <= je; j0 += kGroup) {         // full groups: eight independent weights, then their chain of adds
+        double w[kGroup];
 #pragma unroll
-      for (int i = 0; i < kGroup; ++i) w[i] = weight(j0 + i);
-      double s8 = 0.0;
+        for (int i = 0; i < kGroup; ++i) w[i] = weight(j0 + i);
+        double s8 = 0.0;
 #pragma unroll
-      for (int i = 0; i < kGroup; ++i) s8 = __dadd_rn(s8, w[i]);
-      s = __dadd_rn(s, s8);
-    }
-    if (j0 < cnt) {
-      double s8 = 0.0;
-      for (int j = j0; j < cnt; ++j) s8 = __dadd_rn(s8, weight(j));
-      s = __dadd_rn(s, s8);
+        for (int i = 0; i < kGroup; ++i) s8 = __dadd_rn(s8, w[i]);
+        s64 = __dadd_rn(s64, s8);
+      }
+      if (j0 < je) {
+        double s8 = 0.0;
+        for (int j = j0; j < je; ++j) s8 = __dadd_rn(s8, weight(j));
+        s64 = __dadd_rn(s64, s8);
+      }
+      s = __dadd_rn(s, s64);
     }
   }
   if (o < n) chunk_sums[(size_t)o * nchunk + c] = s;
@@ -369,15 +382,29 @@ __device__ __forceinline__ double bcast_f64(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// lane L's super-chunk of a row: its (up to) 8 chunk sums and their sequential sum
+__device__ __forceinline__ double super_chunk(const double* __restrict__ row_chunks, int nchunk, int sup, double (&c8)[kSuper]) {
+  double sc = 0.0;
+#pragma unroll
+  for (int j = 0; j < kSuper; ++j) {
+    const int c = sup * kSuper + j;
+    c8[j] = c < nchunk ? row_chunks[c] : 0.0;
+    if (c < nchunk) sc = __dadd_rn(sc, c8[j]);
+  }
+  return sc;
+}
+
 __global__ __launch_bounds__(256) void ep_row_sums_kernel(const double* __restrict__ chunk_sums, int n, int nchunk,
                                                           double* __restrict__ row_sums) {
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (o >= n) return;
+  const int nsuper = (nchunk + kSuper - 1) / kSuper;
   double s = 0.0;
-  for (int base = 0; base < nchunk; base += 64) {
-    const double v = base + lane < nchunk ? chunk_sums[(size_t)o * nchunk + base + lane] : 0.0;
-    const int cnt = min(64, nchunk - base);
-    for (int i = 0; i < cnt; ++i) s += bcast_f64(v, i);
+  for (int base = 0; base < nsuper; base += 64) {
+    double c8[kSuper];
+    const double sc = super_chunk(chunk_sums + (size_t)o * nchunk, nchunk, base + lane, c8);
+    const int cnt = min(64, nsuper - base);
+    for (int i = 0; i < cnt; ++i) s = __dadd_rn(s, bcast_f64(sc, i));
   }
   if (lane == 0) row_sums[o] = s;
 }
@@ -441,22 +468,40 @@ __global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict_
   }
   const int o = lo;
   double rem = target - (o ? row_cum[o - 1] : 0.0);
-  // chunk: first c whose inclusive in-row cumulative reaches rem (the last one otherwise)
-  int c = nchunk - 1;
+  // every level below: the first child whose inclusive cumulative reaches what is left of the target, the last one otherwise
+  // super-chunk (lane = super-chunk, 64 at a time), then the chunk inside it
+  const int nsuper = (nchunk + kSuper - 1) / kSuper;
+  int c;
   {
-    double acc = 0.0;
+    const double* row_chunks = chunk_sums + (size_t)o * nchunk;
+    double acc = 0.0, c8[kSuper];
+    int sup = nsuper - 1, base = 0;
     bool found = false;
-    for (int base = 0; base < nchunk && !found; base += 64) {
-      const double v = base + lane < nchunk ? chunk_sums[(size_t)o * nchunk + base + lane] : 0.0;
-      const int cnt = min(64, nchunk - base);
+    for (; base < nsuper; base += 64) {
+      const double sc = super_chunk(row_chunks, nchunk, base + lane, c8);
+      const int cnt = min(64, nsuper - base);
       for (int i = 0; i < cnt; ++i) {
-        if (base + i == nchunk - 1) { found = true; break; }
-        const double nx = acc + bcast_f64(v, i);
-        if (nx >= rem) { c = base + i; found = true; break; }
+        if (base + i == nsuper - 1) { found = true; break; }
+        const double nx = __dadd_rn(acc, bcast_f64(sc, i));
+        if (nx >= rem) { sup = base + i; found = true; break; }
         acc = nx;
+      }
+      if (found) break;
+    }
+    rem -= acc;
+    const int nch = min(kSuper, nchunk - sup * kSuper);
+    int cj = nch - 1;
+    acc = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < kSuper; ++jj) {
+      const double v = bcast_f64(c8[jj], sup - base);
+      if (jj < nch - 1 && cj == nch - 1) {
+        const double nx = __dadd_rn(acc, v);
+        if (nx >= rem) cj = jj; else acc = nx;
       }
     }
     rem -= acc;
+    c = sup * kSuper + cj;
   }
   // the chunk's weights, 64 consecutive keys at a time (coalesced rows), parked in LDS
   const double mpa = mpa_all[o];
@@ -480,41 +525,46 @@ __global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict_
     }
   }
   __syncthreads();
-  // lane = group: its kGroup weights and their sum
-  const int ngroups = (kend - k0 + kGroup - 1) / kGroup;
-  const int kg = k0 + lane * kGroup;
+  // lane = group: its kGroup weights and their sum; lanes 0..7 = blocks of 8 groups
+  const int nkeys = kend - k0;
+  const int kg = lane * kGroup;
   double w[kGroup];
 #pragma unroll
-  for (int i = 0; i < kGroup; ++i) w[i] = wbuf[wave][lane * kGroup + i];
+  for (int i = 0; i < kGroup; ++i) w[i] = wbuf[wave][kg + i];
   double s8 = 0.0;
 #pragma unroll
   for (int i = 0; i < kGroup; ++i)
-    if (kg + i < kend) s8 = __dadd_rn(s8, w[i]);
-  // group: first whose inclusive in-chunk cumulative reaches rem (the last non-empty one otherwise)
-  int gi = ngroups - 1;
-  {
-    double acc = 0.0;
-    for (int i = 0; i < ngroups - 1; ++i) {
-      const double nx = __dadd_rn(acc, bcast_f64(s8, i));
-      if (nx >= rem) { gi = i; break; }
-      acc = nx;
-    }
-    rem -= acc;
+    if (kg + i < nkeys) s8 = __dadd_rn(s8, w[i]);
+  __syncthreads();
+  wbuf[wave][lane] = s8;                     // the group sums (the weights are in registers now)
+  __syncthreads();
+  double s64 = 0.0;
+  if (lane < kChunk / kBlock) {
+#pragma unroll
+    for (int i = 0; i < kBlock / kGroup; ++i)
+      if ((lane * (kBlock / kGroup) + i) * kGroup < nkeys) s64 = __dadd_rn(s64, wbuf[wave][lane * (kBlock / kGroup) + i]);
   }
-  // key inside the group (the last valid one otherwise)
-  const int cnt = min(kGroup, kend - (k0 + gi * kGroup));
-  int kk = cnt - 1;
-  {
+  // descend: block, group, key
+  auto pick = [&](int nchild, auto value) {    // value(i): child i's sum, wave-uniform
+    int sel = nchild - 1;
     double acc = 0.0;
 #pragma unroll
-    for (int i = 0; i < kGroup; ++i) {
-      const double wi = bcast_f64(w[i], gi);
-      if (i < cnt - 1 && kk == cnt - 1) {
-        acc = __dadd_rn(acc, wi);
-        if (acc >= rem) kk = i;
+    for (int i = 0; i < 8; ++i) {
+      const double v = value(i);
+      if (i < nchild - 1 && sel == nchild - 1) {
+        const double nx = __dadd_rn(acc, v);
+        if (nx >= rem) sel = i; else acc = nx;
       }
     }
-  }
+    rem -= acc;
+    return sel;
+  };
+  const int nblocks = (nkeys + kBlock - 1) / kBlock;
+  const int bi = pick(nblocks, [&](int i) { return bcast_f64(s64, i); });
+  const int ngroups = min(kBlock / kGroup, (nkeys - bi * kBlock + kGroup - 1) / kGroup);
+  const int gi = bi * (kBlock / kGroup) + pick(ngroups, [&](int i) { return bcast_f64(s8, bi * (kBlock / kGroup) + i); });
+  const int cnt = min(kGroup, nkeys - gi * kGroup);
+  const int kk = pick(cnt, [&](int i) { return bcast_f64(w[i], gi); });
   if (lane == 0 && blockIdx.x * 4 + wave < n_samples * 4) corr_idx[t] = (int64_t)o * m + k0 + gi * kGroup + kk;
 }
 
