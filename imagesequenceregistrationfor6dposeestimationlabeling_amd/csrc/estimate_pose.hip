@@ -375,6 +375,81 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_direct_kernel(QGr
   if (o < n) chunk_sums[(size_t)o * nchunk + c] = s;
 }
 
+// The same sums with the logits on the matrix cores: v_mfma_f32_32x32x2_f32 is bit for bit the k-ordered fmaf chain (K1's
+// exact-f32 path rests on that), so a wave forms a 32-key x 32-row tile of logits with DP / 2 MFMAs instead of 16 x DP fma
+// per lane, and the VALU is left with the f64 weights alone (26 of the 41 instructions per element of the kernel above).
+// Tile layout (A = keys, B = queries): lane (r, h) = (lane & 31, lane >> 5) holds, for row r, the keys 8a + 4h + b of the
+// tile in register 4a + b — half h of each 8-key group.  The group's chain of adds starts in the h = 0 lane (keys 0..3),
+// crosses to the h = 1 lane with one v_permlane32_swap per 32-bit half, and ends there (keys 4..7); block and chunk sums
+// live in the h = 1 lanes.  Workgroup = 4 waves = 128 rows x one chunk.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ double from_lower_half(double v) {       // lanes 32..63 receive lanes 0..31's value
+  unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double((int)b[0], (int)a[0]);
+}
+
+template <int DP>
+__global__ __launch_bounds__(256) void ep_chunk_sums_mfma_kernel(QGrid g, const double* __restrict__ mpa_all,
+                                                                 const float* __restrict__ keys, int n, int m, int nchunk,
+                                                                 double alpha, double* __restrict__ chunk_sums) {
+  constexpr int KS = DP / 2;
+  constexpr int LD = DP + 1;                                    // odd dword stride: conflict-free reads down a column
+  constexpr int kSlice = DP <= 16 ? kChunk : 8192 / DP;         // keys per LDS stage (a multiple of kBlock)
+  __shared__ float ks[kSlice * LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int r = lane & 31, h = lane >> 5;
+  const int o = blockIdx.y * 128 + wave * 32 + r;
+  const int oc = min(o, n - 1);
+  const int px = g.pixel(oc);
+  float bq[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) bq[s] = 2 * s + h < g.e ? g.q[(size_t)px * g.e + 2 * s + h] : 0.f;
+  const float lse = g.lse[px];
+  const double mpa = mpa_all[oc];
+  const int c = blockIdx.x, k0 = c * kChunk, kend = min(m, k0 + kChunk);
+  double s512 = 0.0;
+  for (int kb = k0; kb < kend; kb += kSlice) {
+    __syncthreads();
+    for (int i = tid; i < kSlice * DP; i += 256) {
+      const int kk = i / DP, d = i % DP;
+      ks[kk * LD + d] = (kb + kk < kend && d < g.e) ? keys[(size_t)(kb + kk) * g.e + d] : 0.f;
+    }
+    __syncthreads();
+    const int cnt = min(kSlice, kend - kb);
+    for (int jb = 0; jb < cnt; jb += kBlock) {
+      double s64 = 0.0;
+#pragma unroll
+      for (int tile = 0; tile < kBlock / 32; ++tile) {
+        const int t0 = jb + 32 * tile;
+        if (t0 >= cnt) break;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        const float* arow = ks + (t0 + r) * LD + h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(arow[2 * s], bq[s], acc, 0, 0, 0);
+        double part[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {                    // this lane's half of group a: keys t0 + 8a + 4h + (0..3)
+          const int kq = t0 + 8 * a + 4 * h;
+          double w[4];
+#pragma unroll
+          for (int b = 0; b < 4; ++b) w[b] = kq + b < cnt ? ep_weight(acc[4 * a + b] - lse, mpa, alpha) : 0.0;
+          const double from_h0 = from_lower_half(__dadd_rn(__dadd_rn(__dadd_rn(w[0], w[1]), w[2]), w[3]));
+          part[a] = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(from_h0, w[0]), w[1]), w[2]), w[3]);    // h = 1: the group sum
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s64 = __dadd_rn(s64, part[a]);     // (a missing group adds +0.0: exact)
+      }
+      s512 = __dadd_rn(s512, s64);
+    }
+  }
+  if (h == 1 && o < n) chunk_sums[(size_t)o * nchunk + c] = s512;
+}
+
 // a wave per row: the row's chunk sums are read coalesced, then added in chunk order (every lane runs the same chain on
 // broadcast values); ep_row_scan_kernel does the inclusive scan over rows.
 __device__ __forceinline__ double bcast_f64(double v, int lane) {
@@ -1070,9 +1145,14 @@ extern "C" int isr_ep_sample_direct(const float* qgrid, const float* lse_grid, i
   const QGrid g{qgrid, lse_grid, e, res, win * g_pitch, win, (win / 2) * (g_pitch + 1)};
   const dim3 grid(sw.nchunk, (n + kRowsPerBlock - 1) / kRowsPerBlock);
   const uint32_t slo = (uint32_t)seed, shi = (uint32_t)(seed >> 32);
+  const bool valu = isr::tuning(ISR_TUNE_EP_WSUM_VALU) != 0;
+  const dim3 grid_mfma(sw.nchunk, (n + 127) / 128);
 #define ISR_EP_DIRECT(DPv)                                                                                                    \
   do {                                                                                                                        \
-    ep_chunk_sums_direct_kernel<DPv><<<grid, kRowsPerBlock, 0, stream>>>(g, sw.mpa, keys, n, m, sw.nchunk, alpha, sw.chunk_sums); \
+    if (valu)                                                                                                                 \
+      ep_chunk_sums_direct_kernel<DPv><<<grid, kRowsPerBlock, 0, stream>>>(g, sw.mpa, keys, n, m, sw.nchunk, alpha, sw.chunk_sums); \
+    else                                                                                                                      \
+      ep_chunk_sums_mfma_kernel<DPv><<<grid_mfma, 256, 0, stream>>>(g, sw.mpa, keys, n, m, sw.nchunk, alpha, sw.chunk_sums);   \
     sample_rows(sw, n, stream);                                                                                               \
     ep_sample_kernel<DPv><<<n_samples, 256, 0, stream>>>(nullptr, g, keys, sw.mpa, n, m, sw.nchunk, alpha, sw.chunk_sums,       \
                                                          sw.row_cum, n_samples, slo, shi, corr_idx);                          \

@@ -61,7 +61,8 @@ int isr_device_count(void);
 #define ISR_TUNE_NN_TILE_ST 5    /* 0 default | target cell scale x 1000                                    ISR_NN_TILE="st,sq,tb" */
 #define ISR_TUNE_NN_TILE_SQ 6    /* 0 default | query cell scale x 1000 */
 #define ISR_TUNE_NN_TILE_TB 7    /* 0 default | 64 | 128 | 256 threads per workgroup */
-#define ISR_TUNE_COUNT 8
+#define ISR_TUNE_EP_WSUM_VALU 8  /* 0 (default) the sampler's chunk sums form their logits on the f32 MFMA | 1 on VALU fma chains (same bits) */
+#define ISR_TUNE_COUNT 9
 int isr_tuning_set(int knob, int value);
 int isr_tuning_get(int knob);
 
