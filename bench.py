@@ -24,6 +24,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
                 bf16 MFMA peak; `traffic` from profiles/ (rocprofv3 --pmc) when committed.
   cpu_baseline  the CPU oracle (kind "port": the reference's own OpenCV/Open3D path cannot run
                 here) timed on a bounded sample of the same workload on this box's host cores.
+and, untimed, `parity_check` (the last step recomputed by the oracle) and `estimate_pose` (the reference's other per-image
+path, poseEstSurf.estimate_pose, at its own size: ms per call of the matrix-free and of the materialised route).
 """
 from __future__ import annotations
 
@@ -81,6 +83,7 @@ def parse_args():
     ap.add_argument("--verify", choices=("pick", "vote"), default="pick",
                     help="verification stage: 'pick' = consecutive-pair Chamfer pick (verfication.py:61-108, the headline); "
                          "'vote' = the n x n ADD-S vote whose top choice icp.py:37-39 reads (choosePose.py:121-151)")
+    ap.add_argument("--no-estimate-pose", action="store_true", help="skip the untimed estimate_pose timing (reference size)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed oracle re-computation of the last step")
     return ap.parse_args()
 
@@ -359,6 +362,38 @@ def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower,
     return out
 
 
+def measure_estimate_pose(dev, reps=5):
+    """The other per-image path (poseEstSurf.py:11-261) at the reference's own size — a 224 x 224
+    crop, 12-D descriptors, 80 000 surface points, 10 000 samples, <= 1 000 scored poses: wall time per call of the
+    matrix-free route (the default) and of the route through the materialised (n, m) matrices, which return the same bits.
+    Untimed region of the bench; not part of `value`."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import pose_est_surf as pes, synth
+    s = synth.crop_scene()
+    a = [torch.from_numpy(s["mask_lgts"]).to(dev), torch.from_numpy(s["query"]).to(dev), torch.from_numpy(s["pts"]).to(dev),
+         torch.from_numpy(s["normals"]).to(dev), torch.from_numpy(s["keys"]).to(dev), s["diameter"], s["K"]]
+    out = {"shape": {"r": 224, "e": 12, "m": 80000, "max_poses": 10000, "max_pose_evaluations": 1000, "down_sample_scale": 3},
+           "unit": "ms per call (wall, inputs resident)"}
+    ref = {}
+    for avg in (True, False):
+        for mat in (False, True):
+            kw = dict(max_poses=10000, max_pose_evaluations=1000, avg_queries=avg, seed=3, materialize=mat)
+            res = pes.estimate_pose(*a, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                res = pes.estimate_pose(*a, **kw)
+            torch.cuda.synchronize()
+            key = f"avg_queries_{str(avg).lower()}" + ("_materialized" if mat else "")
+            out[key] = (time.perf_counter() - t0) / reps * 1e3
+            if not mat:
+                ref[avg] = res
+                out[f"poses_scored_avg_queries_{str(avg).lower()}"] = int(res[0].shape[0])
+            else:
+                out[f"routes_bit_identical_avg_queries_{str(avg).lower()}"] = bool(
+                    all(torch.equal(x, y) if torch.is_tensor(x) else np.array_equal(x, y) for x, y in zip(ref[avg], res)))
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -615,6 +650,11 @@ def main():
                          "note": "brute-force rate measured live: roofline_nn; DESIGN.md section 4 (K3/K4)"},
             "stage_ms_per_step": {k: v[1] / args.steps for k, v in timing.items()},
         }
+        if world == 1 and not args.no_estimate_pose:
+            try:
+                line["estimate_pose"] = measure_estimate_pose(dev)
+            except Exception as e:
+                line["estimate_pose"] = {"error": repr(e)}
         if not args.no_parity_check and args.ablate != "noverify":
             try:
                 line["parity_check"] = parity_check(args, model, Q_all[0], keys, pts, last, R_gt, t_gt, upper, lower, cad)

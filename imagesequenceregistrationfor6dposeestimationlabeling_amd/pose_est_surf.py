@@ -244,7 +244,7 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
                   pnp_method=SOLVEPNP_AP3P, pose_batch_size=500, max_pool=True, avg_queries=True, do_prune=True,
                   visualize=False, poses=None, debug=False, returnPoints=False, *, seed=0, materialize=False):
     """poseEstSurf.py:11-261.  mask_lgts (r,r), query_img (r,r,e), obj_pts (m,3), obj_keys (m,e) on the
-    device (host arrays are uploaded); obj_normals a NumPy (m,3) array as in the reference (:121).
+    device (host arrays are uploaded); obj_normals a NumPy (m,3) array as in the reference (:121) or a device tensor.
     Returns R (n_poses,3,3) f32, t (n_poses,3) f32, pose_scores, mask_scores, coord_scores (device),
     dist_2d, size_mask, normals_mask (NumPy, pre-prune length) [+ p3dCp, p2dCp if returnPoints].
     materialize=False (default): the (n, m) correspondence matrices of :70-107 are never formed — the sampler and the
@@ -277,7 +277,9 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
         corr_idx = (sample_direct(grid, mprob, alpha, max_poses, seed) if grid is not None
                     else sample(corr_raw, mprob, alpha, max_poses, seed))
         poses_d, ok = p3p_samples(corr_idx, res, m, obj_pts_d, Ks, seed)
-        normals_d = _dev(np.asarray(obj_normals, np.float64))                      # normals_scaled.npy is float64 (:121)
+        # normals_scaled.npy is float64 (:121); a device tensor is taken as it is (a NumPy array is 1.9 MB of upload per call)
+        normals_d = (obj_normals.to(dev, torch.float64) if torch.is_tensor(obj_normals)
+                     else _dev(np.asarray(obj_normals, np.float64)))
         dist_d, sm_d, nm_d, keep_d, kidx_d, nk_d, Rt32 = prune(corr_idx, poses_d, ok, obj_pts_d, normals_d, res, m, Ks[0, 0],
                                                                 obj_diameter, dist_2d_min, do_prune, max_pose_evaluations)
         n_keep = int(nk_d.item())                  # the one host round trip: it sizes the outputs

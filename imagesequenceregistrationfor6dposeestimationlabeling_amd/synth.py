@@ -148,3 +148,29 @@ def rot_angle(Ra, Rb):
     """Rotation angle between two rotations, stable near 0: |Ra - Rb|_F = 2 sqrt(2) sin(angle / 2)."""
     f = np.linalg.norm(np.asarray(Ra, np.float64) - np.asarray(Rb, np.float64))
     return float(2.0 * np.arcsin(min(1.0, f / (2.0 * np.sqrt(2.0)))))
+
+
+def crop_scene(seed=7, r=224, e=12, m=80000, f=700.0):
+    """estimate_pose's inputs at the reference's own size (poseEstSurf.py:11-15 as called from inference.py: a 224 x 224
+    crop, 12-D descriptors, m = 80 000 surface points, genFeat.py:201): mask logits of a rendered bumpy ellipsoid, a query
+    image whose object pixels carry the (noisy) keys of the surface points that project there."""
+    rng = np.random.default_rng(seed)
+    pts = bumpy_ellipsoid(rng, m)
+    nrm = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+    keys = unit_keys(rng, m, e, tau=6.0)
+    R, t = random_poses(rng, 1, tz=420.0, t_sigma=5.0)
+    R, t = R[0], t[0]
+    K = np.array([[f, 0, r / 2 - 0.5], [0, f, r / 2 - 0.5], [0, 0, 1]])
+    uv = project(K, R, t, pts)
+    cam = pts.astype(np.float64) @ R.T + t
+    vis = (nrm @ R.T * cam).sum(1) < 0
+    ui, vi = np.rint(uv[:, 0]).astype(int), np.rint(uv[:, 1]).astype(int)
+    ok = np.nonzero(vis & (ui >= 0) & (ui < r) & (vi >= 0) & (vi < r))[0]
+    ok = ok[np.argsort(-cam[ok, 2])]                                 # nearest written last
+    mask_lgts = np.full((r, r), -6.0, np.float32)
+    query = (0.3 * rng.normal(size=(r, r, e))).astype(np.float32)
+    mask_lgts[vi[ok], ui[ok]] = 6.0
+    query[vi[ok], ui[ok]] = keys[ok] + 0.2 * rng.normal(size=(len(ok), e)).astype(np.float32)
+    return dict(pts=pts, normals=nrm, keys=keys, R=R, t=t, K=K, mask_lgts=mask_lgts, query=query,
+                diameter=diameter(pts), r=r, e=e, m=m)
+

@@ -240,27 +240,7 @@ def test_estimate_pose_end_to_end(cuda0):
 
 
 def _scene_ref(seed=7, r=224, e=12, m=80000, f=700.0):
-    """_scene at the reference's own size (poseEstSurf.py:11-15 as called from inference.py: a 224 x 224 crop, 12-D
-    descriptors, m = 80 000 surface points, genFeat.py:201), vectorised."""
-    rng = np.random.default_rng(seed)
-    pts = synth.bumpy_ellipsoid(rng, m)
-    nrm = pts / np.linalg.norm(pts, axis=1, keepdims=True)
-    keys = synth.unit_keys(rng, m, e, tau=6.0)
-    R, t = synth.random_poses(rng, 1, tz=420.0, t_sigma=5.0)
-    R, t = R[0], t[0]
-    K = np.array([[f, 0, r / 2 - 0.5], [0, f, r / 2 - 0.5], [0, 0, 1]])
-    uv = synth.project(K, R, t, pts)
-    cam = pts.astype(np.float64) @ R.T + t
-    vis = (nrm @ R.T * cam).sum(1) < 0
-    ui, vi = np.rint(uv[:, 0]).astype(int), np.rint(uv[:, 1]).astype(int)
-    ok = np.nonzero(vis & (ui >= 0) & (ui < r) & (vi >= 0) & (vi < r))[0]
-    ok = ok[np.argsort(-cam[ok, 2])]                                 # nearest written last
-    mask_lgts = np.full((r, r), -6.0, np.float32)
-    query = (0.3 * rng.normal(size=(r, r, e))).astype(np.float32)
-    mask_lgts[vi[ok], ui[ok]] = 6.0
-    query[vi[ok], ui[ok]] = keys[ok] + 0.2 * rng.normal(size=(len(ok), e)).astype(np.float32)
-    return dict(pts=pts, normals=nrm, keys=keys, R=R, t=t, K=K, mask_lgts=mask_lgts, query=query,
-                diameter=synth.diameter(pts), r=r, e=e, m=m)
+    return synth.crop_scene(seed, r, e, m, f)
 
 
 @pytest.mark.parametrize("avg_queries", [True, False])

@@ -20,7 +20,7 @@ args = ap.parse_args()
 dev = torch.device("cuda:0")
 s = _scene_ref()
 a = [torch.from_numpy(s["mask_lgts"]).to(dev), torch.from_numpy(s["query"]).to(dev), torch.from_numpy(s["pts"]).to(dev),
-     s["normals"], torch.from_numpy(s["keys"]).to(dev), s["diameter"], s["K"]]
+     torch.from_numpy(s["normals"]).to(dev), torch.from_numpy(s["keys"]).to(dev), s["diameter"], s["K"]]
 kw = dict(max_poses=10000, max_pose_evaluations=1000, avg_queries=bool(args.avg_queries), seed=3, materialize=bool(args.materialize))
 out = pes.estimate_pose(*a, **kw)
 torch.cuda.synchronize()
