@@ -715,7 +715,7 @@ __device__ __forceinline__ float unordered_f32(uint32_t u) {
 }
 
 struct K9f { float k[9]; };
-constexpr size_t kFusedLdsMax = 144 * 1024;      // of gfx950's 160 KB per workgroup: res <= 110 with the fused z-buffer
+constexpr size_t kFusedLdsMax = 144 * 1024;      // of gfx950's 160 KB per workgroup: res <= 135 with the fused z-buffer
 
 __global__ void zbuf_project_kernel(const float* __restrict__ pts, int m, const float* __restrict__ Rt, int B, K9f K,
                                     int res, unsigned long long* __restrict__ zbuf) {
@@ -845,28 +845,48 @@ __global__ __launch_bounds__(256) void zbuf_score_direct_kernel(const unsigned l
   }
 }
 
-// The direct scorer, fused with its z-buffer: one workgroup of 1024 threads per pose keeps the res x res buffer of packed
+// The direct scorer, fused with its z-buffer: one workgroup of 512 threads per pose keeps the res x res buffer of packed
 // (ordered z, vertex) words in LDS (43.8 KB at res = 74), projects all m vertices into it with LDS atomics, evaluates the
-// pooled log-correspondence of every hit pixel 1024-wide into a second LDS array, and its first 256 threads then add the
-// pixels in exactly zbuf_score_kernel's order (thread t: pixels t, t + 256, ... in f64; 64-lane tree; four wave partials).
+// pooled log-correspondence of every hit pixel 512-wide into the vertex half of the pixel's word, and its first 256 threads
+// then add the pixels in exactly zbuf_score_kernel's order (thread t: pixels t, t + 256, ... in f64; 64-lane tree; four wave partials).
 // No global z-buffer, no memset, no global atomics: round 3's zbuf_project_kernel was 0.5 ms per 224 poses (4.4 ms per
 // 1 000) of L2 atomics on ~50 vertices per covered pixel.
-template <int DP>
-__global__ __launch_bounds__(1024) void zbuf_fused_direct_kernel(const float* __restrict__ pts, int m, const float* __restrict__ Rt,
-                                                                 K9f K, int res, const float* __restrict__ mlp,
-                                                                 const float* __restrict__ nmlp, const float* __restrict__ qgrid,
-                                                                 const float* __restrict__ lse_grid, int g_pitch, int e, int win,
-                                                                 int pool, const float* __restrict__ keys,
-                                                                 float* __restrict__ pose_score, float* __restrict__ mask_score,
-                                                                 float* __restrict__ coord_score) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long zb[];     // n words, then n floats
-  __shared__ double red[3][4];
+// maximum over the 64 lanes without the LDS crossbar: four DPP steps inside each row of 16, then the four row leaders
+__device__ __forceinline__ float wave_max_f32(float v) {
+  auto step = [&](auto ctrl) {
+    const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), decltype(ctrl)::value, 0xF, 0xF, false);
+    v = fmaxf(v, __int_as_float(o));
+  };
+  step(std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+  step(std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+  step(std::integral_constant<int, 0x141>{});     // row_half_mirror
+  step(std::integral_constant<int, 0x140>{});     // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+
+template <int DP, int THREADS>
+__global__ __launch_bounds__(THREADS) void zbuf_fused_direct_kernel(const float* __restrict__ pts, int m, const float* __restrict__ Rt,
+                                                                    K9f K, int res, const float* __restrict__ mlp,
+                                                                    const float* __restrict__ nmlp, const float* __restrict__ qgrid,
+                                                                    const float* __restrict__ lse_grid, int g_pitch, int e, int win,
+                                                                    int pool, const float* __restrict__ keys,
+                                                                    float* __restrict__ pose_score, float* __restrict__ mask_score,
+                                                                    float* __restrict__ coord_score) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long zb[];     // n words: (ordered z, vertex), later (ordered z, score);
+  __shared__ double red[3][4];                                               // then n u16: the pixels that were hit
+  __shared__ int nhit_s;
   const int b = blockIdx.x, n = res * res, tid = threadIdx.x;
-  float* val = reinterpret_cast<float*>(zb + n);
-  for (int i = tid; i < n; i += 1024) zb[i] = ~0ull;
+  uint16_t* hits = reinterpret_cast<uint16_t*>(zb + n);
+  for (int i = tid; i < n; i += THREADS) zb[i] = ~0ull;
+  if (tid == 0) nhit_s = 0;
   __syncthreads();
   const float* T = Rt + 12 * (size_t)b;
-  for (int v = tid; v < m; v += 1024) {
+#pragma unroll 4
+  for (int v = tid; v < m; v += THREADS) {
     const float x = pts[3 * (size_t)v], y = pts[3 * (size_t)v + 1], z = pts[3 * (size_t)v + 2];
     const float cx = x * T[0] + y * T[1] + z * T[2] + T[3];
     const float cy = x * T[4] + y * T[5] + z * T[6] + T[7];
@@ -875,37 +895,94 @@ __global__ __launch_bounds__(1024) void zbuf_fused_direct_kernel(const float* __
     const float iy = cx * K.k[3] + cy * K.k[4] + cz * K.k[5];
     const float iz = cx * K.k[6] + cy * K.k[7] + cz * K.k[8];
     const float ux = rintf(ix / iz), uy = rintf(iy / iz);
-    if (!(ux >= 0.f) || !(ux < (float)res) || !(uy >= 0.f) || !(uy < (float)res)) continue;
-    atomicMin(&zb[(int)uy * res + (int)ux], ((unsigned long long)ordered_u32(cz) << 32) | (unsigned)v);
+    if ((ux >= 0.f) && (ux < (float)res) && (uy >= 0.f) && (uy < (float)res))
+      atomicMin(&zb[(int)uy * res + (int)ux], ((unsigned long long)ordered_u32(cz) << 32) | (unsigned)v);
   }
   __syncthreads();
-  for (int pix = tid; pix < n; pix += 1024) {
-    const unsigned long long key = zb[pix];
-    float best = 0.f;
-    if (key != ~0ull && unordered_f32((uint32_t)(key >> 32)) > 0.f) {
-      float k[DP];
-      load_row<DP>(keys, (size_t)(uint32_t)key, e, k);
-      const int py = pix / res, px = pix % res;
-      const int y0 = (pool ? max(0, py - 1) : py) * win, y1 = (pool ? min(res, py + 2) : py + 1) * win;
-      const int x0 = (pool ? max(0, px - 1) : px) * win, x1 = (pool ? min(res, px + 2) : px + 1) * win;
-      best = -__builtin_inff();
-      for (int gy = y0; gy < y1; ++gy)
-        for (int gx = x0; gx < x1; ++gx) {
-          const size_t gp = (size_t)gy * g_pitch + gx;
-          float qv[DP];
-          load_row<DP>(qgrid, gp, e, qv);
-          best = fmaxf(best, chain<DP>(qv, k) - lse_grid[gp]);
-        }
+  auto is_hit = [](unsigned long long key) { return key != ~0ull && unordered_f32((uint32_t)(key >> 32)) > 0.f; };
+  auto window = [&](int pix, int* y0, int* y1, int* x0, int* x1) {
+    const int py = pix / res, px = pix % res;
+    *y0 = (pool ? max(0, py - 1) : py) * win; *y1 = (pool ? min(res, py + 2) : py + 1) * win;
+    *x0 = (pool ? max(0, px - 1) : px) * win; *x1 = (pool ? min(res, px + 2) : px + 1) * win;
+  };
+  const int wmax = (pool ? 3 : 1) * win;
+  if (wmax * wmax <= 16) {
+    // small windows (pooled queries: 3 x 3): one thread per output pixel
+    for (int pix = tid; pix < n; pix += THREADS) {
+      const unsigned long long key = zb[pix];
+      if (is_hit(key)) {
+        float k[DP];
+        load_row<DP>(keys, (size_t)(uint32_t)key, e, k);
+        int y0, y1, x0, x1;
+        window(pix, &y0, &y1, &x0, &x1);
+        float best = -__builtin_inff();
+        for (int gy = y0; gy < y1; ++gy)
+          for (int gx = x0; gx < x1; ++gx) {
+            const size_t gp = (size_t)gy * g_pitch + gx;
+            float qv[DP];
+            load_row<DP>(qgrid, gp, e, qv);
+            best = fmaxf(best, chain<DP>(qv, k) - lse_grid[gp]);
+          }
+        zb[pix] = (key & 0xFFFFFFFF00000000ull) | __float_as_uint(best);      // the vertex has served: its slot takes the score
+      }
     }
-    val[pix] = best;
+  } else {
+    // large windows (per-pixel queries: 9 x 9 crop pixels): one WAVE per hit pixel, lane = window element — consecutive
+    // lanes read consecutive crop pixels (dense 48-byte rows), where one thread per output pixel made every load
+    // instruction touch 64 rows 3 pixels apart.  The hit pixels are listed first so that a wave takes two at a time (their
+    // loads overlap); the maximum over the window goes through DPP, not the LDS crossbar.
+    for (int pix = tid; pix < n; pix += THREADS)
+      if (is_hit(zb[pix])) hits[atomicAdd(&nhit_s, 1)] = (uint16_t)pix;
+    __syncthreads();
+    const int nhit = nhit_s, wave = tid >> 6, lane = tid & 63;
+    constexpr int NW = THREADS / 64;
+    // lane -> its two elements (dy, dx) of the UNCLIPPED wmax x wmax window (a third one per 128 more); elements outside the
+    // grid are masked, so no division by the clipped window's width in the loop
+    const int da_y = lane / wmax, da_x = lane % wmax, db_y = (lane + 64) / wmax, db_x = (lane + 64) % wmax;
+    const int gmax = res * win;
+    auto eval = [&](int pix, unsigned long long key, bool live) {
+      float k[DP];
+      load_row<DP>(keys, (size_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)key), e, k);
+      const int py = pix / res, px = pix % res;
+      const int yb = (pool ? py - 1 : py) * win, xb = (pool ? px - 1 : px) * win;
+      float best = -__builtin_inff();
+      auto element = [&](int dy, int dx, float (&qv)[DP], float* l) {
+        const int gy = yb + dy, gx = xb + dx;
+        const bool ok = live && dy < wmax && gy >= 0 && gy < gmax && gx >= 0 && gx < gmax;
+        const size_t gp = ok ? (size_t)gy * g_pitch + gx : 0;
+        load_row<DP>(qgrid, gp, e, qv);
+        *l = lse_grid[gp];
+        return ok;
+      };
+      float qa[DP], qb[DP], la, lb;
+      const bool va = element(da_y, da_x, qa, &la), vb = element(db_y, db_x, qb, &lb);
+      const float fa = chain<DP>(qa, k) - la, fb = chain<DP>(qb, k) - lb;
+      best = fmaxf(va ? fa : best, vb ? fb : best);
+      for (int i = lane + 128; i < wmax * wmax; i += 64) {         // windows of more than 128 elements (scale >= 4)
+        float qc[DP], lc;
+        if (element(i / wmax, i % wmax, qc, &lc)) best = fmaxf(best, chain<DP>(qc, k) - lc);
+      }
+      return wave_max_f32(best);
+    };
+    for (int h0 = wave; h0 < nhit; h0 += 2 * NW) {
+      const int h1 = h0 + NW;
+      const bool two = h1 < nhit;
+      const int p0 = hits[h0], p1 = hits[two ? h1 : h0];
+      const unsigned long long k0 = zb[p0], k1 = zb[p1];
+      const float b0 = eval(p0, k0, true), b1 = eval(p1, k1, two);
+      if (lane == 0) {
+        zb[p0] = (k0 & 0xFFFFFFFF00000000ull) | __float_as_uint(b0);
+        if (two) zb[p1] = (k1 & 0xFFFFFFFF00000000ull) | __float_as_uint(b1);
+      }
+    }
   }
   __syncthreads();
   double sm = 0.0, sc = 0.0, cnt = 0.0;
   if (tid < 256) {
     for (int pix = tid; pix < n; pix += 256) {
       const unsigned long long key = zb[pix];
-      const bool hit = key != ~0ull && unordered_f32((uint32_t)(key >> 32)) > 0.f;
-      if (hit) { sc += (double)val[pix]; cnt += 1.0; }
+      const bool hit = is_hit(key);
+      if (hit) { sc += (double)__uint_as_float((uint32_t)key); cnt += 1.0; }
       sm += (double)(hit ? mlp[pix] : nmlp[pix]);
     }
     double v3[3] = {sm, sc, cnt};
@@ -1236,16 +1313,23 @@ extern "C" int isr_zbuf_score_direct(const float* obj_pts, int m, const float* R
   const int n = res * res;
   K9f K;
   for (int i = 0; i < 9; ++i) K.k[i] = (float)Kcam[i];
-  const size_t lds = (size_t)n * (sizeof(unsigned long long) + sizeof(float));
-  if (lds <= kFusedLdsMax) {       // the z-buffer lives in LDS: one launch, no scratch
-#define ISR_ZB_FUSED(DPv)                                                                                                     \
+  const size_t lds = (size_t)n * (sizeof(unsigned long long) + sizeof(uint16_t));
+  if (lds <= kFusedLdsMax && n <= 65535) {       // the z-buffer lives in LDS: one launch, no scratch
+    // 1 024-thread workgroups are resident one per CU (measured): best while the poses fit the chip in one round
+    const bool wide = B <= 256;
+#define ISR_ZB_FUSED_T(DPv, TH)                                                                                               \
   do {                                                                                                                        \
     if (lds > 64 * 1024)     /* per device, so not cached in a static */                                                      \
-      ISR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zbuf_fused_direct_kernel<DPv>),                        \
+      ISR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&zbuf_fused_direct_kernel<DPv, TH>),                    \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsMax));                     \
-    zbuf_fused_direct_kernel<DPv><<<B, 1024, lds, stream>>>(obj_pts, m, Rt, K, res, mask_log_prob, neg_mask_log_prob, qgrid,  \
-                                                            lse_grid, g_pitch, e, win, pool ? 1 : 0, keys, pose_score,        \
-                                                            mask_score, coord_score);                                         \
+    zbuf_fused_direct_kernel<DPv, TH><<<B, TH, lds, stream>>>(obj_pts, m, Rt, K, res, mask_log_prob, neg_mask_log_prob, qgrid, \
+                                                              lse_grid, g_pitch, e, win, pool ? 1 : 0, keys, pose_score,      \
+                                                              mask_score, coord_score);                                       \
+  } while (0)
+#define ISR_ZB_FUSED(DPv)                                                                                                     \
+  do {                                                                                                                        \
+    if (wide) ISR_ZB_FUSED_T(DPv, 1024);                                                                                      \
+    else ISR_ZB_FUSED_T(DPv, 512);                                                                                            \
   } while (0)
     if (e == 12) ISR_ZB_FUSED(12);
     else if (e <= 16) ISR_ZB_FUSED(16);
@@ -1253,6 +1337,7 @@ extern "C" int isr_zbuf_score_direct(const float* obj_pts, int m, const float* R
     else if (e <= 64) ISR_ZB_FUSED(64);
     else ISR_ZB_FUSED(128);
 #undef ISR_ZB_FUSED
+#undef ISR_ZB_FUSED_T
     ISR_CHECK_LAUNCH("zbuf_fused_direct_kernel");
     return ISR_OK;
   }
