@@ -305,6 +305,8 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     pose_scores = torch.empty(n_poses, device=dev)
     mask_scores = torch.empty(n_poses, device=dev)
     coord_scores = torch.empty(n_poses, device=dev)
+    if grid is not None:
+        pose_batch_size = 65535            # the reference batches to bound the (poses, n + 1) scatter buffers; nothing to bound here
     for l in range(0, n_poses, pose_batch_size):
         Rl, tl = R[l:l + pose_batch_size], t[l:l + pose_batch_size]
         ps, ms, cs = (zbuf_score_direct(obj_pts_d, Rl, tl, Ks, res, mlp, nmlp, grid, max_pool) if grid is not None
