@@ -44,11 +44,19 @@ class RefineObjective:
         self.K = (ctypes.c_double * 9)(*np.asarray(K_crop, np.float64).reshape(9).tolist())
         self.R = np.asarray(R, np.float64).reshape(3, 3)
         self.out = torch.empty(13, dtype=torch.float64, device=self.dev)
+        self.out_host = torch.empty(13, dtype=torch.float64).pin_memory()
         self.ws = ops.workspace(self.dev, 1 << 16, "refine_obj")
+        self.n_launch = 0                 # device evaluations so far
+        self._last = None                 # (pose bytes, full) -> outputs of the last evaluation
 
     def _eval(self, t, R=None, full=False):
+        """One launch per distinct pose: BFGS asks for the value and then for the gradient at the same point
+        (`fun` and `jac` are separate callables in the reference, pose_refine.py:93-101) — the kernel returns both."""
         Rm = self.R if R is None else np.asarray(R, np.float64).reshape(3, 3)
         Rt = np.concatenate([Rm, np.asarray(t, np.float64).reshape(3, 1)], axis=1).reshape(12)
+        tag = (Rt.tobytes(), bool(full))
+        if self._last is not None and self._last[0] == tag:
+            return self._last[1]
         rt = (ctypes.c_double * 12)(*Rt.tolist())
         N, e = self.keys.shape
         fn = lib().isr_refine_objective_full if full else lib().isr_refine_objective
@@ -56,8 +64,13 @@ class RefineObjective:
             rc = fn(ptr(self.X), ptr(self.keys), N, e, ptr(self.q), ptr(self.den), self.q.shape[0], self.mode,
                     ctypes.cast(self.K, ctypes.c_void_p), ctypes.cast(rt, ctypes.c_void_p), ptr(self.out), ptr(self.ws),
                     self.ws.numel(), current_stream(self.dev))
-        check(rc, "isr_refine_objective")
-        return self.out.cpu().numpy()[: 13 if full else 4]
+            check(rc, "isr_refine_objective")
+            self.out_host.copy_(self.out, non_blocking=True)
+            torch.cuda.current_stream(self.dev).synchronize()
+        self.n_launch += 1
+        res = self.out_host.numpy()[: 13 if full else 4].copy()
+        self._last = (tag, res)
+        return res
 
     def with_rotation(self, pose, return_grad=False):
         """The 6-vector is (rotation vector, t): score, or its gradient (d/d rvec by the Rodrigues Jacobian)."""
