@@ -185,44 +185,61 @@ constexpr int kBlock = 64;           // 8 groups
 constexpr int kSuper = 8;            // chunks per super-chunk
 constexpr int kRowsPerBlock = 256;
 
-// exp(x) in f64 for the sampler's arguments (x = alpha * log-probability <= ~0): round-to-nearest argument reduction by
-// ln 2 (hi/lo), degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18), one v_ldexp_f64 (gradual underflow below
-// e^-708, 0 below e^-745; the argument is clamped at -750 so that -inf gives 0, not NaN).  Branch-free, ~22 f64
-// instructions: a third of the library exp with its special cases.  The Horner steps are written as v_fma_f64 with the
-// coefficient in a scalar register pair — left alone the compiler keeps the coefficients in VGPRs and copies each one into
-// the destination of a v_fmac_f64 (13 extra moves per element in a loop bound by instruction issue); same operation,
-// same bits.
+// exp(x) in f64 for the sampler's arguments (x = alpha * log-probability <= ~0), table-driven: x = (64 e + j) ln2/64 + r with
+// |r| <= ln2/128, exp(x) = 2^e * 2^(j/64) * exp(r) — the 64 correctly rounded 2^(j/64) sit in LDS, exp(r) is a degree-5
+// polynomial (truncation 3.5e-17), one v_ldexp_f64 (gradual underflow below e^-708, 0 below e^-745; the argument is
+// clamped at -750 so that -inf gives 0, not NaN).  Branch-free, 16 f64 / integer instructions of which 7 are v_fma_f64 —
+// the kernel that adds the 4.4e8 weights is bound by exactly those (v_fma_f64 issues at 6.1-6.5 cycles, the rest at 4.4-5,
+// profiles/r03_microbench_f64_op_rates.txt); the degree-13 polynomial without a table (15 fma) was 0.54 ms against 0.45.
+// The Horner steps are v_fma_f64 with the coefficient in a scalar register pair — left alone the compiler keeps the
+// coefficients in VGPRs and copies each one into the destination of a v_fmac_f64.  Within 2 ulp of the correctly rounded value.
+__device__ const double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+
+__device__ __forceinline__ void load_exp_table(double* tab_lds) {       // call with all threads, then __syncthreads()
+  if (threadIdx.x < 64) tab_lds[threadIdx.x] = kExp2Tab[threadIdx.x];
+}
+
 __device__ __forceinline__ double fma_sc(double a, double b, double c_scalar) {
   double d;
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_scalar));
   return d;
 }
 
-__device__ __forceinline__ double ep_exp(double x) {
+__device__ __forceinline__ double ep_exp(double x, const double* tab) {
   x = __builtin_fmax(x, -750.0);
-  const double nf = __builtin_rint(x * 1.4426950408889634074);
-  double r = __builtin_fma(nf, -6.93147180369123816490e-01, x);
-  r = __builtin_fma(nf, -1.90821492927058770002e-10, r);
-  double p = 1.6059043836821613e-10;                 // 1/13!
-  p = fma_sc(p, r, 2.08767569878680989792e-09);      // 1/12!
-  p = fma_sc(p, r, 2.50521083854417187751e-08);      // 1/11!
-  p = fma_sc(p, r, 2.75573192239858906526e-07);      // 1/10!
-  p = fma_sc(p, r, 2.75573192239858906526e-06);      // 1/9!
-  p = fma_sc(p, r, 2.48015873015873015873e-05);      // 1/8!
-  p = fma_sc(p, r, 1.98412698412698412698e-04);      // 1/7!
-  p = fma_sc(p, r, 1.38888888888888888889e-03);      // 1/6!
-  p = fma_sc(p, r, 8.33333333333333333333e-03);      // 1/5!
-  p = fma_sc(p, r, 4.16666666666666666667e-02);      // 1/4!
-  p = fma_sc(p, r, 1.66666666666666666667e-01);      // 1/3!
+  const double nf = __builtin_rint(x * 92.33248261689366);            // 64 / ln 2
+  double r = __builtin_fma(nf, -0.010830424696905538, x);              // ln2/64, upper 32 bits: nf * hi is exact
+  r = __builtin_fma(nf, 6.563929801064195e-13, r);                     // minus its remainder
+  const int ni = (int)nf;
+  const double T = tab[ni & 63];
+  double p = 8.33333333333333333333e-03;                               // 1/5!
+  p = fma_sc(p, r, 4.16666666666666666667e-02);                        // 1/4!
+  p = fma_sc(p, r, 1.66666666666666666667e-01);                        // 1/3!
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)nf);
+  return __builtin_ldexp(__dmul_rn(T, p), ni >> 6);
 }
 
 // explicit roundings: no fused multiply-add across the weight and the running sum (the oracle multiplies, then adds)
-__device__ __forceinline__ double ep_weight(float cl, double mpa, double alpha) {
-  return __dmul_rn(ep_exp(__dmul_rn(alpha, (double)cl)), mpa);
+__device__ __forceinline__ double ep_weight(float cl, double mpa, double alpha, const double* tab) {
+  return __dmul_rn(ep_exp(__dmul_rn(alpha, (double)cl), tab), mpa);
 }
 
 __global__ void ep_mpa_kernel(const float* __restrict__ mask_prob, int n, double alpha, double* __restrict__ mpa) {
@@ -233,8 +250,11 @@ __global__ void ep_mpa_kernel(const float* __restrict__ mask_prob, int n, double
 // test / validation aid: the weights themselves
 __global__ void ep_weights_kernel(const float* __restrict__ corr_log, const double* __restrict__ mpa, int n, int m,
                                   double alpha, double* __restrict__ w) {
+  __shared__ double tab[64];
+  load_exp_table(tab);
+  __syncthreads();
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (size_t)n * m) w[i] = ep_weight(corr_log[i], mpa[i / m], alpha);
+  if (i < (size_t)n * m) w[i] = ep_weight(corr_log[i], mpa[i / m], alpha, tab);
 }
 
 // matrix provider: workgroup = 256 rows x one chunk.  The chunk is walked in 32-key slices: the slice of every row is
@@ -243,6 +263,8 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_kernel(const floa
                                                                       const double* __restrict__ mpa_all, int n, int m, int nchunk,
                                                                       double alpha, double* __restrict__ chunk_sums) {
   __shared__ float tile[kRowsPerBlock][33];
+  __shared__ double tab[64];
+  load_exp_table(tab);
   const int tid = threadIdx.x, c = blockIdx.x, o0 = blockIdx.y * kRowsPerBlock;
   const int o = o0 + tid;
   const double mpa = o < n ? mpa_all[o] : 0.0;
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_kernel(const floa
     const int cnt = min(32, kend - kb);
     for (int j0 = 0; j0 < cnt; j0 += kGroup) {
       double s8 = 0.0;
-      for (int j = j0; j < min(cnt, j0 + kGroup); ++j) s8 = __dadd_rn(s8, ep_weight(tile[tid][j], mpa, alpha));
+      for (int j = j0; j < min(cnt, j0 + kGroup); ++j) s8 = __dadd_rn(s8, ep_weight(tile[tid][j], mpa, alpha, tab));
       s64 = __dadd_rn(s64, s8);
     }
     if (((kb - k0) & 32) || kb + 32 >= kend) {      // a block of 64 keys (two slices) is complete
@@ -319,6 +341,8 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_direct_kernel(QGr
                                                                              double* __restrict__ chunk_sums) {
   constexpr int kSlice = DP <= 16 ? kChunk : 8192 / DP;     // keys per LDS stage (a multiple of kGroup)
   __shared__ __attribute__((aligned(16))) float ks[kSlice * DP];
+  __shared__ double tab[64];
+  load_exp_table(tab);
   const int tid = threadIdx.x, c = blockIdx.x;
   const int o = blockIdx.y * kRowsPerBlock + tid;
   float q[DP], lse = 0.f;
@@ -349,7 +373,7 @@ __global__ __launch_bounds__(kRowsPerBlock) void ep_chunk_sums_direct_kernel(QGr
         acc = __builtin_fmaf(q[4 * d4 + 2], kk.z, acc);
         acc = __builtin_fmaf(q[4 * d4 + 3], kk.w, acc);
       }
-      return ep_weight(acc - lse, mpa, alpha);
+      return ep_weight(acc - lse, mpa, alpha, tab);
     };
     for (int jb = 0; jb < cnt; jb += kBlock) {          // kSlice is a multiple of kBlock: blocks do not straddle slices
       const int je = min(cnt, jb + kBlock);
@@ -399,6 +423,8 @@ __global__ __launch_bounds__(256) void ep_chunk_sums_mfma_kernel(QGrid g, const 
   constexpr int LD = DP + 1;                                    // odd dword stride: conflict-free reads down a column
   constexpr int kSlice = DP <= 16 ? kChunk : 8192 / DP;         // keys per LDS stage (a multiple of kBlock)
   __shared__ float ks[kSlice * LD];
+  __shared__ double tab[64];
+  load_exp_table(tab);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
   const int o = blockIdx.y * 128 + wave * 32 + r;
@@ -437,7 +463,7 @@ __global__ __launch_bounds__(256) void ep_chunk_sums_mfma_kernel(QGrid g, const 
           const int kq = t0 + 8 * a + 4 * h;
           double w[4];
 #pragma unroll
-          for (int b = 0; b < 4; ++b) w[b] = kq + b < cnt ? ep_weight(acc[4 * a + b] - lse, mpa, alpha) : 0.0;
+          for (int b = 0; b < 4; ++b) w[b] = kq + b < cnt ? ep_weight(acc[4 * a + b] - lse, mpa, alpha, tab) : 0.0;
           const double from_h0 = from_lower_half(__dadd_rn(__dadd_rn(__dadd_rn(w[0], w[1]), w[2]), w[3]));
           part[a] = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(from_h0, w[0]), w[1]), w[2]), w[3]);    // h = 1: the group sum
         }
@@ -519,6 +545,9 @@ __global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict_
                                                         const double* __restrict__ row_cum, int n_samples, uint32_t seed_lo,
                                                         uint32_t seed_hi, int64_t* __restrict__ corr_idx) {
   __shared__ double wbuf[4][kChunk];
+  __shared__ double tab[64];
+  load_exp_table(tab);
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int t = min(blockIdx.x * 4 + wave, n_samples * 4 - 1);       // 4 draws per sample: the grid is exact
   const int smp = t >> 2, j = t & 3;
@@ -585,7 +614,7 @@ __global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < kChunk / 64; ++i) {
       const int k = k0 + i * 64 + lane;
-      wbuf[wave][i * 64 + lane] = k < kend ? ep_weight(corr_log[(size_t)o * m + k], mpa, alpha) : 0.0;
+      wbuf[wave][i * 64 + lane] = k < kend ? ep_weight(corr_log[(size_t)o * m + k], mpa, alpha, tab) : 0.0;
     }
   } else {
     constexpr int DQ = DP ? DP : 4;
@@ -596,7 +625,7 @@ __global__ __launch_bounds__(256) void ep_sample_kernel(const float* __restrict_
       const int k = k0 + i * 64 + lane;
       float kv[DQ];
       load_row<DQ>(keys, (size_t)min(k, kend - 1), g.e, kv);
-      wbuf[wave][i * 64 + lane] = k < kend ? ep_weight(chain<DQ>(q, kv) - lse, mpa, alpha) : 0.0;
+      wbuf[wave][i * 64 + lane] = k < kend ? ep_weight(chain<DQ>(q, kv) - lse, mpa, alpha, tab) : 0.0;
     }
   }
   __syncthreads();

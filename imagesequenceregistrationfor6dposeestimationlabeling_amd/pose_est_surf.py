@@ -122,22 +122,30 @@ class DescriptorGrid:
     avg_queries=True : the pooled queries, one grid pixel per output pixel (win = 1, poseEstSurf.py:70);
     avg_queries=False: the crop's own pixels, win = scale grid pixels per output pixel (poseEstSurf.py:72-96)."""
 
-    def __init__(self, q: torch.Tensor, keys: torch.Tensor, res: int, pitch: int, win: int):
+    def __init__(self, q: torch.Tensor, keys: torch.Tensor, res: int, pitch: int, win: int, lse: torch.Tensor = None):
         require_cuda(q, keys)
         self.q = q.to(torch.float32).contiguous().view(-1, q.shape[-1])
         self.keys = keys.to(torch.float32).contiguous()
         self.res, self.pitch, self.win, self.e = int(res), int(pitch), int(win), int(self.q.shape[1])
         if self.keys.shape[1] != self.e or self.pitch < self.res * self.win or self.q.shape[0] < self.pitch * (self.res * self.win - 1) + self.res * self.win:
             raise ValueError(f"DescriptorGrid: q {tuple(self.q.shape)} keys {tuple(self.keys.shape)} res {res} pitch {pitch} win {win}")
-        _, _, self.lse = ops.corr_argmax(self.q, self.keys, want_lse=True)
+        # lse: the rows' log-sum-exps when the caller already has them (one K1 launch over a block of images: a row's
+        # result does not depend on the launch it rides in)
+        self.lse = self.row_lse(self.q, self.keys) if lse is None else lse.to(torch.float32).contiguous()
+        if self.lse.shape != (self.q.shape[0],):
+            raise ValueError(f"DescriptorGrid: lse {tuple(self.lse.shape)} for {self.q.shape[0]} grid pixels")
+
+    @staticmethod
+    def row_lse(q_rows: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
+        return ops.corr_argmax(q_rows, keys, want_lse=True)[2]
 
     @classmethod
-    def pooled(cls, queries: torch.Tensor, keys: torch.Tensor, res: int):
-        return cls(queries, keys, res, res, 1)
+    def pooled(cls, queries: torch.Tensor, keys: torch.Tensor, res: int, lse: torch.Tensor = None):
+        return cls(queries, keys, res, res, 1, lse)
 
     @classmethod
-    def per_pixel(cls, query_img: torch.Tensor, keys: torch.Tensor, scale: int):
-        return cls(query_img, keys, query_img.shape[0] // scale, query_img.shape[1], scale)
+    def per_pixel(cls, query_img: torch.Tensor, keys: torch.Tensor, scale: int, lse: torch.Tensor = None):
+        return cls(query_img, keys, query_img.shape[0] // scale, query_img.shape[1], scale, lse)
 
 
 def sample_direct(grid: DescriptorGrid, mask_prob: torch.Tensor, alpha: float, n_samples: int, seed: int) -> torch.Tensor:
@@ -239,6 +247,109 @@ def zbuf_score_direct(obj_pts, R, t, K, res, mask_log_prob, neg_mask_log_prob, g
     return out
 
 
+class _Call:
+    """One estimate_pose call split at its only host round trip (the number of surviving poses sizes the outputs):
+    front() launches everything up to the ordered selection of the poses to score, back(n_keep) scores them and
+    assembles the reference's return tuple.  estimate_pose runs the two halves back to back; estimate_poses runs the
+    fronts of a block of images on several streams, reads all the counts at once, then runs the backs."""
+
+    def __init__(self, mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses=10000,
+                 max_pose_evaluations=1000, down_sample_scale=3, alpha=1.5, dist_2d_min=0.1, pnp_method=SOLVEPNP_AP3P,
+                 pose_batch_size=500, max_pool=True, avg_queries=True, do_prune=True, visualize=False, poses=None,
+                 debug=False, returnPoints=False, *, seed=0, materialize=False):
+        del pnp_method
+        if visualize:
+            raise IsrError("estimate_pose(visualize=True) needs cv2.imshow; not available")
+        self.mask_lgts, self.query_img = _dev(mask_lgts, torch.float32), _dev(query_img, torch.float32)
+        self.obj_pts = _dev(obj_pts, torch.float32).contiguous()
+        self.obj_keys = _dev(obj_keys, torch.float32).contiguous()
+        self.dev = self.mask_lgts.device
+        self.obj_normals, self.obj_diameter = obj_normals, obj_diameter
+        self.Ks = _k_scaled(K, down_sample_scale)
+        self.max_poses, self.max_eval, self.scale, self.alpha = max_poses, max_pose_evaluations, down_sample_scale, alpha
+        self.dist_2d_min, self.batch, self.max_pool, self.avg_queries = dist_2d_min, pose_batch_size, max_pool, avg_queries
+        self.do_prune, self.poses, self.debug, self.returnPoints = do_prune, poses, debug, returnPoints
+        self.seed, self.materialize = seed, materialize
+        self.nk_d = self.res = None
+
+    def pool(self):
+        """:47-69; returns the rows whose log-sum-exps the matrix-free route needs (None on the materialised route)."""
+        self.mlp, self.nmlp, self.mprob, self.queries, self.res = prepare(self.mask_lgts, self.query_img, self.scale, self.max_pool)
+        if self.materialize:
+            return None
+        return self.queries if self.avg_queries else self.query_img.reshape(-1, self.query_img.shape[-1])
+
+    def front(self, lse=None):
+        m = self.obj_keys.shape[0]
+        if self.res is None:
+            self.pool()
+        res, mprob, queries = self.res, self.mprob, self.queries
+        self.grid = self.corr_log = None
+        if not self.materialize:
+            self.grid = (DescriptorGrid.pooled(queries, self.obj_keys, res, lse) if self.avg_queries
+                         else DescriptorGrid.per_pixel(self.query_img, self.obj_keys, self.scale, lse))
+        elif self.avg_queries:
+            corr_raw, self.corr_log = corr_matrices(queries, self.obj_keys, res, self.max_pool)   # (n, m) f32 each, :70 and :97-107
+            if self.corr_log is None:
+                self.corr_log = corr_raw
+        else:
+            # :72-96: per-pixel log-softmax; block-centre values feed the sampler, block maxima the scores
+            corr_raw, corr_blk, _ = patch_corr(self.query_img, self.obj_keys, self.scale)
+            self.corr_log = pool_corr(corr_blk, res) if self.max_pool else corr_blk
+        if self.poses is not None:
+            return
+        self.corr_idx = (sample_direct(self.grid, mprob, self.alpha, self.max_poses, self.seed) if self.grid is not None
+                         else sample(corr_raw, mprob, self.alpha, self.max_poses, self.seed))
+        poses_d, self.ok = p3p_samples(self.corr_idx, res, m, self.obj_pts, self.Ks, self.seed)
+        # normals_scaled.npy is float64 (:121); a device tensor is taken as it is (a NumPy array is 1.9 MB of upload per call)
+        normals_d = (self.obj_normals.to(self.dev, torch.float64) if torch.is_tensor(self.obj_normals)
+                     else _dev(np.asarray(self.obj_normals, np.float64)))
+        (self.dist_d, self.sm_d, self.nm_d, _, self.kidx_d, self.nk_d, self.Rt32) = prune(
+            self.corr_idx, poses_d, self.ok, self.obj_pts, normals_d, res, m, self.Ks[0, 0], self.obj_diameter, self.dist_2d_min,
+            self.do_prune, self.max_eval)
+
+    def back(self, n_keep=None):
+        dev, res, m = self.dev, self.res, self.obj_keys.shape[0]
+        dist_2d = size_mask = normals_mask = None
+        p3dCp = p2dCp = None
+        if self.poses is None:
+            n_poses = min(n_keep, self.max_eval)
+            # the reference's arrays have one entry per SOLVED sample (poses_mask, :145), in sample order
+            pmask = self.ok.cpu().numpy().astype(bool)
+            dist_2d = self.dist_d.cpu().numpy()[pmask]
+            size_mask = self.sm_d.cpu().numpy().astype(bool)[pmask]
+            normals_mask = self.nm_d.cpu().numpy().astype(bool)[pmask]
+            R, t = self.Rt32[:n_poses, :, :3].contiguous(), self.Rt32[:n_poses, :, 3].contiguous()
+            if self.returnPoints:
+                kept = self.kidx_d[:n_keep].long()
+                ci = self.corr_idx[kept]
+                p2dCp = torch.stack([(ci // m) % res, (ci // m) // res], dim=-1).float().cpu().numpy()   # img_pts[p2d_idx].float()
+                p3dCp = self.obj_pts[ci % m].cpu().numpy()
+        else:
+            poses = np.asarray(self.poses)[slice(None, self.max_eval)]
+            n_poses = len(poses)
+            R = torch.from_numpy(np.ascontiguousarray(poses[:, :3, :3])).float().to(dev)
+            t = torch.from_numpy(np.ascontiguousarray(poses[:, :3, 3])).float().to(dev)
+        if self.debug:
+            print('n_poses', n_poses)
+        pose_scores = torch.empty(n_poses, device=dev)
+        mask_scores = torch.empty(n_poses, device=dev)
+        coord_scores = torch.empty(n_poses, device=dev)
+        # the reference batches to bound its (poses, n + 1) scatter buffers; the matrix-free scorer has nothing to bound
+        batch = 65535 if self.grid is not None else self.batch
+        for l in range(0, n_poses, batch):
+            Rl, tl = R[l:l + batch], t[l:l + batch]
+            ps, ms, cs = (zbuf_score_direct(self.obj_pts, Rl, tl, self.Ks, res, self.mlp, self.nmlp, self.grid, self.max_pool)
+                          if self.grid is not None
+                          else zbuf_score(self.obj_pts, Rl, tl, self.Ks, res, self.mlp, self.nmlp, self.corr_log))
+            pose_scores[l:l + batch] = ps
+            mask_scores[l:l + batch] = ms
+            coord_scores[l:l + batch] = cs
+        if self.returnPoints:
+            return R, t, pose_scores, mask_scores, coord_scores, dist_2d, size_mask, normals_mask, p3dCp, p2dCp
+        return R, t, pose_scores, mask_scores, coord_scores, dist_2d, size_mask, normals_mask
+
+
 def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses=10000,
                   max_pose_evaluations=1000, down_sample_scale=3, alpha=1.5, dist_2d_min=0.1,
                   pnp_method=SOLVEPNP_AP3P, pose_batch_size=500, max_pool=True, avg_queries=True, do_prune=True,
@@ -250,70 +361,68 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     materialize=False (default): the (n, m) correspondence matrices of :70-107 are never formed — the sampler and the
     scorer compute the elements they need from the descriptors (DescriptorGrid); True: the round-2/3 route through the
     arrays (corr_matrices / patch_corr + pool_corr).  Both return the same bits."""
-    del pnp_method
-    if visualize:
-        raise IsrError("estimate_pose(visualize=True) needs cv2.imshow; not available")
-    mask_lgts, query_img = _dev(mask_lgts, torch.float32), _dev(query_img, torch.float32)
-    obj_pts_d, obj_keys_d = _dev(obj_pts, torch.float32).contiguous(), _dev(obj_keys, torch.float32).contiguous()
+    call = _Call(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses, max_pose_evaluations,
+                 down_sample_scale, alpha, dist_2d_min, pnp_method, pose_batch_size, max_pool, avg_queries, do_prune, visualize,
+                 poses, debug, returnPoints, seed=seed, materialize=materialize)
+    call.front()
+    return call.back(None if call.nk_d is None else int(call.nk_d.item()))     # the one host round trip: it sizes the outputs
+
+
+def estimate_poses(mask_lgts, query_imgs, obj_pts, obj_normals, obj_keys, obj_diameter, Ks, *, seeds=None, n_streams=4,
+                   **kwargs):
+    """estimate_pose for a block of crops of one object (the reference's per-image loop, inference.py:163, 325-331):
+    mask_lgts (B, r, r), query_imgs (B, r, r, e), Ks one (3, 3) or (B, 3, 3).  Image b's result is estimate_pose's on image b
+    with seed seeds[b] (default b), bit for bit — the same kernels, with ONE K1 launch for the log-sum-exps of the whole
+    block, the per-image chains issued on n_streams side streams so that one image's small kernels fill the tails of
+    another's, and ONE host round trip for all the survivor counts instead of one per image.  Returns a list of B tuples."""
+    mask_lgts, query_imgs = _dev(mask_lgts, torch.float32), _dev(query_imgs, torch.float32)
+    B = mask_lgts.shape[0]
     dev = mask_lgts.device
-    m = obj_keys_d.shape[0]
-    Ks = _k_scaled(K, down_sample_scale)
-    mlp, nmlp, mprob, queries, res = prepare(mask_lgts, query_img, down_sample_scale, max_pool)
-    grid = None
-    if not materialize:
-        grid = (DescriptorGrid.pooled(queries, obj_keys_d, res) if avg_queries
-                else DescriptorGrid.per_pixel(query_img, obj_keys_d, down_sample_scale))
-    elif avg_queries:
-        corr_raw, corr_log = corr_matrices(queries, obj_keys_d, res, max_pool)   # (n, m) f32 each, :70 and :97-107, one pass
-        if corr_log is None:
-            corr_log = corr_raw
-    else:
-        # :72-96: per-pixel log-softmax; block-centre values feed the sampler, block maxima the scores
-        corr_raw, corr_blk, _ = patch_corr(query_img, obj_keys_d, down_sample_scale)
-        corr_log = pool_corr(corr_blk, res) if max_pool else corr_blk
-    dist_2d = size_mask = normals_mask = None
-    p3dCp = p2dCp = None
-    if poses is None:
-        corr_idx = (sample_direct(grid, mprob, alpha, max_poses, seed) if grid is not None
-                    else sample(corr_raw, mprob, alpha, max_poses, seed))
-        poses_d, ok = p3p_samples(corr_idx, res, m, obj_pts_d, Ks, seed)
-        # normals_scaled.npy is float64 (:121); a device tensor is taken as it is (a NumPy array is 1.9 MB of upload per call)
-        normals_d = (obj_normals.to(dev, torch.float64) if torch.is_tensor(obj_normals)
-                     else _dev(np.asarray(obj_normals, np.float64)))
-        dist_d, sm_d, nm_d, keep_d, kidx_d, nk_d, Rt32 = prune(corr_idx, poses_d, ok, obj_pts_d, normals_d, res, m, Ks[0, 0],
-                                                                obj_diameter, dist_2d_min, do_prune, max_pose_evaluations)
-        n_keep = int(nk_d.item())                  # the one host round trip: it sizes the outputs
-        n_poses = min(n_keep, max_pose_evaluations)
-        # the reference's arrays have one entry per SOLVED sample (poses_mask, :145), in sample order
-        pmask = ok.cpu().numpy().astype(bool)
-        dist_2d = dist_d.cpu().numpy()[pmask]
-        size_mask = sm_d.cpu().numpy().astype(bool)[pmask]
-        normals_mask = nm_d.cpu().numpy().astype(bool)[pmask]
-        R, t = Rt32[:n_poses, :, :3].contiguous(), Rt32[:n_poses, :, 3].contiguous()
-        if returnPoints:
-            kept = kidx_d[:n_keep].long()
-            ci = corr_idx[kept]
-            p2dCp = torch.stack([(ci // m) % res, (ci // m) // res], dim=-1).float().cpu().numpy()   # img_pts[p2d_idx].float()
-            p3dCp = obj_pts_d[ci % m].cpu().numpy()
-    else:
-        poses = np.asarray(poses)[slice(None, max_pose_evaluations)]
-        n_poses = len(poses)
-        R = torch.from_numpy(np.ascontiguousarray(poses[:, :3, :3])).float().to(dev)
-        t = torch.from_numpy(np.ascontiguousarray(poses[:, :3, 3])).float().to(dev)
-    if debug:
-        print('n_poses', n_poses)
-    pose_scores = torch.empty(n_poses, device=dev)
-    mask_scores = torch.empty(n_poses, device=dev)
-    coord_scores = torch.empty(n_poses, device=dev)
-    if grid is not None:
-        pose_batch_size = 65535            # the reference batches to bound the (poses, n + 1) scatter buffers; nothing to bound here
-    for l in range(0, n_poses, pose_batch_size):
-        Rl, tl = R[l:l + pose_batch_size], t[l:l + pose_batch_size]
-        ps, ms, cs = (zbuf_score_direct(obj_pts_d, Rl, tl, Ks, res, mlp, nmlp, grid, max_pool) if grid is not None
-                      else zbuf_score(obj_pts_d, Rl, tl, Ks, res, mlp, nmlp, corr_log))
-        pose_scores[l:l + pose_batch_size] = ps
-        mask_scores[l:l + pose_batch_size] = ms
-        coord_scores[l:l + pose_batch_size] = cs
-    if returnPoints:
-        return R, t, pose_scores, mask_scores, coord_scores, dist_2d, size_mask, normals_mask, p3dCp, p2dCp
-    return R, t, pose_scores, mask_scores, coord_scores, dist_2d, size_mask, normals_mask
+    obj_pts_d, obj_keys_d = _dev(obj_pts, torch.float32).contiguous(), _dev(obj_keys, torch.float32).contiguous()
+    normals_d = (obj_normals.to(dev, torch.float64) if torch.is_tensor(obj_normals) else _dev(np.asarray(obj_normals, np.float64)))
+    Ks = np.asarray(Ks, np.float64)
+    seeds = list(range(B)) if seeds is None else list(seeds)
+    main = torch.cuda.current_stream(dev)
+    streams = _side_streams(dev, max(1, min(n_streams, B)))
+    # pooling of every image, then ONE K1 launch for the log-sum-exps of all their descriptor rows (a row's result does not
+    # depend on the launch it rides in; B x 5 476 rows run at the kernel's full rate, one image's 5 476 do not fill the chip)
+    calls = [_Call(mask_lgts[b], query_imgs[b], obj_pts_d, normals_d, obj_keys_d, obj_diameter, Ks if Ks.ndim == 2 else Ks[b],
+                   seed=seeds[b], **kwargs) for b in range(B)]
+    rows = [c.pool() for c in calls]
+    lses = [None] * B
+    if B and rows[0] is not None:
+        lse_all = DescriptorGrid.row_lse(torch.cat(rows), obj_keys_d)
+        lses = list(torch.split(lse_all, [r.shape[0] for r in rows]))
+    for st in streams:
+        st.wait_stream(main)
+    for b, c in enumerate(calls):
+        with torch.cuda.stream(streams[b % len(streams)]):
+            c.front(lses[b])
+    counts = None
+    if calls and calls[0].nk_d is not None:
+        for st in streams:
+            main.wait_stream(st)
+        counts = torch.cat([c.nk_d for c in calls]).cpu().tolist()          # the one round trip of the block
+        for st in streams:
+            st.wait_stream(main)
+    out = []
+    for b, c in enumerate(calls):
+        with torch.cuda.stream(streams[b % len(streams)]):
+            out.append(c.back(None if counts is None else counts[b]))
+    for st in streams:
+        main.wait_stream(st)
+    for res in out:
+        for x in res:
+            if torch.is_tensor(x):
+                x.record_stream(main)
+    return out
+
+
+_streams = {}
+
+
+def _side_streams(dev, n):
+    pool = _streams.setdefault(dev.index, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(dev))
+    return pool[:n]

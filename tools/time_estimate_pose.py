@@ -16,6 +16,8 @@ ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--avg-queries", type=int, default=1)
 ap.add_argument("--materialize", type=int, default=0, help="1: the route through the (n, m) arrays; 0: matrix-free (the default of estimate_pose)")
 ap.add_argument("--only-call", action="store_true", help="skip the per-stage matrix timings")
+ap.add_argument("--block", type=int, default=0, help="> 0: also time estimate_poses on a block of that many crops")
+ap.add_argument("--streams", type=int, default=4)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 s = _scene_ref()
@@ -31,6 +33,19 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / args.reps * 1e3
 print(f"estimate_pose(avg_queries={bool(args.avg_queries)}, materialize={bool(args.materialize)}) r=224 e=12 m=80000 max_poses=10000: {ms:.2f} ms per call; "
       f"{out[0].shape[0]} poses scored, best score {float(out[2].max()):.4f}")
+if args.block:
+    B = args.block
+    ml, q = a[0][None].expand(B, -1, -1).contiguous(), a[1][None].expand(B, -1, -1, -1).contiguous()
+    kwb = {k: v for k, v in kw.items() if k != "seed"}
+    outs = pes.estimate_poses(ml, q, a[2], a[3], a[4], a[5], a[6], n_streams=args.streams, **kwb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        outs = pes.estimate_poses(ml, q, a[2], a[3], a[4], a[5], a[6], n_streams=args.streams, **kwb)
+    torch.cuda.synchronize()
+    msb = (time.perf_counter() - t0) / args.reps * 1e3 / B
+    print(f"estimate_poses(block of {B}, {args.streams} streams, avg_queries={bool(args.avg_queries)}): {msb:.3f} ms per image = "
+          f"{1e3 / msb:.0f} images/s ({ms / msb:.2f}x the single call); poses scored per image {sorted(set(o[0].shape[0] for o in outs))}")
 if args.only_call:
     sys.exit(0)
 # the materialised log-softmax matrix alone: 4 n m bytes written (the reference keeps the same matrix resident)
