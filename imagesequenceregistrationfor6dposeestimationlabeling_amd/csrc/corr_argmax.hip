@@ -469,11 +469,50 @@ __global__ __launch_bounds__(kThreads) void corr_f32_kernel(
   }
 }
 
+// ------------------------------------------------------- exact-f32 K1 on the bf16 matrix cores (split route)
+// The f32 MFMA runs on the SIMD's FP32 lanes: it cannot overlap with the softmax epilogue, and corr_f32_kernel pays MFMA time
+// plus VALU time per tile (profiles/r03_k1_f32_pmc.txt).  The bf16 MFMA runs beside the VALU.  An f32 number is the exact sum
+// of three bf16 numbers (x = x1 + x2 + x3, 8 + 8 + 8 mantissa bits), so <q, k> = sum over the nine plane pairs; the six
+// pairs down to 2^-16 — q1k1, q1k2, q2k1, q2k2, q1k3, q3k1 — are ONE bf16 dot product of the 96-wide rows
+//     Q' = [q1 | q1 | q2 | q2 | q1 | q3 | 0 | 0]     K' = [k1 | k2 | k1 | k2 | k3 | k1 | 0 | 0]      (blocks of 16, D <= 16)
+// with products exact in f32 and f32 accumulation: logits to f32 accuracy (the dropped pairs are 2^-24 relative) from
+// corr_bf16_direct_kernel<8> at its D = 128 rate — with the queries pre-multiplied by log2 e, the log2-domain kernel.
+// Indices stay EXACT: the margin test's error bound also covers the dropped pairs, the rounding of q log2 e and the rounding
+// of the f32 chain itself (together < 3.3 x 2^-23 sqrt(|q'|^2 |k'|^2): the key-norm bound is inflated by 1.08), and what it
+// cannot certify goes to corr_recheck_kernel, which decides by the f32 fmaf chain of the ORIGINAL rows — the logit
+// corr_f32_kernel and the oracle compute — lowest key on ties.  logp / lse come from the split logits (a few 1e-7 of the
+// chain's).  A query's result depends on (query, keys) only, as on every path.
+__device__ __forceinline__ uint16_t bf16_rne(float x, float* rem) {
+  uint32_t u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  u &= 0xFFFF0000u;
+  *rem = x - __uint_as_float(u);          // exact: the discarded low bits
+  return (uint16_t)(u >> 16);
+}
+
+// rows (R, ld) f32, D <= 16 -> (R, 128) bf16; QUERY: [x1 x1 x2 x2 x1 x3 0 0] of x * prescale, else [x1 x2 x1 x2 x3 x1 0 0]
+template <bool QUERY>
+__global__ __launch_bounds__(256) void corr_split_f32_kernel(const float* __restrict__ X, int R, int D, int ld, float prescale,
+                                                             uint16_t* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)R * 16) return;
+  const long row = i >> 4;
+  const int d = (int)(i & 15);
+  float x = d < D ? X[row * ld + d] : 0.f;
+  if (QUERY) x = x * prescale;
+  float r1, r2, r3;
+  const uint16_t x1 = bf16_rne(x, &r1), x2 = bf16_rne(r1, &r2), x3 = bf16_rne(r2, &r3);
+  uint16_t* o = out + row * 128 + d;
+  if (QUERY) { o[0] = x1; o[16] = x1; o[32] = x2; o[48] = x2; o[64] = x1; o[80] = x3; }
+  else       { o[0] = x1; o[16] = x2; o[32] = x1; o[48] = x2; o[64] = x3; o[80] = x1; }
+  o[96] = 0; o[112] = 0;
+}
+
 // ------------------------------------------------------------------------------ key norms
 // max_n |k_n|^2 for the error bound of the margin test, one partial per block; block 0 also zeroes
 // the recheck counter of this call.
 __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __restrict__ K, int N, int D,
-                                                           int ldk, CorrWs ws) {
+                                                           int ldk, float inflate, CorrWs ws) {
   __shared__ float red[4];
   float mx = 0.f;
   for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += kKnBlocks * 256) {
@@ -496,7 +535,7 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
   __syncthreads();
   if (threadIdx.x == 0) {
-    ws.kn2[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    ws.kn2[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * inflate;   // inflate > 1: the split-f32 route's extra error terms
     if (blockIdx.x == 0) { ws.rcount[0] = 0; ws.rcount[1] = 0; }
   }
 }
@@ -630,10 +669,20 @@ __device__ __attribute__((noinline)) double exact_logit(const uint16_t* __restri
 // The listed queries (gathered through rlist) against one key range per blockIdx.y, on the same MFMA
 // chain as the main kernels (C = 0: the same f32 logits); every element at or above the query's
 // threshold is evaluated exactly; per (range, list entry) the best exact value and its lowest key.
+// F32 originals (split-f32 route): the candidates are decided by the k-ordered f32 fmaf chain of the ORIGINAL rows —
+// the exact-f32 kernel's (and the oracle's) logit — instead of the exact products of the bf16 rows.
+struct F32Rows { const float* q; const float* k; int ldq, ldk, D; };
+
+__device__ __attribute__((noinline)) double chain_logit_f32(const float* __restrict__ qrow, const float* __restrict__ krow, int D) {
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) acc = __builtin_fmaf(qrow[d], krow[d], acc);
+  return (double)acc;
+}
+
 template <int DK>
 __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
-    int rsplit, double scale, CorrWs ws) {
+    int rsplit, double scale, F32Rows f32, CorrWs ws) {
   using KS = KeyStage<DK>;
   __shared__ uint4 lds[2][KS::CHUNKS];
   const int cnt = *ws.rcount;
@@ -692,7 +741,8 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
                 for (int i = 0; i < 16; ++i) {            // ascending key inside the lane: strict > keeps the lowest
                   if (acc[i] >= thr[qb]) {
                     const int n = kb + 4 * h + (i & 3) + 8 * (i >> 2);
-                    const double v = exact_logit(Q + (size_t)qrow[qb] * ldq, K + (size_t)n * ldk, 16 * DK, scale);
+                    const double v = f32.q ? chain_logit_f32(f32.q + (size_t)qrow[qb] * f32.ldq, f32.k + (size_t)n * f32.ldk, f32.D)
+                                           : exact_logit(Q + (size_t)qrow[qb] * ldq, K + (size_t)n * ldk, 16 * DK, scale);
                     if (v > best[qb] || (v == best[qb] && n < bidx[qb])) { best[qb] = v; bidx[qb] = n; }
                   }
                 }
@@ -838,15 +888,31 @@ size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   return w.off;
 }
 
+// the split route of the f32 path (D <= 16): the two 128-wide bf16 images, then a bf16 workspace
+size_t carve_split(isr::Workspace& w, int P, int N, uint16_t** q2, uint16_t** k2, CorrWs* o) {
+  *q2 = w.take<uint16_t>((size_t)P * 128);
+  *k2 = w.take<uint16_t>((size_t)N * 128);
+  return carve(w, P, N, ISR_DTYPE_BF16_LOG2, o);
+}
+
+constexpr int kSplitMaxD = 16;
+
 }  // namespace
 
 extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype) {
-  (void)D;
   if (P <= 0 || N <= 0) return 0;
   isr::Workspace w(nullptr, 0);
   CorrWs o;
-  return carve(w, P, N, dtype, &o) + 256;
+  size_t bytes = carve(w, P, N, dtype, &o) + 256;
+  if (dtype == ISR_DTYPE_F32 && (D <= 0 || D <= kSplitMaxD)) {     // either f32 route fits (D = 0: unknown, assume the larger)
+    isr::Workspace w2(nullptr, 0);
+    uint16_t *q2, *k2;
+    const size_t split = carve_split(w2, P, N, &q2, &k2, &o) + 256;
+    if (split > bytes) bytes = split;
+  }
+  return bytes;
 }
+
 
 // Diagnostics: the shader clock the direct kernel actually ran at in the LAST call on this workspace:
 // workgroup (0, 0) reads s_memtime (counts at the shader clock) and s_memrealtime (constant 100 MHz) when it
@@ -854,7 +920,7 @@ extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype
 extern "C" int isr_corr_argmax_clock_mhz(const void* ws_, size_t ws_bytes, int P, int N, int dtype,
                                          double* mhz_host, isr_stream_t stream_) {
   ISR_REQUIRE(ws_ && mhz_host && P > 0 && N > 0, "isr_corr_argmax_clock_mhz: bad argument");
-  ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, 0, dtype), "isr_corr_argmax_clock_mhz: workspace too small");
+  ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, 128, dtype), "isr_corr_argmax_clock_mhz: workspace too small");
   *mhz_host = 0.0;
   if (dtype == ISR_DTYPE_F32) return ISR_OK;
   isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
@@ -873,7 +939,7 @@ extern "C" int isr_corr_argmax_clock_mhz(const void* ws_, size_t ws_bytes, int P
 extern "C" int isr_corr_argmax_recheck_count(const void* ws_, size_t ws_bytes, int P, int N, int dtype,
                                              int32_t* count_host, isr_stream_t stream_) {
   ISR_REQUIRE(ws_ && count_host && P > 0 && N > 0, "isr_corr_argmax_recheck_count: bad argument");
-  ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, 0, dtype), "isr_corr_argmax_recheck_count: workspace too small");
+  ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, 128, dtype), "isr_corr_argmax_recheck_count: workspace too small");
   *count_host = -1;
   if (dtype == ISR_DTYPE_F32) return ISR_OK;
   isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
@@ -885,43 +951,26 @@ extern "C" int isr_corr_argmax_recheck_count(const void* ws_, size_t ws_bytes, i
   return ISR_OK;
 }
 
-extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
-                               int dtype, int32_t* idx, float* logp, float* lse, void* ws_,
-                               size_t ws_bytes, isr_stream_t stream_) {
-  ISR_REQUIRE(Q && K && idx, "isr_corr_argmax: null pointer");
-  ISR_REQUIRE(P > 0 && N > 0 && D > 0, "isr_corr_argmax: P=%d N=%d D=%d must be positive", P, N, D);
-  ISR_REQUIRE(ldq >= D && ldk >= D, "isr_corr_argmax: ldq=%d ldk=%d < D=%d", ldq, ldk, D);
-  ISR_REQUIRE(dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2 || dtype == ISR_DTYPE_F32,
-              "isr_corr_argmax: dtype %d", dtype);
-  if (!ws_ || ws_bytes < isr_corr_argmax_workspace_bytes(P, N, D, dtype)) {
-    isr::set_error("isr_corr_argmax: workspace %zu < %zu", ws_bytes,
-                   isr_corr_argmax_workspace_bytes(P, N, D, dtype));
-    return ISR_ERR_WORKSPACE;
-  }
-  hipStream_t stream = isr::as_stream(stream_);
-  const CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * kQB * 32);
-  isr::Workspace w(ws_, ws_bytes);
-  CorrWs ws;
-  carve(w, P, N, dtype, &ws);
+namespace {
+
+// the bf16 kernels of one call (direct kernel, per-query fallback, finalize, exact recheck, merge).  f32.q != nullptr: the
+// split-f32 route — Q / K are the 128-wide split images, the recheck decides by the f32 chain of the original rows.
+int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int ldq, int ldk, bool log2, const CorrPlan& p,
+                const CorrWs& ws, int32_t* idx, float* logp, float* lse, F32Rows f32, float kn_inflate, hipStream_t stream) {
   const dim3 grid(p.qblocks, p.nsplit);
   const int fin_blocks = (P + 255) / 256;
   const int fin_bf16 = (p.nsplit == 1 && fin_blocks > kFallbackGrid) ? kFallbackGrid : fin_blocks;   // one key range: list-driven
-
-  if (dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2) {
-    ISR_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128,
-                "isr_corr_argmax(bf16): D=%d must be 16, 32, 64 or 128 (zero-pad the columns)", D);
-    ISR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)Q % 16 == 0) && ((uintptr_t)K % 16 == 0),
-                "isr_corr_argmax(bf16): rows must be 16-byte aligned (ldq=%d ldk=%d)", ldq, ldk);
-    ISR_REQUIRE((long long)p.range_chunks * kChunk * ldk * 2 < (1ll << 31),
-                "isr_corr_argmax(bf16): a key range of %d rows x ldk=%d exceeds the 2 GiB buffer window",
-                p.range_chunks * kChunk, ldk);
-    const uint16_t* q = static_cast<const uint16_t*>(Q);
-    const uint16_t* k = static_cast<const uint16_t*>(K);
-    const bool log2 = dtype == ISR_DTYPE_BF16_LOG2;
-    const int cgrid = (int)(((long)p.qblocks * p.nchunks < kFallbackGrid) ? (long)p.qblocks * p.nchunks : kFallbackGrid);   // fallback: strides over listed blocks x chunks
-    const dim3 rgrid(128, p.rsplit);      // groups of 256 listed queries stride over 128 workgroups per key range
-    const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
-    corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, ws);
+  ISR_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128,
+              "isr_corr_argmax(bf16): D=%d must be 16, 32, 64 or 128 (zero-pad the columns)", D);
+  ISR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0),
+              "isr_corr_argmax(bf16): rows must be 16-byte aligned (ldq=%d ldk=%d)", ldq, ldk);
+  ISR_REQUIRE((long long)p.range_chunks * kChunk * ldk * 2 < (1ll << 31),
+              "isr_corr_argmax(bf16): a key range of %d rows x ldk=%d exceeds the 2 GiB buffer window",
+              p.range_chunks * kChunk, ldk);
+  const int cgrid = (int)(((long)p.qblocks * p.nchunks < kFallbackGrid) ? (long)p.qblocks * p.nchunks : kFallbackGrid);   // fallback: strides over listed blocks x chunks
+  const dim3 rgrid(128, p.rsplit);      // groups of 256 listed queries stride over 128 workgroups per key range
+  const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
+  corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, kn_inflate, ws);
 #define ISR_LAUNCH_BF16(DKv)                                                                                  \
   do {                                                                                                        \
     if (log2) {                                                                                               \
@@ -939,17 +988,65 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
       corr_finalize_kernel<2><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
     }                                                                                                         \
-    corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, ws);      \
+    corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);  \
   } while (0)
-    switch (D) {
-      case 16: ISR_LAUNCH_BF16(1); break;
-      case 32: ISR_LAUNCH_BF16(2); break;
-      case 64: ISR_LAUNCH_BF16(4); break;
-      default: ISR_LAUNCH_BF16(8); break;
-    }
+  if (f32.q) {       // split-f32 route: 128-wide rows whose last two blocks are zero, log2 domain
+    corr_bf16_direct_kernel<8, kQB, false, 6><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws, idx, logp, lse);
+    corr_bf16_kernel<8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
+    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
+    corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
+  } else
+  switch (D) {
+    case 16: ISR_LAUNCH_BF16(1); break;
+    case 32: ISR_LAUNCH_BF16(2); break;
+    case 64: ISR_LAUNCH_BF16(4); break;
+    default: ISR_LAUNCH_BF16(8); break;
+  }
 #undef ISR_LAUNCH_BF16
-    corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, p.rsplit, ws, idx);
-    ISR_CHECK_LAUNCH("corr bf16 kernels");
+  corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, p.rsplit, ws, idx);
+  ISR_CHECK_LAUNCH("corr bf16 kernels");
+  return ISR_OK;
+}
+
+}  // namespace
+
+extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
+                               int dtype, int32_t* idx, float* logp, float* lse, void* ws_,
+                               size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(Q && K && idx, "isr_corr_argmax: null pointer");
+  ISR_REQUIRE(P > 0 && N > 0 && D > 0, "isr_corr_argmax: P=%d N=%d D=%d must be positive", P, N, D);
+  ISR_REQUIRE(ldq >= D && ldk >= D, "isr_corr_argmax: ldq=%d ldk=%d < D=%d", ldq, ldk, D);
+  ISR_REQUIRE(dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2 || dtype == ISR_DTYPE_F32,
+              "isr_corr_argmax: dtype %d", dtype);
+  if (!ws_ || ws_bytes < isr_corr_argmax_workspace_bytes(P, N, D, dtype)) {
+    isr::set_error("isr_corr_argmax: workspace %zu < %zu", ws_bytes,
+                   isr_corr_argmax_workspace_bytes(P, N, D, dtype));
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  if (dtype == ISR_DTYPE_F32 && D <= kSplitMaxD && isr::tuning(ISR_TUNE_K1_F32_CHAIN) == 0) {
+    // split route: exact indices and f32-accurate sums from the bf16 matrix cores (corr_split_f32_kernel's header)
+    isr::Workspace w(ws_, ws_bytes);
+    uint16_t *q2, *k2;
+    CorrWs ws;
+    carve_split(w, P, N, &q2, &k2, &ws);
+    const CorrPlan p = make_plan(P, N, slots_for(ISR_DTYPE_BF16_LOG2, 128), kWaves * kQB * 32);
+    const float* qf = static_cast<const float*>(Q);
+    const float* kf = static_cast<const float*>(K);
+    corr_split_f32_kernel<true><<<(unsigned)(((long)P * 16 + 255) / 256), 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q2);
+    corr_split_f32_kernel<false><<<(unsigned)(((long)N * 16 + 255) / 256), 256, 0, stream>>>(kf, N, D, ldk, 1.f, k2);
+    return launch_bf16(q2, k2, P, N, 128, 128, 128, true, p, ws, idx, logp, lse, F32Rows{qf, kf, ldq, ldk, D}, 1.08f, stream);
+  }
+  const CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * kQB * 32);
+  isr::Workspace w(ws_, ws_bytes);
+  CorrWs ws;
+  carve(w, P, N, dtype, &ws);
+  const dim3 grid(p.qblocks, p.nsplit);
+  const int fin_blocks = (P + 255) / 256;
+
+  if (dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2) {
+    return launch_bf16(static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), P, N, D, ldq, ldk,
+                       dtype == ISR_DTYPE_BF16_LOG2, p, ws, idx, logp, lse, F32Rows{nullptr, nullptr, 0, 0, 0}, 1.f, stream);
   } else {
     ISR_REQUIRE(D <= 128, "isr_corr_argmax(f32): D=%d > 128", D);
     const float* q = static_cast<const float*>(Q);

@@ -48,7 +48,9 @@ __device__ __forceinline__ float tile_max(const f32x16& acc) {
 // NAT = false: log2-unit logits (ISR_DTYPE_BF16_LOG2): l += exp2(s').
 // NAT = true:  natural-unit logits (ISR_DTYPE_BF16):   l += exp2(s * log2 e) — one multiply more per
 //   element.  Maxima are raw logits in either case.
-template <int DK, int QB, bool NAT>
+// DKU <= DK: the 16-wide blocks that can be non-zero (the split-f32 route stores 8 blocks of which the last two are zero
+// padding: their MFMAs would add exact zeros, so they are not issued — same bits, 6 instead of 8 matrix instructions per tile).
+template <int DK, int QB, bool NAT, int DKU = DK>
 __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
@@ -69,14 +71,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   const long long t_sclk0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
   const long long t_ref0 = probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 
-  bf16x8 bq[QB][DK];
+  bf16x8 bq[QB][DKU];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     int row = q0 + qb * 32 + r;
     row = row < P ? row : P - 1;
     const uint16_t* src = Q + (size_t)row * ldq + 8 * h;
 #pragma unroll
-    for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+    for (int s = 0; s < DKU; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
   }
   // ONE key range (gridDim.y == 1: every launch whose query blocks alone fill the chip): this workgroup sees
   // every chunk of its queries, adds the chunk sums in f64 in ascending order itself — the very operations
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   for (int qb = 0; qb < QB; ++qb) {
     float n2 = 0.f;
 #pragma unroll
-    for (int s = 0; s < DK; ++s)
+    for (int s = 0; s < DKU; ++s)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float v = __uint_as_float((uint32_t)(uint16_t)bq[qb][s][e] << 16);
@@ -162,12 +164,12 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   // A fragments of key sub-tile `sub` of LDS buffer `buf`.  One register set: a fragment's ds_read
   // for the NEXT sub-tile is issued right behind the last MFMA that reads the current one, i.e. one
   // whole item (~300 cycles) before the MFMA that needs it.
-  bf16x8 a[DK];
+  bf16x8 a[DKU];
   auto load_a = [&](int buf, int sub) {
     const int row = sub * 32 + r;
     const int sw = (row / RPB) & (NCH - 1);
 #pragma unroll
-    for (int s = 0; s < DK; ++s) {
+    for (int s = 0; s < DKU; ++s) {
       const uint4 v = lds[buf][row * NCH + ((2 * s + h) ^ sw)];
       a[s] = *reinterpret_cast<const bf16x8*>(&v);
     }
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   f32x16 acc[2];
   acc[0] = splat16(0.f);
 #pragma unroll
-  for (int s = 0; s < DK; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[0][s], acc[0], 0, 0, 0);
+  for (int s = 0; s < DKU; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[0][s], acc[0], 0, 0, 0);
 
   auto stage_body = [&](int stage, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         f32x16& nxt = acc[(w + 1) & 1];
         nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[qbn][0], splat16(0.f), 0, 0, 0);
 #pragma unroll
-        for (int s = 1; s < DK; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qbn][s], nxt, 0, 0, 0);
+        for (int s = 1; s < DKU; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qbn][s], nxt, 0, 0, 0);
         if (qb == 0) {                                    // the chain above was the fragments' last reader
           if (w == NW - 2) { if (has_next) load_a(buf ^ 1, 0); }
           else load_a(buf, sub + 1);
@@ -238,9 +240,9 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         // ties the item's results to a fixed point of the instruction stream: a stage is one basic
         // block, and without it instruction selection sinks all eight epilogues below all eight MFMA
         // chains (eight tiles live, 243 VGPRs, nothing overlapped).
-        constexpr int G = ((NAT ? 60 : 44) + DK - 1) / DK;
+        constexpr int G = ((NAT ? 60 : 44) + DKU - 1) / DKU;
 #pragma unroll
-        for (int s = 0; s < DK; ++s) {
+        for (int s = 0; s < DKU; ++s) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           if (qb == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // this fragment's next ds_read
           __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
@@ -284,14 +286,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     int cand = T;
     float cmax = -__builtin_inff(), c2 = -__builtin_inff();
     unsigned long long todo = __ballot(true);
-    auto fetch = [&](int kb, bf16x8 (&dst)[DK]) {
+    auto fetch = [&](int kb, bf16x8 (&dst)[DKU]) {
       int row = kb + r;
       row = row < N ? row : N - 1;
       const uint16_t* src = K + (size_t)row * ldk + 8 * h;
 #pragma unroll
-      for (int s = 0; s < DK; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+      for (int s = 0; s < DKU; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
     };
-    bf16x8 a0[DK], a1[DK];
+    bf16x8 a0[DKU], a1[DKU];
     int kb_cur = __shfl(T, __ffsll(todo) - 1, 64);
     fetch(kb_cur, a0);
     while (true) {                                        // wave-uniform trip count (<= 32)
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       }
       f32x16 c = splat16(0.f);
 #pragma unroll
-      for (int s = 0; s < DK; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s], bq[qb][s], c, 0, 0, 0);
+      for (int s = 0; s < DKU; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s], bq[qb][s], c, 0, 0, 0);
       if (kb_cur + 32 > k1) mask_tail(c, kb_cur + 4 * h, k1);
       if (T == kb_cur) {
         // the two largest of this lane's 16 rows (with multiplicity) and the lowest row of the largest
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       }
       if (!more) break;
 #pragma unroll
-      for (int s = 0; s < DK; ++s) a0[s] = a1[s];
+      for (int s = 0; s < DKU; ++s) a0[s] = a1[s];
       kb_cur = kb_nxt;
     }
     // runner-up of the query inside this key range.  The lane that owns the winner contributes its

@@ -408,3 +408,47 @@ def test_corr_randomised_shapes_distributions_and_scales(cuda0, oracle_lib):
         b = int(rng.integers(a + 1, P + 1))
         i2, l2 = ops.corr_argmax(qb[a:b].contiguous().to(cuda0), kb.to(cuda0), log2_prescaled=log2)
         assert torch.equal(i2, idx[a:b]) and torch.equal(l2, logp[a:b]), (c, kind, a, b)
+
+
+@pytest.mark.parametrize("P,N,D", [(300, 31, 12), (1000, 4097, 12), (777, 12289, 5), (5000, 20000, 16), (64, 128, 8),
+                                   (20000, 80000, 12), (513, 4096, 13)])
+def test_corr_f32_split_route_equals_chain_route(cuda0, oracle_lib, P, N, D):
+    """f32 descriptors with D <= 16 run on the bf16 matrix cores (three-way bf16 split of every f32 number, six plane pairs as one
+    96-wide bf16 dot product, log2-domain direct kernel) with an f32-chain exact recheck: the indices are those of the f32-MFMA
+    chain kernel (ISR_TUNE_K1_F32_CHAIN) and of the oracle — ties to the lowest key, duplicates across a chunk boundary, zero
+    rows, a spiked and a negated query — logp / lse agree to a few 1e-7 relative to the logit scale, and a slice at an odd
+    offset reproduces its rows bit for bit."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    g = torch.Generator(device=cuda0).manual_seed(P + N + D)
+    K = torch.randn(N, D, device=cuda0, generator=g) * 2.0
+    K[N // 2] = K[0]
+    if N > 4200:
+        K[4100] = K[3]
+    gt = torch.randint(N, (P,), device=cuda0, generator=g)
+    Q = K[gt] * 1.5 + 0.5 * torch.randn(P, D, device=cuda0, generator=g)
+    Q[::7] = 0.0
+    Q[1] *= 20.0
+    Q[2] = -Q[2]
+    Q[3] = K[0] * 1.5                                                      # exact tie between key 0 and its duplicate
+    with ops.tuning(k1_f32_chain=1):
+        want = ops.corr_argmax(Q, K, want_lse=True)
+    got = ops.corr_argmax(Q, K, want_lse=True)
+    assert torch.equal(got[0], want[0])
+    scale = 1.0 + float(want[2].abs().max())
+    assert float((got[1] - want[1]).abs().max()) < 3e-6 * scale and float((got[2] - want[2]).abs().max()) < 3e-6 * scale
+    o = oracle_lib.corr_argmax_f32(Q[:256].cpu().numpy(), K.cpu().numpy())
+    assert np.array_equal(got[0][:256].cpu().numpy(), o["idx"])
+    if P > 300:
+        # launch independence, for logits inside the direct kernel's range (|log2-unit logit| < 128, as on the bf16 paths: an
+        # out-of-range query is still decided exactly, but which of its key ranges are redone with a per-query reference — and
+        # with that the last bit of its logp — follows the launch's key split)
+        Kn = 5.0 * K / K.norm(dim=1, keepdim=True)
+        Qs = 1.2 * Kn[gt] + 0.3 * torch.randn(P, D, device=cuda0, generator=g)
+        Qs[::5] = 0.0
+        full = ops.corr_argmax(Qs, Kn, want_lse=True)
+        assert float(full[2].max()) * 1.4427 < 100.0
+        K = Kn
+        for lo, n in ((37, 200), (0, 300)):
+            sl = ops.corr_argmax(Qs[lo:lo + n], K, want_lse=True)
+            for a, b in zip(sl, full):
+                assert torch.equal(a, b[lo:lo + n])
