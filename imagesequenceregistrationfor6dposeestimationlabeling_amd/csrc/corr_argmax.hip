@@ -669,6 +669,19 @@ __device__ __attribute__((noinline)) double exact_logit(const uint16_t* __restri
 // The listed queries (gathered through rlist) against one key range per blockIdx.y, on the same MFMA
 // chain as the main kernels (C = 0: the same f32 logits); every element at or above the query's
 // threshold is evaluated exactly; per (range, list entry) the best exact value and its lowest key.
+// Key ranges of the recheck pass: its cost is the latency of ONE workgroup streaming its key range for a group of listed
+// queries, so a short list (the usual case: ~0.1 % of the queries) is spread over up to kRSplitGrid ranges — as many as
+// the rval / ridx scratch (rsplit * P entries, sized for a list of all P queries over rsplit ranges) holds for the actual
+// list length.  (With 4 ranges fixed the pass took 0.43 ms of a 1.6 ms estimate_pose call at P = 5 476, N = 80 000.)
+// The outcome does not depend on the partition: ranges merge in ascending order, ties keep the lower key.
+constexpr int kRSplitGrid = 64;
+__device__ __forceinline__ int recheck_ranges(int cnt, int P, int rsplit, int nstage_all) {
+  const long cap = (long)rsplit * P;
+  int rs = kRSplitGrid;
+  while (rs > 1 && ((long)rs * cnt > cap || rs > nstage_all)) rs >>= 1;
+  return rs;
+}
+
 // F32 originals (split-f32 route): the candidates are decided by the k-ordered f32 fmaf chain of the ORIGINAL rows —
 // the exact-f32 kernel's (and the oracle's) logit — instead of the exact products of the bf16 rows.
 struct F32Rows { const float* q; const float* k; int ldq, ldk, D; };
@@ -688,12 +701,14 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
   const int cnt = *ws.rcount;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
-  const int range = blockIdx.y;
   const int nstage_all = (N + kTK - 1) / kTK;
-  const int per = (nstage_all + rsplit - 1) / rsplit;
+  const int rs = recheck_ranges(cnt, P, rsplit, nstage_all);
+  // the launch is a flat list of workgroups: rs key ranges x (gridDim.x / rs) slots striding over the groups of listed queries
+  const int range = blockIdx.x % rs, slot = blockIdx.x / rs, nslots = gridDim.x / rs;
+  const int per = (nstage_all + rs - 1) / rs;
   const int k0 = range * per * kTK;
   const int k1 = min(N, k0 + per * kTK);
-  for (int g = blockIdx.x; g * (kWaves * kQB * 32) < cnt; g += gridDim.x) {   // block-uniform
+  for (int g = slot; g * (kWaves * kQB * 32) < cnt; g += nslots) {   // block-uniform
     const int e0 = (g * kWaves + wave) * (kQB * 32);
     bf16x8 bq[kQB][DK];
     float thr[kQB];
@@ -761,23 +776,25 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
       if (oi >= 0 && (bidx[qb] < 0 || ov > best[qb] || (ov == best[qb] && oi < bidx[qb]))) { best[qb] = ov; bidx[qb] = oi; }
       const int e = e0 + qb * 32 + r;
       if (h == 0 && e < cnt) {
-        ws.rval[(size_t)range * P + e] = best[qb];
-        ws.ridx[(size_t)range * P + e] = bidx[qb];
+        ws.rval[(size_t)range * cnt + e] = best[qb];
+        ws.ridx[(size_t)range * cnt + e] = bidx[qb];
       }
     }
   }
 }
 
 // list entry e: best over the recheck key ranges (ascending: ties keep the lower key) -> idx[rlist[e]]
-__global__ __launch_bounds__(256) void corr_recheck_merge_kernel(int P, int rsplit, CorrWs ws,
+__global__ __launch_bounds__(256) void corr_recheck_merge_kernel(int P, int N, int rsplit, CorrWs ws,
                                                                  int32_t* __restrict__ idx) {
   const int cnt = *ws.rcount;
+  const int rs = recheck_ranges(cnt, P, rsplit, (N + kTK - 1) / kTK);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += gridDim.x * blockDim.x) {
     double best = -__builtin_inf();
     int bi = -1;
-    for (int r = 0; r < rsplit; ++r) {
-      const int i = ws.ridx[(size_t)r * P + e];
-      const double v = ws.rval[(size_t)r * P + e];
+#pragma unroll 8
+    for (int r = 0; r < rs; ++r) {
+      const int i = ws.ridx[(size_t)r * cnt + e];
+      const double v = ws.rval[(size_t)r * cnt + e];
       if (i >= 0 && (bi < 0 || v > best)) { best = v; bi = i; }
     }
     if (bi >= 0) idx[ws.rlist[e]] = bi;
@@ -951,6 +968,23 @@ extern "C" int isr_corr_argmax_recheck_count(const void* ws_, size_t ws_bytes, i
   return ISR_OK;
 }
 
+// the same for an f32 call (D <= 16 with the split route active: the length of its f32-chain recheck list; -1 otherwise)
+extern "C" int isr_corr_argmax_recheck_count_f32(const void* ws_, size_t ws_bytes, int P, int N, int D,
+                                                 int32_t* count_host, isr_stream_t stream_) {
+  ISR_REQUIRE(ws_ && count_host && P > 0 && N > 0 && D > 0, "isr_corr_argmax_recheck_count_f32: bad argument");
+  ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, D, ISR_DTYPE_F32), "isr_corr_argmax_recheck_count_f32: workspace too small");
+  *count_host = -1;
+  if (D > kSplitMaxD || isr::tuning(ISR_TUNE_K1_F32_CHAIN) != 0) return ISR_OK;
+  isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
+  uint16_t *q2, *k2;
+  CorrWs ws;
+  carve_split(w, P, N, &q2, &k2, &ws);
+  hipStream_t stream = isr::as_stream(stream_);
+  ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.rcount, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  ISR_CHECK_HIP(hipStreamSynchronize(stream));
+  return ISR_OK;
+}
+
 namespace {
 
 // the bf16 kernels of one call (direct kernel, per-query fallback, finalize, exact recheck, merge).  f32.q != nullptr: the
@@ -968,7 +1002,7 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
               "isr_corr_argmax(bf16): a key range of %d rows x ldk=%d exceeds the 2 GiB buffer window",
               p.range_chunks * kChunk, ldk);
   const int cgrid = (int)(((long)p.qblocks * p.nchunks < kFallbackGrid) ? (long)p.qblocks * p.nchunks : kFallbackGrid);   // fallback: strides over listed blocks x chunks
-  const dim3 rgrid(128, p.rsplit);      // groups of 256 listed queries stride over 128 workgroups per key range
+  const dim3 rgrid(16 * kRSplitGrid);   // workgroups = key ranges (by list length, <= 64) x slots striding over the groups of 256 listed queries
   const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
   corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, kn_inflate, ws);
 #define ISR_LAUNCH_BF16(DKv)                                                                                  \
@@ -1003,7 +1037,7 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     default: ISR_LAUNCH_BF16(8); break;
   }
 #undef ISR_LAUNCH_BF16
-  corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, p.rsplit, ws, idx);
+  corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, N, p.rsplit, ws, idx);
   ISR_CHECK_LAUNCH("corr bf16 kernels");
   return ISR_OK;
 }

@@ -92,6 +92,9 @@ int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, 
  * decided by the exact recheck; -1 for ISR_DTYPE_F32.  count_host is a HOST pointer; synchronises. */
 int isr_corr_argmax_recheck_count(const void* ws, size_t ws_bytes, int P, int N, int dtype,
                                   int32_t* count_host, isr_stream_t stream);
+/* the same for an f32 call with D <= 16 (the split route's f32-chain recheck list; -1 when that route is not taken) */
+int isr_corr_argmax_recheck_count_f32(const void* ws, size_t ws_bytes, int P, int N, int D, int32_t* count_host,
+                                      isr_stream_t stream);
 
 /* Diagnostics: the shader clock (MHz) the bf16 kernel held during the last isr_corr_argmax call on this
  * workspace, from s_memtime / s_memrealtime over the life of one workgroup; 0 for ISR_DTYPE_F32. */
