@@ -36,7 +36,10 @@ extern "C" {
 #define ISR_ERR_UNSUPPORTED (-4) /* valid request this build does not implement */
 
 #define ISR_DTYPE_BF16 0 /* bf16 inputs, v_mfma_f32_32x32x16_bf16, f32 accumulate */
-#define ISR_DTYPE_F32 1  /* f32 inputs, v_mfma_f32_32x32x2_f32: k-ordered fmaf chain, bit-exact */
+#define ISR_DTYPE_F32 1  /* f32 inputs; the index is the arg-max of the k-ordered f32 fmaf-chain logits (lowest key on ties).
+                            D > 16: v_mfma_f32_32x32x2_f32, whose accumulation IS that chain.  D <= 16: every f32 number as three
+                            bf16 numbers, the six plane pairs down to 2^-16 as one 96-wide bf16 dot product on the bf16 matrix
+                            cores (f32-accurate sums), margin test + recheck by the f32 chain of the original rows */
 #define ISR_DTYPE_BF16_LOG2 2 /* bf16 inputs whose QUERIES were multiplied by log2(e) before their one
                                 rounding to bf16: logits are in log2 units inside the kernel (exp2 + add
                                 per element, nothing else) — the fastest path; outputs stay natural-log */
