@@ -25,7 +25,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with two extra o
   cpu_baseline  the CPU oracle (kind "port": the reference's own OpenCV/Open3D path cannot run
                 here) timed on a bounded sample of the same workload on this box's host cores.
 and, untimed, `parity_check` (the last step recomputed by the oracle) and `estimate_pose` (the reference's other per-image
-path, poseEstSurf.estimate_pose, at its own size: ms per call of the matrix-free and of the materialised route).
+path, poseEstSurf.estimate_pose, at its own size: ms per call of the matrix-free and of the materialised route) and
+`reference_shape` (the reference's own 75 x 75 / 12-D / 80 000-key per-image loop through sequence.register_crops).
 """
 from __future__ import annotations
 
@@ -83,7 +84,7 @@ def parse_args():
     ap.add_argument("--verify", choices=("pick", "vote"), default="pick",
                     help="verification stage: 'pick' = consecutive-pair Chamfer pick (verfication.py:61-108, the headline); "
                          "'vote' = the n x n ADD-S vote whose top choice icp.py:37-39 reads (choosePose.py:121-151)")
-    ap.add_argument("--no-estimate-pose", action="store_true", help="skip the untimed estimate_pose timing (reference size)")
+    ap.add_argument("--no-estimate-pose", action="store_true", help="skip the untimed estimate_pose / reference-shape timings")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed oracle re-computation of the last step")
     return ap.parse_args()
 
@@ -362,6 +363,31 @@ def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower,
     return out
 
 
+def measure_reference_shape(dev, n=128, group=128, reps=4):
+    """The reference's OWN per-image loop shape (inference.py:163, 248-293; genFeat.py:201): 224 x 224 crops -> 75 x 75
+    lattice of ~2 200 masked pixels, 12-D f32 descriptors, 80 000 keys, 500 P3P hypotheses, through
+    sequence.register_crops (one K1 launch + one filter / RANSAC chain per group of crops).  Untimed region; not `value`."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence, synth
+    cb = synth.crop_batch(dev, n)
+    cams = np.broadcast_to(cb["Kc"], (n, 3, 3))
+    out = {"shape": {"crop": 224, "lattice": cb["S1"], "masked_pixels_mean": float(np.mean(cb["counts"])), "D": cb["D"],
+                     "N": int(cb["keys"].shape[0]), "itr": 500, "crops_per_group": group}, "unit": "images/s"}
+    for label, model in (("f32_exact", sequence.SequenceModel(keys=cb["keys"], pts=cb["pts"])),
+                         ("bf16", sequence.SequenceModel(keys=cb["keys"].bfloat16(), pts=cb["pts"], log2_queries=True))):
+        kw = dict(n_feat=cb["D"], down_sample=cb["ds"], itr=500, seeds=list(range(n)), refine_iters=6, group=group)
+        res, _ = sequence.register_crops(model, cb["feats"], cb["masks"], cams, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            res, _ = sequence.register_crops(model, cb["feats"], cb["masks"], cams, **kw)
+        torch.cuda.synchronize()
+        out[label] = reps * n / (time.perf_counter() - t0)
+        errs = [synth.rot_angle(res[i].pose.cpu().numpy()[:, :3], cb["R"][i]) for i in range(n) if int(res[i].status.item())]
+        out[label + "_registered"] = len(errs)
+        out[label + "_median_rot_err_rad"] = float(np.median(errs)) if errs else None
+    return out
+
+
 def measure_estimate_pose(dev, reps=5):
     """The other per-image path (poseEstSurf.py:11-261) at the reference's own size — a 224 x 224
     crop, 12-D descriptors, 80 000 surface points, 10 000 samples, <= 1 000 scored poses: wall time per call of the
@@ -391,6 +417,17 @@ def measure_estimate_pose(dev, reps=5):
             else:
                 out[f"routes_bit_identical_avg_queries_{str(avg).lower()}"] = bool(
                     all(torch.equal(x, y) if torch.is_tensor(x) else np.array_equal(x, y) for x, y in zip(ref[avg], res)))
+    B = 32                              # a block of crops (the reference's loop over frames): estimate_poses
+    ml, q = a[0][None].expand(B, -1, -1).contiguous(), a[1][None].expand(B, -1, -1, -1).contiguous()
+    for avg in (True, False):
+        kw = dict(max_poses=10000, max_pose_evaluations=1000, avg_queries=avg)
+        pes.estimate_poses(ml, q, a[2], a[3], a[4], a[5], a[6], n_streams=2, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            pes.estimate_poses(ml, q, a[2], a[3], a[4], a[5], a[6], n_streams=2, **kw)
+        torch.cuda.synchronize()
+        out[f"block_of_{B}_ms_per_image_avg_queries_{str(avg).lower()}"] = (time.perf_counter() - t0) / (2 * B) * 1e3
     return out
 
 
@@ -655,6 +692,10 @@ def main():
                 line["estimate_pose"] = measure_estimate_pose(dev)
             except Exception as e:
                 line["estimate_pose"] = {"error": repr(e)}
+            try:
+                line["reference_shape"] = measure_reference_shape(dev)
+            except Exception as e:
+                line["reference_shape"] = {"error": repr(e)}
         if not args.no_parity_check and args.ablate != "noverify":
             try:
                 line["parity_check"] = parity_check(args, model, Q_all[0], keys, pts, last, R_gt, t_gt, upper, lower, cad)

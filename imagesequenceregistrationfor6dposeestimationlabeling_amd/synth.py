@@ -174,3 +174,43 @@ def crop_scene(seed=7, r=224, e=12, m=80000, f=700.0):
     return dict(pts=pts, normals=nrm, keys=keys, R=R, t=t, K=K, mask_lgts=mask_lgts, query=query,
                 diameter=diameter(pts), r=r, e=e, m=m)
 
+
+def crop_batch(dev, n=128, seed=0, N=80000, D=12, H=224, ds=3, f=600.0):
+    """n crops at the reference's own per-image shape (inference.py:163, 248-293; genFeat.py:201): network outputs
+    (n, H, H, D + 1) f32 on the device whose every ds-th pixel inside the object mask carries the (noisy, 25 % wrong) key of the
+    surface point that projects there, masks (n, H, H, 3) u8, the crop camera, the true poses.  Returns a dict; tensors on dev."""
+    import torch
+    rng = np.random.default_rng(seed)
+    S1 = (H + ds - 1) // ds
+    pts = tless_like(rng, N)
+    keys = unit_keys(rng, N, D, tau=6.0)
+    Kc = camera(S1, S1, f=f)          # the crop is cut to the object box x 1.2 (inference.py:203-206): the object fills it
+    R, t = random_poses(rng, n, t_sigma=3.0)
+    pts_d, keys_d = torch.from_numpy(pts).to(dev), torch.from_numpy(keys).to(dev)
+    g = torch.Generator(device=dev).manual_seed(seed + 1)
+    feats = torch.empty((n, H, H, D + 1), dtype=torch.float32, device=dev)
+    masks = torch.zeros((n, H, H, 3), dtype=torch.uint8, device=dev)
+    counts = []
+    Kd = torch.from_numpy(Kc).to(dev)
+    for i in range(n):
+        Rt = torch.from_numpy(np.concatenate([R[i], t[i][:, None]], 1)).to(dev)
+        Xc = pts_d.double() @ Rt[:, :3].T + Rt[:, 3]
+        p = Xc @ Kd.T
+        uv = p[:, :2] / p[:, 2:3]
+        px = torch.round(uv).long()
+        ok = (px[:, 0] >= 0) & (px[:, 0] < S1) & (px[:, 1] >= 0) & (px[:, 1] < S1) & ((uv - px).abs().max(1).values < 0.45)
+        owner = torch.full((S1 * S1,), -1, dtype=torch.long, device=dev)
+        sel = torch.nonzero(ok)[:, 0]
+        sel = sel[torch.randperm(len(sel), device=dev, generator=g)]
+        owner[px[sel, 1] * S1 + px[sel, 0]] = sel                     # one surface point per lattice pixel
+        hit = torch.nonzero(owner >= 0)[:, 0]
+        rows, cols = hit // S1, hit % S1
+        src = owner[hit]
+        wrong = torch.rand(len(src), device=dev, generator=g) < 0.25
+        src_f = torch.where(wrong, torch.randint(N, (len(src),), device=dev, generator=g), src)
+        feats[i] = 0.3 * torch.randn(H, H, D + 1, device=dev, generator=g)
+        feats[i, rows * ds, cols * ds, :D] = keys_d[src_f] + 0.2 * torch.randn(len(src), D, device=dev, generator=g)
+        masks[i, rows * ds, cols * ds] = 255
+        counts.append(len(src))
+    return dict(feats=feats, masks=masks, Kc=Kc, R=R, t=t, pts=pts_d, keys=keys_d, counts=counts, S1=S1, D=D, ds=ds)
+

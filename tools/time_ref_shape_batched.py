@@ -23,39 +23,10 @@ ap.add_argument("--once", action="store_true")
 ap.add_argument("--streams", type=int, default=1, help="1: K1 and the chains on one stream; 3: chains on side streams beside the next K1")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
-rng = np.random.default_rng(0)
-N, D, H, W, ds = 80000, 12, 224, 224, 3
-S1 = 75
-pts = synth.tless_like(rng, N)
-keys = synth.unit_keys(rng, N, D, tau=6.0)
-Kc = synth.camera(S1, S1, f=600.0)          # the crop is cut to the object box x 1.2 (inference.py:203-206): the object fills it
 n = args.distinct
-R, t = synth.random_poses(rng, n, t_sigma=3.0)
-pts_d, keys_d = torch.from_numpy(pts).to(dev), torch.from_numpy(keys).to(dev)
-g = torch.Generator(device=dev).manual_seed(1)
-feats = torch.empty((n, H, W, 13), dtype=torch.float32, device=dev)
-masks = torch.zeros((n, H, W, 3), dtype=torch.uint8, device=dev)
-counts = []
-for i in range(n):
-    Rt = torch.from_numpy(np.concatenate([R[i], t[i][:, None]], 1)).to(dev)
-    Xc = pts_d.double() @ Rt[:, :3].T + Rt[:, 3]
-    p = Xc @ torch.from_numpy(Kc).to(dev).T
-    uv = p[:, :2] / p[:, 2:3]
-    px = torch.round(uv).long()
-    ok = (px[:, 0] >= 0) & (px[:, 0] < S1) & (px[:, 1] >= 0) & (px[:, 1] < S1) & ((uv - px).abs().max(1).values < 0.45)
-    owner = torch.full((S1 * S1,), -1, dtype=torch.long, device=dev)
-    sel = torch.nonzero(ok)[:, 0]
-    sel = sel[torch.randperm(len(sel), device=dev, generator=g)]
-    owner[px[sel, 1] * S1 + px[sel, 0]] = sel                     # one surface point per lattice pixel
-    hit = torch.nonzero(owner >= 0)[:, 0]
-    rows, cols = hit // S1, hit % S1
-    src = owner[hit]
-    wrong = torch.rand(len(src), device=dev, generator=g) < 0.25
-    src_f = torch.where(wrong, torch.randint(N, (len(src),), device=dev, generator=g), src)
-    feats[i] = 0.3 * torch.randn(H, W, 13, device=dev, generator=g)
-    feats[i, rows * ds, cols * ds, :D] = keys_d[src_f] + 0.2 * torch.randn(len(src), D, device=dev, generator=g)
-    masks[i, rows * ds, cols * ds] = 255
-    counts.append(len(src))
+cb = synth.crop_batch(dev, n)
+N, D, ds, S1, Kc, R, counts = cb["keys"].shape[0], cb["D"], cb["ds"], cb["S1"], cb["Kc"], cb["R"], cb["counts"]
+feats, masks, pts_d, keys_d = cb["feats"], cb["masks"], cb["pts"], cb["keys"]
 torch.cuda.synchronize()
 print(f"{n} distinct crops, masked lattice pixels per crop: mean {np.mean(counts):.0f} (min {min(counts)}, max {max(counts)}) of {S1 * S1}; "
       f"N = {N}, D = {D}, itr = {args.itr}", flush=True)
