@@ -94,6 +94,9 @@ SIGNATURES = {
     "isr_ep_prune": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _d, _d, _d, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "isr_zbuf_score_workspace_bytes": (_sz, [_i, _i]),
     "isr_zbuf_score": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_estimate_pose_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "isr_estimate_pose": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _d, _vp, _i, _i, _i, _d, _d, _i, _i, _i, _u64,
+                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_zbuf_score_direct": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_refine_objective": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_refine_objective_full": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -1381,3 +1381,118 @@ extern "C" int isr_zbuf_score_direct(const float* obj_pts, int m, const float* R
 #define ISR_ZB_DIRECT  ISR_CHECK_LAUNCH("zbuf direct kernels");
   return ISR_OK;
 }
+
+// ------------------------------------------------------------------------------------------ the whole call
+// estimate_pose (poseEstSurf.py:11-261) as ONE entry point: pooling, the rows' log-sum-exps (K1), matrix-free sampling, P3P,
+// pruning and ordered selection, matrix-free scoring — the launches pose_est_surf.estimate_pose issues stage by stage, from
+// one host call, with every intermediate carved from `ws`.  The stream is synchronised ONCE, where the reference's Python sizes
+// its outputs: the number of surviving poses.
+namespace {
+
+struct EpLayout {
+  float *mlp, *nmlp, *mprob, *queries, *lse;
+  int32_t* k1_idx;
+  int64_t* corr_idx;
+  double* poses;
+  uint8_t* keep;
+  int32_t *keep_idx, *n_keep;
+  void *ws_prep, *ws_k1, *ws_sample;
+  size_t b_prep, b_k1, b_sample;
+};
+
+size_t ep_layout(isr::Workspace& w, int r, int e, int m, int scale, int max_poses, int avg_queries, EpLayout* L) {
+  const int res = r / scale, n = res * res;
+  const int rows = avg_queries ? n : r * r;                 // descriptor rows whose log-sum-exps K1 computes
+  L->mlp = w.take<float>(n);
+  L->nmlp = w.take<float>(n);
+  L->mprob = w.take<float>(n);
+  L->queries = w.take<float>((size_t)n * e);
+  L->lse = w.take<float>(rows);
+  L->k1_idx = w.take<int32_t>(rows);
+  L->corr_idx = w.take<int64_t>((size_t)max_poses * 4);
+  L->poses = w.take<double>((size_t)max_poses * 12);
+  L->keep = w.take<uint8_t>(max_poses);
+  L->keep_idx = w.take<int32_t>(max_poses);
+  L->n_keep = w.take<int32_t>(4);
+  L->b_prep = 2 * sizeof(float) * (size_t)n + 1024;
+  L->ws_prep = w.take<char>(L->b_prep);
+  L->b_k1 = isr_corr_argmax_workspace_bytes(rows, m, e, ISR_DTYPE_F32);
+  L->ws_k1 = w.take<char>(L->b_k1);
+  L->b_sample = isr_ep_sample_workspace_bytes(n, m);        // also covers the scorer's fallback z-buffer? no: sized below
+  L->ws_sample = w.take<char>(L->b_sample);
+  return w.off;
+}
+
+}  // namespace
+
+extern "C" size_t isr_estimate_pose_workspace_bytes(int r, int e, int m, int scale, int max_poses, int max_pose_evaluations,
+                                                    int avg_queries) {
+  if (r <= 0 || e <= 0 || m <= 0 || scale <= 0 || r / scale <= 0 || max_poses <= 0 || max_pose_evaluations <= 0) return 0;
+  isr::Workspace w(nullptr, 0);
+  EpLayout L;
+  size_t bytes = ep_layout(w, r, e, m, scale, max_poses, avg_queries, &L);
+  const size_t zb = isr_zbuf_score_workspace_bytes(max_pose_evaluations, r / scale);      // only used when the z-buffer does not fit the LDS
+  return bytes + zb + 1024;
+}
+
+extern "C" int isr_estimate_pose(const float* mask_lgts, const float* query_img, int r, int e, const float* obj_pts,
+                                 const double* obj_normals, const float* obj_keys, int m, double obj_diameter,
+                                 const double* Kcam, int max_poses, int max_pose_evaluations, int down_sample_scale,
+                                 double alpha, double dist_2d_min, int max_pool, int avg_queries, int do_prune, uint64_t seed,
+                                 float* Rt32, float* pose_scores, float* mask_scores, float* coord_scores, float* dist_2d,
+                                 uint8_t* size_mask, uint8_t* normals_mask, uint8_t* solved, int32_t* n_poses_host,
+                                 int32_t* n_keep_host, void* ws, size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(mask_lgts && query_img && obj_pts && obj_normals && obj_keys && Kcam && Rt32 && pose_scores && mask_scores &&
+                  coord_scores && dist_2d && size_mask && normals_mask && solved && n_poses_host,
+              "isr_estimate_pose: null pointer");
+  ISR_REQUIRE(r > 0 && e > 0 && e <= 128 && m > 0 && down_sample_scale > 0 && r / down_sample_scale > 0 && max_poses > 0 &&
+                  max_pose_evaluations > 0 && max_pose_evaluations <= 65535,
+              "isr_estimate_pose: r=%d e=%d (<= 128) m=%d scale=%d max_poses=%d max_pose_evaluations=%d (<= 65535)", r, e, m,
+              down_sample_scale, max_poses, max_pose_evaluations);
+  const size_t need = isr_estimate_pose_workspace_bytes(r, e, m, down_sample_scale, max_poses, max_pose_evaluations, avg_queries);
+  if (!ws || ws_bytes < need) {
+    isr::set_error("isr_estimate_pose: workspace %zu < %zu", ws_bytes, need);
+    return ISR_ERR_WORKSPACE;
+  }
+  hipStream_t stream = isr::as_stream(stream_);
+  const int scale = down_sample_scale, res = r / scale, n = res * res;
+  isr::Workspace w(ws, ws_bytes);
+  EpLayout L;
+  ep_layout(w, r, e, m, scale, max_poses, avg_queries, &L);
+  void* ws_zb = w.take<char>(isr_zbuf_score_workspace_bytes(max_pose_evaluations, res));
+  const size_t b_zb = isr_zbuf_score_workspace_bytes(max_pose_evaluations, res);
+  // the camera of the pooled grid (poseEstSurf.py:42-45)
+  double Ks[9];
+  for (int i = 0; i < 9; ++i) Ks[i] = Kcam[i];
+  Ks[2] += 0.5; Ks[5] += 0.5;
+  for (int i = 0; i < 6; ++i) Ks[i] /= (double)scale;
+  Ks[2] -= 0.5; Ks[5] -= 0.5;
+  int rc = isr_ep_prepare(mask_lgts, query_img, r, e, scale, max_pool, L.mlp, L.nmlp, L.mprob, L.queries, L.ws_prep, L.b_prep, stream_);
+  if (rc != ISR_OK) return rc;
+  // descriptor grid: pooled queries (win 1) or the crop's own pixels (win = scale)
+  const float* qgrid = avg_queries ? L.queries : query_img;
+  const int rows = avg_queries ? n : r * r, pitch = avg_queries ? res : r, win = avg_queries ? 1 : scale;
+  rc = isr_corr_argmax(qgrid, obj_keys, rows, m, e, e, e, ISR_DTYPE_F32, L.k1_idx, nullptr, L.lse, L.ws_k1, L.b_k1, stream_);
+  if (rc != ISR_OK) return rc;
+  rc = isr_ep_sample_direct(qgrid, L.lse, pitch, e, win, res, L.mprob, obj_keys, m, alpha, max_poses, seed, L.corr_idx, L.ws_sample,
+                            L.b_sample, stream_);
+  if (rc != ISR_OK) return rc;
+  rc = isr_ep_p3p(L.corr_idx, res, m, obj_pts, Ks, max_poses, seed, L.poses, solved, stream_);
+  if (rc != ISR_OK) return rc;
+  rc = isr_ep_prune(L.corr_idx, L.poses, solved, obj_pts, obj_normals, max_poses, res, m, Ks[0], obj_diameter, dist_2d_min, do_prune,
+                    max_pose_evaluations, dist_2d, size_mask, normals_mask, L.keep, L.keep_idx, L.n_keep, Rt32, stream_);
+  if (rc != ISR_OK) return rc;
+  int32_t n_keep = 0;
+  ISR_CHECK_HIP(hipMemcpyAsync(&n_keep, L.n_keep, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  ISR_CHECK_HIP(hipStreamSynchronize(stream));                 // the one round trip: it sizes the outputs
+  const int n_poses = n_keep < max_pose_evaluations ? n_keep : max_pose_evaluations;
+  *n_poses_host = n_poses;
+  if (n_keep_host) *n_keep_host = n_keep;
+  if (n_poses > 0) {
+    rc = isr_zbuf_score_direct(obj_pts, m, Rt32, n_poses, Ks, res, L.mlp, L.nmlp, qgrid, L.lse, pitch, e, win, max_pool, obj_keys,
+                               pose_scores, mask_scores, coord_scores, ws_zb, b_zb, stream_);
+    if (rc != ISR_OK) return rc;
+  }
+  return ISR_OK;
+}
+

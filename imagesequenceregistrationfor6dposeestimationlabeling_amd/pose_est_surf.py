@@ -361,11 +361,56 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     materialize=False (default): the (n, m) correspondence matrices of :70-107 are never formed — the sampler and the
     scorer compute the elements they need from the descriptors (DescriptorGrid); True: the round-2/3 route through the
     arrays (corr_matrices / patch_corr + pool_corr).  Both return the same bits."""
+    if not materialize and poses is None and not returnPoints and not visualize:
+        return _estimate_pose_one_call(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses,
+                                       max_pose_evaluations, down_sample_scale, alpha, dist_2d_min, max_pool, avg_queries,
+                                       do_prune, debug, seed)
     call = _Call(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses, max_pose_evaluations,
                  down_sample_scale, alpha, dist_2d_min, pnp_method, pose_batch_size, max_pool, avg_queries, do_prune, visualize,
                  poses, debug, returnPoints, seed=seed, materialize=materialize)
     call.front()
     return call.back(None if call.nk_d is None else int(call.nk_d.item()))     # the one host round trip: it sizes the outputs
+
+
+def _estimate_pose_one_call(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses, max_eval, scale,
+                            alpha, dist_2d_min, max_pool, avg_queries, do_prune, debug, seed):
+    """isr_estimate_pose: the stages of the matrix-free route issued by ONE library call (the same launches in the same
+    order — the same bits as the stage-by-stage composition), one read-back for the per-sample arrays."""
+    mask_lgts, query_img = _dev(mask_lgts, torch.float32).contiguous(), _dev(query_img, torch.float32).contiguous()
+    dev = mask_lgts.device
+    pts, keys = _dev(obj_pts, torch.float32).contiguous(), _dev(obj_keys, torch.float32).contiguous()
+    normals = (obj_normals.to(dev, torch.float64) if torch.is_tensor(obj_normals)
+               else _dev(np.asarray(obj_normals, np.float64))).contiguous()
+    r, e, m, S = mask_lgts.shape[0], query_img.shape[-1], keys.shape[0], int(max_poses)
+    if mask_lgts.shape != (r, r) or query_img.shape != (r, r, e) or keys.shape[1] != e or pts.shape != (m, 3) or normals.shape != (m, 3):
+        raise ValueError(f"estimate_pose: mask_lgts {tuple(mask_lgts.shape)} query_img {tuple(query_img.shape)} obj_pts "
+                         f"{tuple(pts.shape)} obj_normals {tuple(normals.shape)} obj_keys {tuple(keys.shape)}")
+    L = lib()
+    f32 = torch.empty(max_eval * 15, dtype=torch.float32, device=dev)          # Rt32 (max_eval, 12) | three score vectors
+    Rt32 = f32[:max_eval * 12].view(max_eval, 3, 4)
+    ps, ms, cs = (f32[max_eval * (12 + i):max_eval * (13 + i)] for i in range(3))
+    per = torch.empty(S * 7, dtype=torch.uint8, device=dev)                    # dist_2d (S) f32 | size | normals | solved (S) u8
+    ws = ops.workspace(dev, L.isr_estimate_pose_workspace_bytes(r, e, m, int(scale), S, int(max_eval), int(bool(avg_queries))),
+                       "estimate_pose")
+    keep, kp = _kptr(np.asarray(K, np.float64))
+    n_poses, n_keep = ctypes.c_int32(0), ctypes.c_int32(0)
+    base = per.data_ptr()
+    with torch.cuda.device(dev):
+        rc = L.isr_estimate_pose(ptr(mask_lgts), ptr(query_img), r, e, ptr(pts), ptr(normals), ptr(keys), m, float(obj_diameter), kp,
+                                 S, int(max_eval), int(scale), float(alpha), float(dist_2d_min), int(bool(max_pool)),
+                                 int(bool(avg_queries)), int(bool(do_prune)), seed & 0xFFFFFFFFFFFFFFFF, ptr(Rt32), ptr(ps), ptr(ms),
+                                 ptr(cs), base, base + 4 * S, base + 5 * S, base + 6 * S, ctypes.byref(n_poses),
+                                 ctypes.byref(n_keep), ptr(ws), ws.numel(), current_stream(dev))
+    check(rc, "isr_estimate_pose")
+    n = n_poses.value
+    if debug:
+        print('n_poses', n)
+    host = per.cpu().numpy()
+    pmask = host[6 * S:7 * S].astype(bool)                                      # one entry per SOLVED sample (:145), in order
+    dist_2d = host[:4 * S].view(np.float32)[pmask]
+    size_mask, normals_mask = host[4 * S:5 * S].astype(bool)[pmask], host[5 * S:6 * S].astype(bool)[pmask]
+    R, t = Rt32[:n, :, :3].contiguous(), Rt32[:n, :, 3].contiguous()
+    return R, t, ps[:n].clone(), ms[:n].clone(), cs[:n].clone(), dist_2d, size_mask, normals_mask
 
 
 def estimate_poses(mask_lgts, query_imgs, obj_pts, obj_normals, obj_keys, obj_diameter, Ks, *, seeds=None, n_streams=4,

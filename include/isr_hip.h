@@ -364,6 +364,24 @@ int isr_zbuf_score_direct(const float* obj_pts, int m, const float* Rt, int B, c
                           float* pose_score, float* mask_score, float* coord_score, void* ws, size_t ws_bytes,
                           isr_stream_t stream);
 
+/* The whole of estimate_pose(poses=None) as ONE call (matrix-free route): the launches of isr_ep_prepare, isr_corr_argmax (row
+ * log-sum-exps), isr_ep_sample_direct, isr_ep_p3p, isr_ep_prune and isr_zbuf_score_direct, intermediates carved from ws.
+ * Inputs on the device except Kcam (host, 9 doubles, the UNSCALED crop camera: the (K + .5)/scale - .5 of :42-45 is applied
+ * here); obj_normals (m,3) f64.  Outputs on the device: Rt32 (max_pose_evaluations, 12) f32 [R|t] of the scored poses,
+ * pose / mask / coord scores (max_pose_evaluations), and per SAMPLE (max_poses each) dist_2d f32, size_mask, normals_mask,
+ * solved u8 (the reference's returned arrays are the entries with solved = 1, in order).  *n_poses_host = how many poses were
+ * scored (rows of Rt32 / scores that are valid), *n_keep_host (nullable) = how many samples survived the pruning.  The stream
+ * is synchronised once (the survivor count sizes the scoring launch).  Same bits as the stage entry points in sequence. */
+size_t isr_estimate_pose_workspace_bytes(int r, int e, int m, int scale, int max_poses, int max_pose_evaluations,
+                                         int avg_queries);
+int isr_estimate_pose(const float* mask_lgts, const float* query_img, int r, int e, const float* obj_pts,
+                      const double* obj_normals, const float* obj_keys, int m, double obj_diameter, const double* Kcam,
+                      int max_poses, int max_pose_evaluations, int down_sample_scale, double alpha, double dist_2d_min,
+                      int max_pool, int avg_queries, int do_prune, uint64_t seed, float* Rt32, float* pose_scores,
+                      float* mask_scores, float* coord_scores, float* dist_2d, uint8_t* size_mask, uint8_t* normals_mask,
+                      uint8_t* solved, int32_t* n_poses_host, int32_t* n_keep_host, void* ws, size_t ws_bytes,
+                      isr_stream_t stream);
+
 /* a16  refine_pose objective   pose_refine.py:58-91
  * out4 (device, 4 f64) = { score, d score / d t (3) } with
  *   score = -( mean_i <keys_i, bilinear(query_img, p_i)> - mean_i bilinear(denom_img, p_i) ) / 2,
