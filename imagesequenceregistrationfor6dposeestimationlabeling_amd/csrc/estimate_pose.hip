@@ -1378,7 +1378,15 @@ extern "C" int isr_zbuf_score_direct(const float* obj_pts, int m, const float* R
   unsigned long long* zbuf = w.take<unsigned long long>((size_t)B * n);
   ISR_CHECK_HIP(hipMemsetAsync(zbuf, 0xFF, sizeof(unsigned long long) * (size_t)B * n, stream));
   zbuf_project_kernel<<<dim3((m + 255) / 256, B), 256, 0, stream>>>(obj_pts, m, Rt, B, K, res, zbuf);
-#define ISR_ZB_DIRECT  ISR_CHECK_LAUNCH("zbuf direct kernels");
+#define ISR_ZB_DIRECT(DPv)                                                                                                    \
+  zbuf_score_direct_kernel<DPv><<<B, 256, 0, stream>>>(zbuf, res, m, mask_log_prob, neg_mask_log_prob, qgrid, lse_grid, g_pitch, e, \
+                                                       win, pool ? 1 : 0, keys, pose_score, mask_score, coord_score)
+  if (e <= 16) ISR_ZB_DIRECT(16);
+  else if (e <= 32) ISR_ZB_DIRECT(32);
+  else if (e <= 64) ISR_ZB_DIRECT(64);
+  else ISR_ZB_DIRECT(128);
+#undef ISR_ZB_DIRECT
+  ISR_CHECK_LAUNCH("zbuf direct kernels");
   return ISR_OK;
 }
 
