@@ -422,6 +422,7 @@ def test_sampler_weights_vs_numpy_exp(cuda0):
 
 @pytest.mark.parametrize("avg_queries", [True, False])
 @pytest.mark.parametrize("shape", [(96, 12, 3000, 3), (50, 12, 1337, 3), (64, 20, 700, 2), (40, 7, 513, 1),
+                                   (48, 40, 300, 2), (36, 100, 200, 1),      # 64- and 128-channel instantiations
                                    (200, 12, 900, 2),      # res 100: the pose's z-buffer needs 100 KB of LDS (> the 64 KB default)
                                    (250, 12, 600, 2)])     # res 125: beyond the LDS budget -> the global z-buffer kernels
 def test_matrix_free_stages_equal_the_materialised_ones(cuda0, avg_queries, shape):
