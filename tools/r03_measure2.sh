@@ -1,0 +1,14 @@
+# final measurements of round 3 (second half): python suite, smoke, bench variants, rocprof of the bench.   bash tools/r03_measure2.sh
+set -o pipefail
+python -m pytest tests -m gpu -q > gpurun_out/t_final.log 2>&1; tail -3 gpurun_out/t_final.log
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_final.log 2>&1; tail -1 gpurun_out/smoke_final.log
+python bench.py --steps 20 > gpurun_out/r03b_bench_n1.json 2> gpurun_out/r03b_bench_n1.err && tail -c 200 gpurun_out/r03b_bench_n1.json
+python bench.py --steps 10 --verify vote --no-estimate-pose > gpurun_out/r03b_bench_vote.json 2> gpurun_out/r03b_bench_vote.err
+python bench.py --steps 10 --keys 50000 --itr 4096 --no-cpu-baseline --no-estimate-pose > gpurun_out/r03b_bench_50k.json 2> gpurun_out/r03b_bench_50k.err
+ISR_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 4 --images 16 --no-cpu-baseline --no-estimate-pose > gpurun_out/r03b_bench_gloo2.json 2> gpurun_out/r03b_bench_gloo2.err
+ISR_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29521 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 python bench.py --steps 6 --no-cpu-baseline --no-estimate-pose > gpurun_out/r03b_bench_rccl1.json 2> gpurun_out/r03b_bench_rccl1.err
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03b_prof_bench -o b -- python3 $R/bench.py --steps 16 --no-cpu-baseline --no-parity-check --no-estimate-pose > $R/gpurun_out/r03b_bench_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/r03b_prof_crops -o crops -- python3 $R/tools/time_ref_shape_batched.py --once --dtype f32 --batch 128 > /dev/null 2>&1
+ls $R/gpurun_out/r03b_prof_bench $R/gpurun_out/r03b_prof_crops
