@@ -477,9 +477,11 @@ __global__ __launch_bounds__(kThreads) void corr_f32_kernel(
 //     Q' = [q1 | q1 | q2 | q2 | q1 | q3 | 0 | 0]     K' = [k1 | k2 | k1 | k2 | k3 | k1 | 0 | 0]      (blocks of 16, D <= 16)
 // with products exact in f32 and f32 accumulation: logits to f32 accuracy (the dropped pairs are 2^-24 relative) from
 // corr_bf16_direct_kernel<8> at its D = 128 rate — with the queries pre-multiplied by log2 e, the log2-domain kernel.
-// Indices stay EXACT: the margin test's error bound also covers the dropped pairs, the rounding of q log2 e and the rounding
-// of the f32 chain itself (together < 3.3 x 2^-23 sqrt(|q'|^2 |k'|^2): the key-norm bound is inflated by 1.08), and what it
-// cannot certify goes to corr_recheck_kernel, which decides by the f32 fmaf chain of the ORIGINAL rows — the logit
+// Indices stay EXACT: the margin test's error bound also covers, in units of 2^-24 |q log2 e| |k|, the dropped pairs q2k3, q3k2,
+// q3k3 and the last-bit residuals of the two three-way splits (<= 4), the rounding of q log2 e (<= 1) and the rounding of the
+// f32 chain itself (<= D <= 16): 21 x 2^-24 |q~||k| <= 3.6 x 2^-23 sqrt(|q'|^2 |k'|^2) since |q'||k'| >= 2.97 |q~||k| — the
+// bound (D' + 2) 2^-23 sqrt(|q'|^2 |k'|^2) with D' = 128 grows by 2.8 %, the key-norm term is inflated by 1.08 (3.9 %) — and
+// what it cannot certify goes to corr_recheck_kernel, which decides by the f32 fmaf chain of the ORIGINAL rows — the logit
 // corr_f32_kernel and the oracle compute — lowest key on ties.  logp / lse come from the split logits (a few 1e-7 of the
 // chain's).  A query's result depends on (query, keys) only, as on every path.
 __device__ __forceinline__ uint16_t bf16_rne(float x, float* rem) {

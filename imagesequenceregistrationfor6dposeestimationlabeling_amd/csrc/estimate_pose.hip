@@ -1426,7 +1426,7 @@ size_t ep_layout(isr::Workspace& w, int r, int e, int m, int scale, int max_pose
   L->ws_prep = w.take<char>(L->b_prep);
   L->b_k1 = isr_corr_argmax_workspace_bytes(rows, m, e, ISR_DTYPE_F32);
   L->ws_k1 = w.take<char>(L->b_k1);
-  L->b_sample = isr_ep_sample_workspace_bytes(n, m);        // also covers the scorer's fallback z-buffer? no: sized below
+  L->b_sample = isr_ep_sample_workspace_bytes(n, m);
   L->ws_sample = w.take<char>(L->b_sample);
   return w.off;
 }
