@@ -1,6 +1,8 @@
 #!/bin/bash
-# SQ counters of corr_f32_kernel at the crop-batch shape: bash tools/pmc_f32.sh <outdir>
-out=${1:-gpurun_out/pmc_f32}; R=$GRAFT_REPO_ROOT
+# SQ counters of the exact-f32 K1 at the crop-batch shape: bash tools/pmc_f32.sh <outdir> [kernel-name substring]
+# (default substring: corr_bf16_direct_kernel<8 — the split route, which tools/time_corr_f32.py takes by default; corr_f32_kernel with
+# ISR_TUNE_K1_F32_CHAIN: run round 3's first half, profiles/r03_k1_f32_pmc.txt)
+out=${1:-gpurun_out/pmc_f32}; R=$GRAFT_REPO_ROOT; export ISR_PMC_KERNEL=${2:-corr_bf16_direct_kernel<8}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/$out
 pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$R/$out/$name" -- python3 $R/tools/time_corr_f32.py > "$R/$out/$name.log" 2>&1; }
@@ -9,12 +11,13 @@ pass sq2 SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_
 pass sq3 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_LEVEL_WAVES SQ_INSTS_VMEM
 cd $R
 python3 - "$out" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, os
 out = sys.argv[1]
+kern = os.environ.get("ISR_PMC_KERNEL", "corr_f32_kernel")
 agg = collections.defaultdict(list)
 for f in glob.glob(out + "/*/*/*counter_collection.csv") + glob.glob(out + "/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "corr_f32_kernel" in r["Kernel_Name"]:
+        if kern in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 m = {c: sum(v) / len(v) for c, v in agg.items()}
 with open(out + "/summary.txt", "w") as g:
