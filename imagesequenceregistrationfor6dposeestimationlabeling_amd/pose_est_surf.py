@@ -422,6 +422,10 @@ def estimate_poses(mask_lgts, query_imgs, obj_pts, obj_normals, obj_keys, obj_di
     another's, and ONE host round trip for all the survivor counts instead of one per image.  Returns a list of B tuples."""
     mask_lgts, query_imgs = _dev(mask_lgts, torch.float32), _dev(query_imgs, torch.float32)
     B = mask_lgts.shape[0]
+    if mask_lgts.ndim != 3 or query_imgs.ndim != 4 or query_imgs.shape[0] != B:
+        raise ValueError(f"estimate_poses: mask_lgts {tuple(mask_lgts.shape)} / query_imgs {tuple(query_imgs.shape)} must be (B,r,r) / (B,r,r,e)")
+    if B == 0:
+        return []
     dev = mask_lgts.device
     obj_pts_d, obj_keys_d = _dev(obj_pts, torch.float32).contiguous(), _dev(obj_keys, torch.float32).contiguous()
     normals_d = (obj_normals.to(dev, torch.float64) if torch.is_tensor(obj_normals) else _dev(np.asarray(obj_normals, np.float64)))

@@ -503,3 +503,6 @@ def test_estimate_poses_block_equals_per_image_calls(cuda0, avg_queries):
             assert (torch.equal(x, y) if torch.is_tensor(x) else np.array_equal(x, y))
         counts.append(one[0].shape[0])
     assert len(set(counts)) > 1 and max(counts) > 50
+    assert pes.estimate_poses(ml[:0], q[:0], pts, nrm, keys, base["diameter"], Ks[:0], **kw) == []
+    with pytest.raises(ValueError):
+        pes.estimate_poses(ml[0], q, pts, nrm, keys, base["diameter"], Ks, **kw)
