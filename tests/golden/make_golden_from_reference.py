@@ -24,11 +24,15 @@ reference text is stored.
 Not reproducible this way (cv2 / open3d / torch_scatter are absent and must not be stood in for):
 pnp (inference.py:123-134), estimate_pose's P3P loop and batch_score (poseEstSurf.py:133-237),
 Chamfer / ICP (verfication.py:97-101, icp.py:96-117) — those stay "parity unpinned" (DESIGN.md §2).
+  ref_vote.npz           (`vote` argument) the n x n relative-pose table choosePose.py:98-107 and the ADD-S vote :121-145
 
 Run from the repo root:  python tests/golden/make_golden_from_reference.py
 """
 import ast
+import contextlib
+import io
 import sys
+import types
 from pathlib import Path
 
 import numpy as np
@@ -234,6 +238,50 @@ def main():
     print("wrote", sorted(p.name for p in OUT.glob("ref_*.npz")))
 
 
+def vote():
+    """choosePose.py:98-107 (the n x n table of relative poses) and :121-145 (the ADD-S vote, its argmax and the ranking
+    written to top_50_choices.txt) executed from the reference's own statements on a small sequence: predicted poses are
+    the ground truth with errors of graded size, so that some entries agree and some do not, and two rows tie."""
+    rng = np.random.default_rng(20261005)
+    base = {"torch": torch, "np": np, "F": F, "KDTree": KDTree}
+    ns = dict(base)
+    ref_function("choosePose.py", "compute_rel_poses", ns)
+    ref_function("choosePose.py", "ADDS", ns)
+    table = ref_statements("choosePose.py", 98, 107, ("compute_rel_poses", "transformation_matrix", "relative_poses"))
+    loop = ref_statements("choosePose.py", 121, 138, ("final_error", "0.1 * diameter", "agreed_poses"))
+    pick = ref_statements("choosePose.py", 144, 145, ("np.argmax", "np.argsort"))
+    n = 7
+    verts = rng.normal(size=(250, 3)) * [40, 25, 15]
+    surf = (rng.normal(size=(600, 3)) * [40, 25, 15]).astype(np.float32).astype(np.float64)
+    diameter = float(np.linalg.norm(verts.max(0) - verts.min(0)))
+    Rg = np.array([random_rotation(rng) for _ in range(n)])
+    tg = rng.normal(size=(n, 3)) * 40 + [0, 0, 700]
+    Rp, tp = Rg.copy(), tg.copy()
+    for i, (deg, mm) in enumerate([(0.2, 0.5), (0.3, 1.0), (14.0, 22.0), (0.2, 120.0), (70.0, 75.0), (0.4, 0.8), (0.1, 0.3)]):
+        w = rng.normal(size=3); w *= np.deg2rad(deg) / np.linalg.norm(w)
+        Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        th = np.linalg.norm(w)
+        Rp[i] = (np.eye(3) + np.sin(th) / th * Wx + (1 - np.cos(th)) / th ** 2 * Wx @ Wx) @ Rg[i]
+        d = rng.normal(size=3); tp[i] = tg[i] + mm * d / np.linalg.norm(d)
+    out = {}
+    for tag, (RL, TL) in (("gt", (Rg, tg)), ("pred", (Rp, tp))):
+        ns.update(RList=list(RL), TList=list(TL))
+        with contextlib.redirect_stdout(io.StringIO()):
+            exec(table, ns)
+        out[tag] = np.array(ns["relative_poses"])
+    ns.update(pred_rel_poses=out["pred"], gt_rel_poses=out["gt"], modelVerts=verts, surfacePointsScaled=surf,
+              diameter=diameter, args=types.SimpleNamespace(dataset="tless"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(loop, ns)
+        exec(pick, ns)
+    err = np.array(ns["error"])
+    assert 0 < err.sum() < err.size and len(set(err.sum(1).tolist())) < n, "the case must discriminate and hold a tie"
+    np.savez_compressed(OUT / "ref_vote.npz", verts=verts, surface=surf, diameter=diameter, R_gt=Rg, t_gt=tg, R_pred=Rp, t_pred=tp,
+                        gt_rel=out["gt"], pred_rel=out["pred"], error=err, agreed=np.array(ns["agreed_poses"]),
+                        image_id=int(ns["image_id"]), top_indices=np.array(ns["top_indices"]))
+    print("wrote ref_vote.npz: agreed", int(err.sum()), "of", err.size, "image_id", int(ns["image_id"]), "row sums", err.sum(1).tolist())
+
+
 def refine_modes():
     """refine_pose's objective with interpolation = 'nearest' / 'bicubic' (pose_refine.py:60-68 forwards `mode=` to
     F.grid_sample): the reference's own `sample` + objective statements executed under autograd.  Own RNG stream, so the
@@ -272,6 +320,8 @@ def refine_modes():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "vote":
+        sys.exit(vote())
     if len(sys.argv) > 1 and sys.argv[1] == "refine_modes":
         sys.exit(refine_modes())
     sys.exit(main())

@@ -138,3 +138,19 @@ def test_refine_objective_modes_vs_reference_statements(cuda0, mode):
     with pytest.raises(ValueError):
         pose_refine.RefineObjective(torch.from_numpy(g["X"]).to(cuda0), torch.from_numpy(g["keys"]).to(cuda0), q, den,
                                     g["K_crop"], g["R"], interpolation="lanczos")
+
+
+def test_vote_vs_reference_statements(cuda0):
+    """a10 / a11 on the device against choosePose.py:98-107, :121-145 executed from the reference (ref_vote.npz): the two
+    relative-pose tables, every entry of the n x n error matrix, the chosen image (ties -> the first, as np.argmax) and a top
+    list with the reference's vote counts in the reference's order."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration as reg, sequence
+    g = np.load(G / "ref_vote.npz")
+    reg.set_surface_points(g["surface"])
+    err, adds = reg.vote_error_rows(g["verts"], g["surface"], g["gt_rel"], g["pred_rel"], float(g["diameter"]))
+    assert np.array_equal(err, g["error"])
+    image_id, top, rows = sequence.vote_choose_image(g["verts"], g["surface"], g["R_gt"], g["t_gt"], g["R_pred"], g["t_pred"],
+                                                     float(g["diameter"]))
+    assert image_id == int(g["image_id"]) and np.array_equal(rows, g["error"])
+    sums = g["error"].sum(1)
+    assert np.array_equal(sums[np.asarray(top)], sums[g["top_indices"]])

@@ -132,3 +132,22 @@ def test_refine_objective_modes_match_reference_statements(mode):
                                  dtype=torch.float64)
         assert abs(v64 - s) <= 2e-6 * max(1.0, abs(s))
         np.testing.assert_allclose(g64, gr, rtol=1e-3, atol=5e-2 if mode == "bicubic" else 1e-7)
+
+
+def test_vote_oracle_matches_reference_statements():
+    """choosePose.py:98-107 and :121-145 executed from the reference (ref_vote.npz): the oracle's relative-pose tables, its
+    error matrix, the chosen image and the top list — a case where some pose pairs agree and some do not, with tied rows
+    (np.argmax keeps the first; the reference's argsort order is reproduced for the untied positions and, as a set, for ties)."""
+    g = np.load(G / "ref_vote.npz")
+    gt = ro.rel_pose_table(list(g["R_gt"]), list(g["t_gt"]))
+    pr = ro.rel_pose_table(list(g["R_pred"]), list(g["t_pred"]))
+    np.testing.assert_allclose(gt, g["gt_rel"], atol=1e-12)
+    np.testing.assert_allclose(pr, g["pred_rel"], atol=1e-12)
+    err, adds = ro.vote(g["verts"], g["surface"], g["gt_rel"], g["pred_rel"], float(g["diameter"]))
+    assert np.array_equal(err, g["error"]) and 0 < err.sum() < err.size
+    assert np.array_equal(np.argwhere(err == 1), g["agreed"])
+    sums = err.sum(1)
+    assert int(np.argmax(sums)) == int(g["image_id"])
+    top = g["top_indices"]
+    assert np.array_equal(sums[top], np.sort(sums)[::-1])                       # the reference's list is ordered by votes
+    assert sorted(top.tolist()) == list(range(len(sums)))
