@@ -24,6 +24,7 @@ reference text is stored.
 Not reproducible this way (cv2 / open3d / torch_scatter are absent and must not be stood in for):
 pnp (inference.py:123-134), estimate_pose's P3P loop and batch_score (poseEstSurf.py:133-237),
 Chamfer / ICP (verfication.py:97-101, icp.py:96-117) — those stay "parity unpinned" (DESIGN.md §2).
+  ref_estimate_prune.npz (`prune` argument) poseEstSurf.py:119-121, :145, :147-177: gathers, pruning masks, ordered selection
   ref_vote.npz           (`vote` argument) the n x n relative-pose table choosePose.py:98-107 and the ADD-S vote :121-145
 
 Run from the repo root:  python tests/golden/make_golden_from_reference.py
@@ -282,6 +283,64 @@ def vote():
     print("wrote ref_vote.npz: agreed", int(err.sum()), "of", err.size, "image_id", int(ns["image_id"]), "row sums", err.sum(1).tolist())
 
 
+def prune():
+    """poseEstSurf.py:119-121 (sample indices -> pixel / surface-point / normal gathers), :145 (the solved samples) and
+    :147-177 (the three pruning masks, the pruned pose list and its truncation) executed from the reference's own statements
+    on given samples and poses (the poses themselves come out of cv2.solveP3P in the reference: here they are inputs)."""
+    rng = np.random.default_rng(20261006)
+    base = {"torch": torch, "np": np, "F": F}
+    gather = ref_statements("poseEstSurf.py", 119, 121, ("p2d_idx", "img_pts[p2d_idx]", "obj_normals["))
+    tonp = ref_statements("poseEstSurf.py", 124, 124, ("p2d.cpu().numpy()",))
+    solved = ref_statements("poseEstSurf.py", 145, 145, ("poses_mask",))
+    masks = ref_statements("poseEstSurf.py", 147, 169, ("dist_2d_min * res_sampled", "z_min", "normals_dot", "do_prune"))
+    tail = ref_statements("poseEstSurf.py", 174, 177, ("max_pose_evaluations", "n_poses"))
+    res, m, S = 24, 500, 400
+    obj_pts = (rng.normal(size=(m, 3)) * [40, 25, 15]).astype(np.float32)
+    obj_normals = obj_pts.astype(np.float64) / np.linalg.norm(obj_pts, axis=1, keepdims=True)       # f64, as normals_scaled.npy
+    K = np.array([[130.0, 0, res / 2 - 0.4], [0, 128.0, res / 2 + 0.1], [0, 0, 1]])
+    diameter = float(np.linalg.norm(obj_pts.max(0) - obj_pts.min(0)))
+    ys, xs = np.meshgrid(np.arange(res), np.arange(res), indexing="ij")
+    img_pts = torch.from_numpy(np.stack([xs.ravel(), ys.ravel()], -1))                             # (n, 2) xy, :56-59
+    R0 = random_rotation(rng)
+    t0 = np.array([3.0, -2.0, 650.0])
+    poses = np.zeros((S, 3, 4))
+    for i in range(S):
+        w = rng.normal(size=3) * 0.15
+        Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        Rq, _ = np.linalg.qr((np.eye(3) + Wx) @ R0)
+        Rq *= np.sign(np.diag(Rq.T @ R0))[None, :]
+        poses[i, :, :3] = Rq
+        poses[i, :, 3] = t0 + rng.normal(size=3) * [8, 8, 60] + (0 if i % 9 else [0, 0, rng.choice([-2000.0, 4000.0])])
+    poses_mask = rng.random(S) > 0.1
+    # samples: surface points that face the camera under R0 and their projections (+ a share of arbitrary picks)
+    cam = obj_pts.astype(np.float64) @ R0.T + t0
+    uv = cam @ K.T
+    uv = np.rint(uv[:, :2] / uv[:, 2:]).astype(np.int64)
+    vis = np.nonzero(((obj_normals @ R0.T) * cam).sum(1) < 0)[0]
+    ks = rng.choice(vis, (S, 4))
+    ks[::5] = rng.choice(m, (len(ks[::5]), 4))
+    pix = np.clip(uv[ks, 1], 0, res - 1) * res + np.clip(uv[ks, 0], 0, res - 1)
+    pix[::7, 1:3] = pix[::7, :1]                                                                   # three samples from one pixel area
+    corr_idx = torch.from_numpy(pix * m + ks)
+    out = {}
+    for tag, do_prune, max_eval in (("prune", True, 60), ("noprune", False, 25)):
+        ns = dict(base, corr_idx=corr_idx.clone(), m=m, img_pts=img_pts, obj_pts=torch.from_numpy(obj_pts), obj_normals=obj_normals,
+                  poses=poses.copy(), poses_mask=poses_mask.copy(), dist_2d_min=0.1, res_sampled=res, K=K.copy(), obj_diameter=diameter,
+                  do_prune=do_prune, max_pose_evaluations=max_eval)
+        for code in (gather, tonp, solved, masks, tail):
+            exec(code, ns)
+        out.update({f"{tag}_dist_2d": ns["dist_2d"], f"{tag}_size_mask": ns["size_mask"], f"{tag}_normals_mask": ns["normals_mask"],
+                    f"{tag}_dist_2d_mask": ns["dist_2d_mask"], f"{tag}_R": ns["R"], f"{tag}_t": ns["t"], f"{tag}_n_poses": ns["n_poses"],
+                    f"{tag}_max_eval": max_eval})
+        if do_prune:
+            out["prune_p3dCp"], out["prune_p2dCp"] = ns["p3dCp"], ns["p2dCp"]
+            kept = ns["dist_2d_mask"] & ns["size_mask"] & ns["normals_mask"]
+            assert 5 < kept.sum() < 0.8 * len(kept) and (~ns["size_mask"]).any() and (~ns["normals_mask"]).any() and (~ns["dist_2d_mask"]).any()
+    np.savez_compressed(OUT / "ref_estimate_prune.npz", res=res, m=m, obj_pts=obj_pts, obj_normals=obj_normals, K=K, diameter=diameter,
+                        corr_idx=corr_idx.numpy(), poses=poses, poses_mask=poses_mask, **out)
+    print("wrote ref_estimate_prune.npz: solved", int(poses_mask.sum()), "kept", int(out["prune_n_poses"]), "of max", 60)
+
+
 def refine_modes():
     """refine_pose's objective with interpolation = 'nearest' / 'bicubic' (pose_refine.py:60-68 forwards `mode=` to
     F.grid_sample): the reference's own `sample` + objective statements executed under autograd.  Own RNG stream, so the
@@ -322,6 +381,8 @@ def refine_modes():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "vote":
         sys.exit(vote())
+    if len(sys.argv) > 1 and sys.argv[1] == "prune":
+        sys.exit(prune())
     if len(sys.argv) > 1 and sys.argv[1] == "refine_modes":
         sys.exit(refine_modes())
     sys.exit(main())

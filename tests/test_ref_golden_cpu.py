@@ -151,3 +151,22 @@ def test_vote_oracle_matches_reference_statements():
     top = g["top_indices"]
     assert np.array_equal(sums[top], np.sort(sums)[::-1])                       # the reference's list is ordered by votes
     assert sorted(top.tolist()) == list(range(len(sums)))
+
+
+def test_prune_oracle_matches_reference_statements():
+    """poseEstSurf.py:119-121, :145, :147-177 executed from the reference (ref_estimate_prune.npz): the oracle's pruning masks
+    and pixel distances on the same samples and poses."""
+    g = np.load(G / "ref_estimate_prune.npz")
+    res, m = int(g["res"]), int(g["m"])
+    ci, pm = g["corr_idx"], g["poses_mask"]
+    p2d_idx, p3d_idx = ci // m, ci % m
+    p2d = np.stack([p2d_idx % res, p2d_idx // res], -1).astype(np.float32)[pm]
+    p3d = g["obj_pts"][p3d_idx][pm]
+    n3d = g["obj_normals"][p3d_idx[:, :3]][pm]
+    d, dm, sm, nm = epo.prune_masks(g["poses"][pm], p2d, p3d, n3d, g["K"], float(g["diameter"]), res)
+    for tag in ("prune", "noprune"):
+        assert np.array_equal(d, g[f"{tag}_dist_2d"]) and np.array_equal(dm, g[f"{tag}_dist_2d_mask"])
+        assert np.array_equal(sm, g[f"{tag}_size_mask"]) and np.array_equal(nm, g[f"{tag}_normals_mask"])
+    keep = dm & sm & nm
+    assert np.array_equal(g["poses"][pm][keep][:int(g["prune_max_eval"]), :, :3], g["prune_R"])
+    assert np.array_equal(g["poses"][pm][:int(g["noprune_max_eval"]), :, 3], g["noprune_t"])
