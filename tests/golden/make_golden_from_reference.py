@@ -24,6 +24,7 @@ reference text is stored.
 Not reproducible this way (cv2 / open3d / torch_scatter are absent and must not be stood in for):
 pnp (inference.py:123-134), estimate_pose's P3P loop and batch_score (poseEstSurf.py:133-237),
 Chamfer / ICP (verfication.py:97-101, icp.py:96-117) — those stay "parity unpinned" (DESIGN.md §2).
+  ref_assembly.npz       (`assembly` argument) inference.py:252-263, :265-280, :282-290: masked lattice pixels -> getCors -> top-80 % -> ep3d / ep2d
   ref_estimate_prune.npz (`prune` argument) poseEstSurf.py:119-121, :145, :147-177: gathers, pruning masks, ordered selection
   ref_vote.npz           (`vote` argument) the n x n relative-pose table choosePose.py:98-107 and the ADD-S vote :121-145
 
@@ -283,6 +284,46 @@ def vote():
     print("wrote ref_vote.npz: agreed", int(err.sum()), "of", err.size, "image_id", int(ns["image_id"]), "row sums", err.sum(1).tolist())
 
 
+def assembly():
+    """inference.py:252-263 (every third pixel of features and mask, the camera of the sub-sampled crop), :265-280 (masked
+    pixels, their features, getCors, the 3-D / 2-D correspondence arrays) and :282-290 (the top-80 % cut and the filtered
+    arrays handed to pnp) executed from the reference's own statements on a synthetic network output."""
+    torch.manual_seed(3)
+    rng = np.random.default_rng(20261007)
+    base = {"torch": torch, "np": np, "F": F}
+    ns0 = dict(base)
+    ref_function("inference.py", "getCors", ns0)
+    sub = ref_statements("inference.py", 252, 263, ("down_sample", "imfeats[:, ::down_sample, ::down_sample]", "camMat[:2, 2] += 0.5"))
+    corr = ref_statements("inference.py", 265, 280, ("torch.where(inputMask)", "getCors(", "ep2d[:, 0] = maskIds[1]", "ep2d[:, 0:2]"))
+    cut = ref_statements("inference.py", 282, 290, ("threshval", "nidx", "ep3d[nidx"))
+    out = {}
+    for c, (H, N, fill) in enumerate([(120, 3000, 0.55), (60, 800, 0.12)]):            # > 500 and <= 500 masked lattice pixels
+        keys = unit_rows(rng, N, 12, 5.0)
+        pts = (rng.normal(size=(N, 3)) * [40, 25, 15]).astype(np.float32).astype(np.float64)
+        nrm = pts / np.linalg.norm(pts, axis=1, keepdims=True)
+        feats = (0.4 * rng.normal(size=(1, H, H, 12))).astype(np.float32)
+        mask = np.zeros((H, H, 3), np.uint8)
+        yy, xx = np.mgrid[:H, :H]
+        blob = ((yy - H / 2) ** 2 / (0.42 * H) ** 2 + (xx - H / 2.2) ** 2 / (0.3 * H) ** 2 < 1) & (rng.random((H, H)) < fill + 0.4)
+        mask[blob] = 255
+        own = rng.integers(0, N, size=(H, H))
+        feats[0][blob] = keys[own[blob]] + 0.25 * rng.normal(size=(int(blob.sum()), 12)).astype(np.float32)
+        camMat = np.array([[1100.0, 0, H / 2 - 0.7], [0, 1090.0, H / 2 + 0.4], [0, 0, 1]])
+        ns = dict(ns0, cropMask=mask, imfeats=torch.from_numpy(feats), inputMask=torch.from_numpy(mask[:, :, 0]),
+                  camMatScaling=True, camMat=camMat.copy(), sfeats=torch.from_numpy(keys), surfacePointsScaled=pts, n2Scaled=nrm)
+        for code in (sub, corr, cut):
+            exec(code, ns)
+        n_masked = len(ns["in1"])
+        assert (n_masked > 500) == (c == 0), n_masked
+        out.update({f"feats{c}": feats, f"mask{c}": mask, f"keys{c}": keys, f"pts{c}": pts, f"camMat_in{c}": camMat,
+                    f"camMat{c}": ns["camMat"], f"maskedfeats{c}": ns["maskedfeats"].numpy(), f"idx1_{c}": ns["idx1"].numpy(),
+                    f"in1_{c}": ns["in1"].numpy(), f"X1_{c}": ns["X1"], f"Y1_{c}": ns["Y1"], f"nidx{c}": ns["nidx"],
+                    f"ep3d{c}": ns["ep3d"], f"ep2d{c}": ns["ep2d"], f"n3d{c}": np.asarray(ns["n3d"])})
+        print("case", c, "masked", n_masked, "kept", len(ns["nidx"]))
+    np.savez_compressed(OUT / "ref_assembly.npz", n_cases=2, **out)
+    print("wrote ref_assembly.npz")
+
+
 def prune():
     """poseEstSurf.py:119-121 (sample indices -> pixel / surface-point / normal gathers), :145 (the solved samples) and
     :147-177 (the three pruning masks, the pruned pose list and its truncation) executed from the reference's own statements
@@ -383,6 +424,8 @@ if __name__ == "__main__":
         sys.exit(vote())
     if len(sys.argv) > 1 and sys.argv[1] == "prune":
         sys.exit(prune())
+    if len(sys.argv) > 1 and sys.argv[1] == "assembly":
+        sys.exit(assembly())
     if len(sys.argv) > 1 and sys.argv[1] == "refine_modes":
         sys.exit(refine_modes())
     sys.exit(main())

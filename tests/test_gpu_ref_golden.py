@@ -186,3 +186,35 @@ def test_prune_vs_reference_statements(cuda0):
             cik = ci[kept]
             p2 = torch.stack([(cik // m) % res, (cik // m) // res], dim=-1).float().cpu().numpy()
             assert np.array_equal(p2, g["prune_p2dCp"]) and np.array_equal(pts[cik % m].cpu().numpy(), g["prune_p3dCp"])
+
+
+def test_masked_queries_getcors_filter_assembly_vs_reference_statements(cuda0):
+    """The per-image front of inference.py on the device against its statements :252-263, :265-280, :282-290 executed from the
+    reference (ref_assembly.npz): every third pixel of the network output under the mask in the reference's order
+    (masked_queries / isr_prep_queries), getCors' indices (exact f32 path, 12 channels: the split route), the top-80 % cut on
+    the reference's own values, and the 3-D / 2-D arrays handed to pnp — both branches of the 500-correspondence rule."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, registration as reg, sequence
+    g = np.load(G / "ref_assembly.npz")
+    for c in range(int(g["n_cases"])):
+        feats = torch.from_numpy(g[f"feats{c}"]).to(cuda0)
+        mask = g[f"mask{c}"]
+        keys, pts = torch.from_numpy(g[f"keys{c}"]).to(cuda0), torch.from_numpy(g[f"pts{c}"]).to(cuda0)
+        mf, ep2d = reg.masked_queries(feats, mask, down_sample=3, n_feat=12)
+        assert torch.equal(mf.cpu(), torch.from_numpy(g[f"maskedfeats{c}"]))
+        assert np.array_equal(ep2d, np.stack([g[f"Y1_{c}"], g[f"X1_{c}"]], 1).astype(np.float64))
+        idx, vals = reg.getCors(mf, keys, leaves=1)
+        assert np.array_equal(idx.numpy(), g[f"idx1_{c}"])
+        np.testing.assert_allclose(vals.cpu().numpy(), g[f"in1_{c}"], atol=2e-5)
+        nidx = reg.filter_top(torch.from_numpy(g[f"in1_{c}"]).to(cuda0))
+        assert np.array_equal(nidx, g[f"nidx{c}"])
+        keep, M, _ = ops.select_top(torch.from_numpy(g[f"in1_{c}"][:, 0]).to(cuda0))
+        p3d, p2d = ops.gather_corr(torch.from_numpy(g[f"idx1_{c}"]).int().to(cuda0), keep, M, pts.float(),
+                                   torch.from_numpy(ep2d).float().to(cuda0))
+        m = int(M.item())
+        assert np.array_equal(p3d[:m].cpu().numpy(), g[f"ep3d{c}"].astype(np.float32))
+        assert np.array_equal(p2d[:m].cpu().numpy(), g[f"ep2d{c}"].astype(np.float32))
+        # the camera of the sub-sampled crop (:260-263)
+        from imagesequenceregistrationfor6dposeestimationlabeling_amd import formats
+        K = g[f"camMat_in{c}"].copy()
+        K[:2, 2] += 0.5; K[:2] /= 3; K[:2, 2] -= 0.5
+        np.testing.assert_array_equal(K, g[f"camMat{c}"])

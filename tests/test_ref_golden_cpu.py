@@ -170,3 +170,21 @@ def test_prune_oracle_matches_reference_statements():
     keep = dm & sm & nm
     assert np.array_equal(g["poses"][pm][keep][:int(g["prune_max_eval"]), :, :3], g["prune_R"])
     assert np.array_equal(g["poses"][pm][:int(g["noprune_max_eval"]), :, 3], g["noprune_t"])
+
+
+def test_assembly_oracle_matches_reference_statements(oracle_lib):
+    """inference.py:252-263, :265-280, :282-290 executed from the reference (ref_assembly.npz): the oracle's getCors on the
+    reference's masked features gives the reference's indices, its top-80 % cut the reference's kept set (both branches of the
+    500-correspondence rule), and the assembled arrays are the reference's."""
+    g = np.load(G / "ref_assembly.npz")
+    for c in range(int(g["n_cases"])):
+        mf, keys = torch.from_numpy(g[f"maskedfeats{c}"]), torch.from_numpy(g[f"keys{c}"])
+        idx, vals = ro.getCors(mf, keys, 1)
+        assert np.array_equal(idx.numpy(), g[f"idx1_{c}"])
+        np.testing.assert_allclose(vals.numpy(), g[f"in1_{c}"], atol=2e-6)
+        o = oracle_lib.corr_argmax_f32(g[f"maskedfeats{c}"], g[f"keys{c}"])
+        assert np.array_equal(o["idx"], g[f"idx1_{c}"])
+        nidx = ro.filter_top(torch.from_numpy(g[f"in1_{c}"]))
+        assert np.array_equal(np.asarray(nidx), g[f"nidx{c}"])
+        assert np.array_equal(g[f"pts{c}"][g[f"idx1_{c}"]][g[f"nidx{c}"]], g[f"ep3d{c}"])
+        assert np.array_equal(np.stack([g[f"Y1_{c}"], g[f"X1_{c}"]], 1)[g[f"nidx{c}"]].astype(np.float64), g[f"ep2d{c}"])
