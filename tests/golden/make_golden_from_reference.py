@@ -24,6 +24,7 @@ reference text is stored.
 Not reproducible this way (cv2 / open3d / torch_scatter are absent and must not be stood in for):
 pnp (inference.py:123-134), estimate_pose's P3P loop and batch_score (poseEstSurf.py:133-237),
 Chamfer / ICP (verfication.py:97-101, icp.py:96-117) — those stay "parity unpinned" (DESIGN.md §2).
+  ref_acceptance.npz     (`acceptance` argument) inference.py:299-320: ADD / ADD-S acceptance counters of the per-image loop
   ref_assembly.npz       (`assembly` argument) inference.py:252-263, :265-280, :282-290: masked lattice pixels -> getCors -> top-80 % -> ep3d / ep2d
   ref_estimate_prune.npz (`prune` argument) poseEstSurf.py:119-121, :145, :147-177: gathers, pruning masks, ordered selection
   ref_vote.npz           (`vote` argument) the n x n relative-pose table choosePose.py:98-107 and the ADD-S vote :121-145
@@ -324,6 +325,52 @@ def assembly():
     print("wrote ref_assembly.npz")
 
 
+def acceptance():
+    """inference.py:299-320 — the per-image acceptance bookkeeping after pnp (ADD-S on T-LESS, ADD otherwise, of the pose and of
+    its rotation alone against 0.1 * diameter; workCT, rotWorkCT, correct_predicted_ids) — executed from the reference's own
+    statements in its own per-image loop shape, for both dataset branches, on poses with graded errors."""
+    rng = np.random.default_rng(20261008)
+    base = {"torch": torch, "np": np, "F": F, "KDTree": KDTree}
+    body = ref_statements("inference.py", 299, 320, ("final_errorR", "0.1 * diameter", "rotWorkCT", "correct_predicted_ids"))
+    n = 10
+
+    def bar_with_arm(k):                      # an elongated, asymmetric object: rotations move its ends a long way
+        a = rng.uniform([-100, -8, -5], [100, 8, 5], size=(k, 3))
+        b = rng.uniform([60, 8, -5], [80, 70, 5], size=(k // 3, 3))
+        return np.concatenate([a, b])
+    verts = bar_with_arm(240)
+    surf = bar_with_arm(700).astype(np.float32).astype(np.float64)
+    diameter = float(np.linalg.norm(verts.max(0) - verts.min(0)))
+    Rg = np.array([random_rotation(rng) for _ in range(n)])
+    tg = rng.normal(size=(n, 3)) * 30 + [0, 0, 700]
+    Rp, tp = Rg.copy(), tg.copy()
+    errs = [(0.3, 0.5), (2.0, 90.0), (50.0, 1.0), (1.0, 2.0), (9.0, 14.0), (120.0, 1.0), (0.2, 0.4), (25.0, 60.0), (3.0, 150.0), (0.5, 1.0)]
+    for i, (deg, mm) in enumerate(errs):
+        w = rng.normal(size=3); w *= np.deg2rad(deg) / np.linalg.norm(w)
+        Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        th = np.linalg.norm(w)
+        Rp[i] = (np.eye(3) + np.sin(th) / th * Wx + (1 - np.cos(th)) / th ** 2 * Wx @ Wx) @ Rg[i]
+        d = rng.normal(size=3); tp[i] = tg[i] + mm * d / np.linalg.norm(d)
+    out = {}
+    for ds in ("tless", "ruapc"):
+        ns = dict(base, modelVerts=verts, surfacePointsScaled=surf, diameter=diameter, workCT=0, rotWorkCT=0, correct_predicted_ids=[],
+                  args=types.SimpleNamespace(dataset=ds))
+        ref_function("inference.py", "ADD", ns)
+        ref_function("inference.py", "ADDS", ns)
+        fe, fr = [], []
+        with contextlib.redirect_stdout(io.StringIO()):
+            for i in range(n):
+                ns.update(gtR=Rg[i], gtT=tg[i], R2=Rp[i], T2=tp[i], path=f"bop/x/train/000001/depth/{i:06d}.png", imID=i)
+                exec(body, ns)
+                fe.append(ns["final_error"]); fr.append(ns["final_errorR"])
+        out.update({f"{ds}_final_error": np.array(fe), f"{ds}_final_errorR": np.array(fr), f"{ds}_workCT": ns["workCT"],
+                    f"{ds}_rotWorkCT": ns["rotWorkCT"], f"{ds}_correct": np.array(ns["correct_predicted_ids"])})
+        assert 0 < ns["workCT"] < ns["rotWorkCT"] < n, (ns["workCT"], ns["rotWorkCT"])
+        print(ds, "workCT", ns["workCT"], "rotWorkCT", ns["rotWorkCT"])
+    np.savez_compressed(OUT / "ref_acceptance.npz", verts=verts, surface=surf, diameter=diameter, R_gt=Rg, t_gt=tg, R_pred=Rp, t_pred=tp, **out)
+    print("wrote ref_acceptance.npz")
+
+
 def prune():
     """poseEstSurf.py:119-121 (sample indices -> pixel / surface-point / normal gathers), :145 (the solved samples) and
     :147-177 (the three pruning masks, the pruned pose list and its truncation) executed from the reference's own statements
@@ -426,6 +473,8 @@ if __name__ == "__main__":
         sys.exit(prune())
     if len(sys.argv) > 1 and sys.argv[1] == "assembly":
         sys.exit(assembly())
+    if len(sys.argv) > 1 and sys.argv[1] == "acceptance":
+        sys.exit(acceptance())
     if len(sys.argv) > 1 and sys.argv[1] == "refine_modes":
         sys.exit(refine_modes())
     sys.exit(main())

@@ -218,3 +218,24 @@ def test_masked_queries_getcors_filter_assembly_vs_reference_statements(cuda0):
         K = g[f"camMat_in{c}"].copy()
         K[:2, 2] += 0.5; K[:2] /= 3; K[:2, 2] -= 0.5
         np.testing.assert_array_equal(K, g[f"camMat{c}"])
+
+
+@pytest.mark.parametrize("dataset", ["tless", "ruapc"])
+def test_acceptance_counts_vs_reference_statements(cuda0, dataset):
+    """sequence.acceptance_counts (one batched call) against inference.py:299-320 executed from the reference image by image
+    (ref_acceptance.npz): the two error values per image to 1e-4 mm (f32 upload), the same accept / reject decisions, workCT,
+    rotWorkCT and the list of accepted image names, on both dataset branches (ADD-S for T-LESS, ADD otherwise)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence
+    g = np.load(G / "ref_acceptance.npz")
+    n = len(g["R_gt"])
+    poses = torch.from_numpy(np.concatenate([g["R_pred"], g["t_pred"][:, :, None]], 2).reshape(n, 12)).to(cuda0)
+    status = torch.ones(n, dtype=torch.int32, device=cuda0)
+    names = [f"{i:06d}.png" for i in range(n)]
+    out = sequence.acceptance_counts(g["verts"], g["surface"], g["R_gt"], g["t_gt"], poses, status, float(g["diameter"]),
+                                     dataset=dataset, names=names)
+    np.testing.assert_allclose(out["final_error"], g[f"{dataset}_final_error"], atol=1e-4)
+    np.testing.assert_allclose(out["final_errorR"], g[f"{dataset}_final_errorR"], atol=1e-4)
+    assert out["workCT"] == int(g[f"{dataset}_workCT"]) and out["rotWorkCT"] == int(g[f"{dataset}_rotWorkCT"])
+    assert out["correct_predicted_ids"] == [str(x) for x in g[f"{dataset}_correct"]]
+    margin = np.abs(np.concatenate([g[f"{dataset}_final_error"], g[f"{dataset}_final_errorR"]]) - 0.1 * float(g["diameter"]))
+    assert margin.min() > 1e-2                          # no decision of the fixture hangs on the f32 rounding

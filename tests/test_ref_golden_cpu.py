@@ -188,3 +188,18 @@ def test_assembly_oracle_matches_reference_statements(oracle_lib):
         assert np.array_equal(np.asarray(nidx), g[f"nidx{c}"])
         assert np.array_equal(g[f"pts{c}"][g[f"idx1_{c}"]][g[f"nidx{c}"]], g[f"ep3d{c}"])
         assert np.array_equal(np.stack([g[f"Y1_{c}"], g[f"X1_{c}"]], 1)[g[f"nidx{c}"]].astype(np.float64), g[f"ep2d{c}"])
+
+
+@pytest.mark.parametrize("dataset", ["tless", "ruapc"])
+def test_acceptance_oracle_matches_reference_statements(dataset):
+    """inference.py:299-320 executed from the reference (ref_acceptance.npz): the oracle's ADD / ADD-S of every pose and of its
+    rotation alone, and the counters they imply."""
+    g = np.load(G / "ref_acceptance.npz")
+    n = len(g["R_gt"])
+    z = np.zeros(3)
+    f = (lambda *a: ro.ADDS(*a, g["surface"])) if dataset == "tless" else ro.ADD
+    fe = np.array([f(g["verts"], g["R_gt"][i], g["t_gt"][i], g["R_pred"][i], g["t_pred"][i]) for i in range(n)])
+    fr = np.array([f(g["verts"], g["R_gt"][i], z, g["R_pred"][i], z) for i in range(n)])
+    assert np.array_equal(fe, g[f"{dataset}_final_error"]) and np.array_equal(fr, g[f"{dataset}_final_errorR"])
+    assert int((fe < 0.1 * g["diameter"]).sum()) == int(g[f"{dataset}_workCT"])
+    assert int((fr < 0.1 * g["diameter"]).sum()) == int(g[f"{dataset}_rotWorkCT"])
