@@ -26,6 +26,7 @@ pnp (inference.py:123-134), estimate_pose's P3P loop and batch_score (poseEstSur
 Chamfer / ICP (verfication.py:97-101, icp.py:96-117) — those stay "parity unpinned" (DESIGN.md §2).
   ref_acceptance.npz     (`acceptance` argument) inference.py:299-320: ADD / ADD-S acceptance counters of the per-image loop
   ref_assembly.npz       (`assembly` argument) inference.py:252-263, :265-280, :282-290: masked lattice pixels -> getCors -> top-80 % -> ep3d / ep2d
+  ref_refine_denominator.npz (`denominator` argument) pose_refine.py:56: the log-sum-exp image over the sampled keys
   ref_estimate_prune.npz (`prune` argument) poseEstSurf.py:119-121, :145, :147-177: gathers, pruning masks, ordered selection
   ref_vote.npz           (`vote` argument) the n x n relative-pose table choosePose.py:98-107 and the ADD-S vote :121-145
 
@@ -371,6 +372,21 @@ def acceptance():
     print("wrote ref_acceptance.npz")
 
 
+def denominator():
+    """pose_refine.py:56 — the log-sum-exp denominator image over the sampled keys — executed from the reference's statement."""
+    rng = np.random.default_rng(20261009)
+    base = {"torch": torch, "np": np, "F": F}
+    stmt = ref_statements("pose_refine.py", 56, 56, ("torch.logsumexp", "keys_sampled.T"))
+    res, e, nk = 40, 12, 700
+    query_img = torch.from_numpy((rng.normal(size=(res, res, e)) * 0.8).astype(np.float32))
+    keys_sampled = torch.from_numpy(unit_rows(rng, nk, e, 4.0))
+    ns = dict(base, query_img=query_img, keys_sampled=keys_sampled)
+    exec(stmt, ns)
+    np.savez_compressed(OUT / "ref_refine_denominator.npz", query_img=query_img.numpy(), keys_sampled=keys_sampled.numpy(),
+                        denom_img=ns["denom_img"].numpy())
+    print("wrote ref_refine_denominator.npz", tuple(ns["denom_img"].shape))
+
+
 def prune():
     """poseEstSurf.py:119-121 (sample indices -> pixel / surface-point / normal gathers), :145 (the solved samples) and
     :147-177 (the three pruning masks, the pruned pose list and its truncation) executed from the reference's own statements
@@ -475,6 +491,8 @@ if __name__ == "__main__":
         sys.exit(assembly())
     if len(sys.argv) > 1 and sys.argv[1] == "acceptance":
         sys.exit(acceptance())
+    if len(sys.argv) > 1 and sys.argv[1] == "denominator":
+        sys.exit(denominator())
     if len(sys.argv) > 1 and sys.argv[1] == "refine_modes":
         sys.exit(refine_modes())
     sys.exit(main())

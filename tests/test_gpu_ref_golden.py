@@ -239,3 +239,13 @@ def test_acceptance_counts_vs_reference_statements(cuda0, dataset):
     assert out["correct_predicted_ids"] == [str(x) for x in g[f"{dataset}_correct"]]
     margin = np.abs(np.concatenate([g[f"{dataset}_final_error"], g[f"{dataset}_final_errorR"]]) - 0.1 * float(g["diameter"]))
     assert margin.min() > 1e-2                          # no decision of the fixture hangs on the f32 rounding
+
+
+def test_refine_denominator_vs_reference_statement(cuda0):
+    """pose_refine.denominator_image (K1's lse output: no (H*W x keys) matrix) against pose_refine.py:56 executed from the
+    reference (ref_refine_denominator.npz)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import pose_refine as pr
+    g = np.load(G / "ref_refine_denominator.npz")
+    d = pr.denominator_image(torch.from_numpy(g["query_img"]).to(cuda0), torch.from_numpy(g["keys_sampled"]).to(cuda0))
+    assert d.shape == g["denom_img"].shape
+    np.testing.assert_allclose(d.cpu().numpy(), g["denom_img"], atol=2e-5)

@@ -203,3 +203,10 @@ def test_acceptance_oracle_matches_reference_statements(dataset):
     assert np.array_equal(fe, g[f"{dataset}_final_error"]) and np.array_equal(fr, g[f"{dataset}_final_errorR"])
     assert int((fe < 0.1 * g["diameter"]).sum()) == int(g[f"{dataset}_workCT"])
     assert int((fr < 0.1 * g["diameter"]).sum()) == int(g[f"{dataset}_rotWorkCT"])
+
+
+def test_refine_denominator_oracle_matches_reference_statement():
+    """pose_refine.py:56 executed from the reference (ref_refine_denominator.npz)."""
+    g = np.load(G / "ref_refine_denominator.npz")
+    d = rpo.denominator_image(torch.from_numpy(g["query_img"]), torch.from_numpy(g["keys_sampled"]))
+    np.testing.assert_allclose(d.numpy().reshape(g["denom_img"].shape), g["denom_img"], atol=2e-6)
