@@ -27,6 +27,7 @@ Chamfer / ICP (verfication.py:97-101, icp.py:96-117) — those stay "parity unpi
   ref_acceptance.npz     (`acceptance` argument) inference.py:299-320: ADD / ADD-S acceptance counters of the per-image loop
   ref_assembly.npz       (`assembly` argument) inference.py:252-263, :265-280, :282-290: masked lattice pixels -> getCors -> top-80 % -> ep3d / ep2d
   ref_refine_denominator.npz (`denominator` argument) pose_refine.py:56: the log-sum-exp image over the sampled keys
+  ref_batch_score.npz    (`batch_score` argument) poseEstSurf.py:183-197, :201-212, :214-223 (batch_score around its two torch_scatter calls)
   ref_estimate_prune.npz (`prune` argument) poseEstSurf.py:119-121, :145, :147-177: gathers, pruning masks, ordered selection
   ref_vote.npz           (`vote` argument) the n x n relative-pose table choosePose.py:98-107 and the ADD-S vote :121-145
 
@@ -387,6 +388,58 @@ def denominator():
     print("wrote ref_refine_denominator.npz", tuple(ns["denom_img"].shape))
 
 
+def batch_score_fragments():
+    """poseEstSurf.py:183-197 (projection of every vertex under every pose, rounding, the ignore bin), :201-212 (populated
+    pixels, the mask score) and :214-223 (the no-hit case, normalisation, the sum) executed from the reference's own statements.
+    The two torch_scatter calls in between (:200 scatter_min, :213 scatter_mean) cannot run here — the library is absent — and
+    are NOT stood in for by the reference: the per-pixel minimum depth / its vertex and the per-pose mean are computed by plain
+    torch (amin with the lowest vertex on equal depth; sum / count) and labelled as such.  What the fixture pins is everything
+    around them: the projection and rounding convention, the ignore bin, z > 0, the mask / coordinate score assembly, -inf for a
+    pose without hits, the normalisations."""
+    rng = np.random.default_rng(20261010)
+    base = {"torch": torch, "np": np, "F": F}
+    pre = ref_statements("poseEstSurf.py", 183, 197, ("obj_pts_cam", "round_()", "mask_neg", "u.long()"))
+    mid = ref_statements("poseEstSurf.py", 201, 212, ("z > 0", "mask_score_2d", "corr_matrix_log[u, z_arg]"))
+    post = ref_statements("poseEstSurf.py", 214, 223, ("coord_score_mask", "np.log(2)", "np.log(m)", "score = mask_score + coord_score"))
+    res, m, B = 16, 500, 9
+    n = res * res
+    obj_pts = torch.from_numpy((rng.normal(size=(m, 3)) * [40, 25, 15]).astype(np.float32))
+    K = torch.tensor([[76.0, 0, res / 2 - 0.4], [0, 74.0, res / 2 + 0.2], [0, 0, 1]])
+    R = torch.from_numpy(np.array([random_rotation(rng) for _ in range(B)]).astype(np.float32))
+    t = torch.from_numpy((rng.normal(size=(B, 3)) * [6, 6, 40] + [0, 0, 500]).astype(np.float32))
+    t[1] = torch.tensor([0.0, 0.0, -400.0])                 # behind the camera: populated pixels with z < 0 -> no hit
+    t[2] = torch.tensor([900.0, 0.0, 500.0])                # out of the image: everything in the ignore bin
+    mask_log_prob = torch.from_numpy(-np.abs(rng.normal(size=n)).astype(np.float32))
+    neg_mask_log_prob = torch.from_numpy(-np.abs(rng.normal(size=n) * 2).astype(np.float32))
+    corr_matrix_log = torch.from_numpy((-np.abs(rng.normal(size=(n, m))) * 4).astype(np.float32))
+    ns = dict(base, R=R, t=t, obj_pts=obj_pts, K=K, res_sampled=res, n=n, m=m, device=torch.device("cpu"),
+              mask_log_prob=mask_log_prob, neg_mask_log_prob=neg_mask_log_prob, corr_matrix_log=corr_matrix_log)
+    exec(pre, ns)
+    u_all = ns["u"].clone()
+    # ---- not the reference: torch_scatter.scatter_min(z, u, dim_size=n + 1) by plain torch
+    z_in, u_in = ns["z"], ns["u"]
+    zmin = torch.full((B, n + 1), float("inf")).scatter_reduce(1, u_in, z_in, "amin", include_self=True)
+    vid = torch.arange(m).expand(B, m)
+    zarg = torch.full((B, n + 1), m, dtype=torch.long).scatter_reduce(
+        1, u_in, torch.where(z_in == zmin.gather(1, u_in), vid, torch.full_like(vid, m)), "amin", include_self=True)
+    zmin = torch.where(torch.isfinite(zmin), zmin, torch.zeros_like(zmin))          # torch_scatter leaves empty bins at 0
+    zarg = torch.where(zarg == m, torch.zeros_like(zarg), zarg)
+    ns.update(z=zmin, z_arg=zarg)
+    exec(mid, ns)
+    # ---- not the reference: torch_scatter.scatter_mean(coord_score, mask_pose_idx, dim_size=n_poses) by plain torch
+    cs, mpi = ns["coord_score"], ns["mask_pose_idx"]
+    ssum = torch.zeros(B).index_add_(0, mpi, cs)
+    scnt = torch.zeros(B).index_add_(0, mpi, torch.ones_like(cs))
+    ns["coord_score"] = torch.where(scnt > 0, ssum / scnt.clamp(min=1), torch.zeros(B))
+    exec(post, ns)
+    assert torch.isinf(ns["coord_score"][1]) and torch.isinf(ns["coord_score"][2]) and torch.isfinite(ns["coord_score"][0])
+    np.savez_compressed(OUT / "ref_batch_score.npz", res=res, obj_pts=obj_pts.numpy(), K=K.numpy().astype(np.float64), R=R.numpy(),
+                        t=t.numpy(), mask_log_prob=mask_log_prob.numpy(), neg_mask_log_prob=neg_mask_log_prob.numpy(),
+                        corr_matrix_log=corr_matrix_log.numpy(), u=u_all.numpy(), score=ns["score"].numpy(),
+                        mask_score=ns["mask_score"].numpy(), coord_score=ns["coord_score"].numpy())
+    print("wrote ref_batch_score.npz: scores", ns["score"].numpy().round(3).tolist())
+
+
 def prune():
     """poseEstSurf.py:119-121 (sample indices -> pixel / surface-point / normal gathers), :145 (the solved samples) and
     :147-177 (the three pruning masks, the pruned pose list and its truncation) executed from the reference's own statements
@@ -493,6 +546,8 @@ if __name__ == "__main__":
         sys.exit(acceptance())
     if len(sys.argv) > 1 and sys.argv[1] == "denominator":
         sys.exit(denominator())
+    if len(sys.argv) > 1 and sys.argv[1] == "batch_score":
+        sys.exit(batch_score_fragments())
     if len(sys.argv) > 1 and sys.argv[1] == "refine_modes":
         sys.exit(refine_modes())
     sys.exit(main())

@@ -210,3 +210,17 @@ def test_refine_denominator_oracle_matches_reference_statement():
     g = np.load(G / "ref_refine_denominator.npz")
     d = rpo.denominator_image(torch.from_numpy(g["query_img"]), torch.from_numpy(g["keys_sampled"]))
     np.testing.assert_allclose(d.numpy().reshape(g["denom_img"].shape), g["denom_img"], atol=2e-6)
+
+
+def test_batch_score_oracle_matches_reference_fragments():
+    """poseEstSurf.py:183-197, :201-212, :214-223 executed from the reference around its two torch_scatter calls
+    (ref_batch_score.npz; the scatter_min / scatter_mean themselves are plain-torch restatements there — the library is absent):
+    the oracle's batch_score gives the same three scores, -inf for the pose behind the camera and for the one off the image."""
+    g = np.load(G / "ref_batch_score.npz")
+    sc, ms, cs = epo.batch_score(torch.from_numpy(g["R"]), torch.from_numpy(g["t"]), torch.from_numpy(g["K"]).float(),
+                                 torch.from_numpy(g["obj_pts"]), int(g["res"]), torch.from_numpy(g["mask_log_prob"]),
+                                 torch.from_numpy(g["neg_mask_log_prob"]), torch.from_numpy(g["corr_matrix_log"]))
+    for a, name, n_inf in ((sc, "score", 2), (ms, "mask_score", 0), (cs, "coord_score", 2)):
+        a, b = a.numpy(), g[name]
+        assert np.array_equal(np.isinf(a), np.isinf(b)) and int(np.isinf(b).sum()) == n_inf
+        np.testing.assert_allclose(a[np.isfinite(b)], b[np.isfinite(b)], atol=2e-6)
