@@ -28,6 +28,7 @@ Chamfer / ICP (verfication.py:97-101, icp.py:96-117) — those stay "parity unpi
   ref_assembly.npz       (`assembly` argument) inference.py:252-263, :265-280, :282-290: masked lattice pixels -> getCors -> top-80 % -> ep3d / ep2d
   ref_refine_denominator.npz (`denominator` argument) pose_refine.py:56: the log-sum-exp image over the sampled keys
   ref_batch_score.npz    (`batch_score` argument) poseEstSurf.py:183-197, :201-212, :214-223 (batch_score around its two torch_scatter calls)
+  ref_pick.npz           (`pick` argument) verfication.py:70-80, :83-85, :98, :100-102, :105-106 (the Chamfer pick around its two Open3D distance calls)
   ref_estimate_prune.npz (`prune` argument) poseEstSurf.py:119-121, :145, :147-177: gathers, pruning masks, ordered selection
   ref_vote.npz           (`vote` argument) the n x n relative-pose table choosePose.py:98-107 and the ADD-S vote :121-145
 
@@ -440,6 +441,58 @@ def batch_score_fragments():
     print("wrote ref_batch_score.npz: scores", ns["score"].numpy().round(3).tolist())
 
 
+def pick():
+    """verfication.py:70-80 (the two images' poses out of scene_gt.json / pred6d.json dictionaries, calculate_relative_pose),
+    :83-85 (the rotation-only transforms of the model cloud, translations commented out), :98, :100-102 (means, the Chamfer
+    value, the list) per pair and :105-106 (min, list.index) executed from the reference's own statements.  The two
+    open3d compute_point_cloud_distance calls in between (:97, :99) cannot run here (Open3D absent) and are NOT the reference's:
+    exact nearest-neighbour distances by scipy.spatial.cKDTree, labelled as such."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(20261011)
+    base = {"torch": torch, "np": np}
+    ns = dict(base)
+    ref_function("verfication.py", "calculate_relative_pose", ns)
+    poses_stmt = ref_statements("verfication.py", 70, 80, ("cam_R_m2c", "calculate_relative_pose", "pred6d[key4]"))
+    cloud_stmt = ref_statements("verfication.py", 83, 85, ("pc1.dot(R1pred.T)", "pc1p1.dot(R_relative)", "pc1.dot(R2pred)"))
+    m1 = ref_statements("verfication.py", 98, 98, ("np.mean(dists_pcdpred_to_pcdgt)",))
+    m2 = ref_statements("verfication.py", 100, 102, ("np.mean(dists_pcdgt_to_pcdpred)", "chamfer_distance", "chamferdis.append"))
+    fin = ref_statements("verfication.py", 105, 106, ("min(chamferdis)", "chamferdis.index"))
+    n = 7
+    pc1 = (rng.normal(size=(700, 3)) * [45, 20, 10] + [10, 0, 0]).astype(np.float32).astype(np.float64)
+    Rg = np.array([random_rotation(rng) for _ in range(n)])
+    tg = rng.normal(size=(n, 3)) * 30 + [0, 0, 700]
+    Rp = Rg.copy()
+    for i, deg in enumerate([3.0, 0.4, 0.5, 9.0, 0.4, 0.5, 20.0]):
+        w = rng.normal(size=3); w *= np.deg2rad(deg) / np.linalg.norm(w)
+        Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        th = np.linalg.norm(w)
+        Rp[i] = (np.eye(3) + np.sin(th) / th * Wx + (1 - np.cos(th)) / th ** 2 * Wx @ Wx) @ Rg[i]
+    tp = tg + rng.normal(size=(n, 3))
+    keys = [str(i) for i in range(n)]
+    data = {k: [{"cam_R_m2c": Rg[i].reshape(-1).tolist(), "cam_t_m2c": tg[i].tolist()}] for i, k in enumerate(keys)}
+    pred6d = {k: [{"R": Rp[i].reshape(-1).tolist(), "T": tp[i].tolist()}] for i, k in enumerate(keys)}
+    ns.update(data=data, pred6d=pred6d, keysgt=keys, keyspred=keys, pc1=pc1, chamferdis=[])
+    rel, clouds = [], None
+    for i in range(0, n - 1):
+        ns.update(i=i, key1=keys[i], key2=keys[i + 1], key3=keys[i], key4=keys[i + 1])        # :62-65
+        exec(poses_stmt, ns)
+        exec(cloud_stmt, ns)
+        rel.append(np.array(ns["R_relative"]))
+        if i == 0:
+            clouds = (np.array(ns["pcgt"]), np.array(ns["pcpred"]))
+        # ---- not the reference: open3d compute_point_cloud_distance = exact nearest-neighbour distances
+        ns["dists_pcdpred_to_pcdgt"] = cKDTree(ns["pcgt"]).query(ns["pcpred"], k=1)[0]
+        exec(m1, ns)
+        ns["dists_pcdgt_to_pcdpred"] = cKDTree(ns["pcpred"]).query(ns["pcgt"], k=1)[0]
+        exec(m2, ns)
+    exec(fin, ns)
+    ch = np.array(ns["chamferdis"])
+    assert ch.max() > 1.5 * ch.min() and ns["min_index"] == int(np.argmin(ch))
+    np.savez_compressed(OUT / "ref_pick.npz", pc1=pc1, R_gt=Rg, t_gt=tg, R_pred=Rp, t_pred=tp, R_relative=np.array(rel),
+                        pcgt0=clouds[0], pcpred0=clouds[1], chamferdis=ch, min_index=int(ns["min_index"]), min_chamfer=float(ns["min_chamfer"]))
+    print("wrote ref_pick.npz: chamferdis", ch.round(4).tolist(), "min_index", ns["min_index"])
+
+
 def prune():
     """poseEstSurf.py:119-121 (sample indices -> pixel / surface-point / normal gathers), :145 (the solved samples) and
     :147-177 (the three pruning masks, the pruned pose list and its truncation) executed from the reference's own statements
@@ -548,6 +601,8 @@ if __name__ == "__main__":
         sys.exit(denominator())
     if len(sys.argv) > 1 and sys.argv[1] == "batch_score":
         sys.exit(batch_score_fragments())
+    if len(sys.argv) > 1 and sys.argv[1] == "pick":
+        sys.exit(pick())
     if len(sys.argv) > 1 and sys.argv[1] == "refine_modes":
         sys.exit(refine_modes())
     sys.exit(main())

@@ -268,3 +268,19 @@ def test_zbuf_score_vs_reference_fragments(cuda0):
         a, b = a.cpu().numpy(), g[name]
         assert np.array_equal(np.isinf(a), np.isinf(b)) and int(np.isinf(b).sum()) == n_inf
         np.testing.assert_allclose(a[np.isfinite(b)], b[np.isfinite(b)], atol=2e-5)
+
+
+def test_chamfer_pick_vs_reference_fragments(cuda0):
+    """registration.chamfer_pairs / sequence.pick_by_chamfer against verfication.py:70-80, :83-85, :98, :100-102, :105-106
+    executed from the reference around its two Open3D distance calls (ref_pick.npz): the rotation-only clouds as written there,
+    every pair's Chamfer value to 1e-4 mm (f32 upload of the cloud), the picked pair."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration as reg, sequence
+    g = np.load(G / "ref_pick.npz")
+    n = len(g["R_gt"])
+    ch = reg.chamfer_pairs(g["pc1"], g["R_pred"], g["R_relative"]).cpu().numpy()
+    np.testing.assert_allclose(ch, g["chamferdis"], atol=1e-4)
+    poses = torch.from_numpy(np.concatenate([g["R_pred"], g["t_pred"][:, :, None]], 2).reshape(n, 12)).to(cuda0)
+    idx, val = sequence.pick_by_chamfer(torch.from_numpy(g["pc1"]).float().to(cuda0), poses, g["R_gt"], g["t_gt"], n)
+    assert idx == int(g["min_index"]) and abs(val - float(g["min_chamfer"])) < 1e-4
+    gap = np.sort(g["chamferdis"])
+    assert gap[1] - gap[0] > 1e-2                          # the pick of the fixture does not hang on the f32 rounding

@@ -224,3 +224,18 @@ def test_batch_score_oracle_matches_reference_fragments():
         a, b = a.numpy(), g[name]
         assert np.array_equal(np.isinf(a), np.isinf(b)) and int(np.isinf(b).sum()) == n_inf
         np.testing.assert_allclose(a[np.isfinite(b)], b[np.isfinite(b)], atol=2e-6)
+
+
+def test_pick_oracle_matches_reference_fragments():
+    """verfication.py:70-80, :83-85, :98, :100-102, :105-106 executed from the reference around its two Open3D distance calls
+    (ref_pick.npz; those two are exact nearest-neighbour distances by cKDTree there): the oracle's relative rotations, its
+    rotation-only clouds of the first pair, every Chamfer value and the picked pair."""
+    g = np.load(G / "ref_pick.npz")
+    n = len(g["R_gt"])
+    rel = np.array([ro.calculate_relative_pose(g["R_gt"][i], g["t_gt"][i], g["R_gt"][i + 1], g["t_gt"][i + 1])[0] for i in range(n - 1)])
+    np.testing.assert_allclose(rel, g["R_relative"], atol=1e-12)
+    np.testing.assert_allclose(g["pc1"].dot(g["R_pred"][0].T).dot(g["R_relative"][0]), g["pcgt0"], atol=1e-12)
+    np.testing.assert_allclose(g["pc1"].dot(g["R_pred"][1]), g["pcpred0"], atol=1e-12)
+    ch = ro.chamfer_pairs(g["pc1"], g["R_pred"], g["R_relative"])
+    np.testing.assert_allclose(np.asarray(ch), g["chamferdis"], rtol=1e-12)
+    assert int(np.argmin(ch)) == int(g["min_index"]) and min(ch) == g["min_chamfer"] or abs(min(ch) - g["min_chamfer"]) < 1e-12
