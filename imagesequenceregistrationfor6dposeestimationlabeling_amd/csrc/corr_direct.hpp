@@ -55,12 +55,21 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
     float* __restrict__ lse_out) {
-  constexpr int NCH = 2 * DK;
+  // 16-byte chunks staged per key row: all 2 DK of them, or — DKU < DK, the split-f32 route's rows with trailing zero blocks —
+  // only the 2 DKU that can be non-zero (12 for DKU = 6: a quarter less key traffic, which is what bounds that route: its
+  // 256-byte key rows do not fit the L2, profiles/r03_estimate_pose_hbm_traffic.txt).
+  constexpr int NCH = 2 * DKU;
+  constexpr bool POW2 = (NCH & (NCH - 1)) == 0;
   constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;
   constexpr int CHUNKS = kTK * NCH;
   constexpr int NLD = CHUNKS / kThreads;
   static_assert(CHUNKS % kThreads == 0, "every thread stages the same number of chunks");
+  static_assert(POW2 || NCH == 12, "LDS chunk placement is written for a power of two or 12 chunks per row");
   __shared__ uint4 lds[2][CHUNKS];
+  // where chunk c of key row `row` lives inside the row's NCH slots: an XOR swizzle for power-of-two rows; for 12-chunk rows a
+  // rotation by (row / 4) % 4 — a row starts 12 row (mod 16) sixteen-byte banks in, which only depends on row % 4, and the
+  // rotation separates the four rows of every such class: the 16 lanes of a ds_read_b128 phase hit 16 distinct banks.
+  auto slot = [](int row, int c) { return POW2 ? (c ^ ((row / RPB) & (NCH - 1))) : (c + ((row >> 2) & 3)) % NCH; };
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     for (int i = 0; i < NLD; ++i) {
       const int ci = tid + i * kThreads;
       const int row = ci / NCH, c = ci % NCH;
-      lds[buf][row * NCH + (c ^ ((row / RPB) & (NCH - 1)))] = stg[i];
+      lds[buf][row * NCH + slot(row, c)] = stg[i];
     }
   };
   // A fragments of key sub-tile `sub` of LDS buffer `buf`.  One register set: a fragment's ds_read
@@ -167,10 +176,9 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   bf16x8 a[DKU];
   auto load_a = [&](int buf, int sub) {
     const int row = sub * 32 + r;
-    const int sw = (row / RPB) & (NCH - 1);
 #pragma unroll
     for (int s = 0; s < DKU; ++s) {
-      const uint4 v = lds[buf][row * NCH + ((2 * s + h) ^ sw)];
+      const uint4 v = lds[buf][row * NCH + slot(row, 2 * s + h)];
       a[s] = *reinterpret_cast<const bf16x8*>(&v);
     }
   };
