@@ -811,26 +811,47 @@ struct CorrPlan {
   int qblocks, nchunks, nsplit, range_chunks, rsplit;
 };
 
+constexpr int kSmallQ = 8192;     // query blocks below which a few key ranges are always allowed (tail balancing)
+
 inline int max_split_for(int qblocks, int nchunks) {
   int ns = (kSlotCap + qblocks - 1) / qblocks;
+  if (qblocks < kSmallQ && ns < 4) ns = 4;
   if (ns > nchunks) ns = nchunks;
   if (ns > kMaxSplit) ns = kMaxSplit;
   return ns < 1 ? 1 : ns;
 }
 
-// Work units = (query block, key range of whole chunks).  The range is split only when the query
-// blocks alone cannot fill the machine (small P, e.g. the reference's 75x75 crops), and then just
-// enough to give every resident slot one unit: every range pays its own row recovery and partials.
+// Work units = (query block, key range of whole chunks); every resident slot runs one unit at a time and the hardware
+// hands out the next unit as slots free up, so a launch lasts  ceil(units / slots) x (one unit).  The number of key ranges
+// is the one that minimises that, with a unit priced at its chunks plus 0.3 chunk for what every range pays on its own
+// (prologue, row recovery, partials for the finalize pass).  Round 3: the old rule — split only when the query blocks
+// alone cannot fill the machine, and then just enough to give every slot one unit — put 588 units on 512 slots at
+// P = 50 176, N = 80 000: two rounds for 1.15 rounds of work (1.20 ms; 0.74 ms with 5 ranges).
+// ISR_TUNE_K1_SPLIT > 0 forces the number of ranges (capped as above): a caller that knows most of its rows are zero
+// padding (crop batches: ~40 % dense) asks for finer units than the nominal row count suggests.
 // The split changes which workgroup computes a chunk, never a chunk's arithmetic.
 CorrPlan make_plan(int P, int N, int slots, int q_per_block) {
   CorrPlan p;
   p.qblocks = (P + q_per_block - 1) / q_per_block;
   p.nchunks = (N + kChunk - 1) / kChunk;
   if (slots > kSlotCap) slots = kSlotCap;
-  int ns = 1;
-  if (p.qblocks < slots) ns = (slots + p.qblocks - 1) / p.qblocks;
+  if (slots < 1) slots = 1;
   const int cap = max_split_for(p.qblocks, p.nchunks);
-  if (ns > cap) ns = cap;
+  int ns = 1;
+  const int forced = isr::tuning(ISR_TUNE_K1_SPLIT);
+  if (forced > 0) {
+    ns = forced < cap ? forced : cap;
+  } else {
+    double best = 1e300;
+    for (int c = 1; c <= cap; ++c) {
+      const int rc = (p.nchunks + c - 1) / c;
+      const int nsp = (p.nchunks + rc - 1) / rc;
+      if (nsp != c) continue;                                  // the same plan as a smaller c
+      const long units = (long)p.qblocks * nsp;
+      const double cost = (double)((units + slots - 1) / slots) * ((double)rc + 0.3);
+      if (cost < best - 1e-9) { best = cost; ns = c; }
+    }
+  }
   p.range_chunks = (p.nchunks + ns - 1) / ns;
   p.nsplit = (p.nchunks + p.range_chunks - 1) / p.range_chunks;
   const int nstage = (N + kTK - 1) / kTK;

@@ -110,21 +110,39 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     const int q = q0 + qb * 32 + r;
     if (!whole && split == 0 && h == 0 && q < P) ws.qn2[q] = n2;
   }
-  // ONE key range and every query of the workgroup is the zero vector (the padding rows behind a crop's masked pixels
-  // in a capacity-sized batch, isr_prep_queries_batch): each logit is exactly 0, each chunk sum the number of its keys,
-  // L = N exactly — corr_finish gets what the loop below would have handed it (bit for bit: v_exp_f32(0) = 1 and sums
-  // of ones are exact), and the workgroup leaves without touching the keys.
-  if (whole) {
+  // Every query of the workgroup is the zero vector (the padding rows behind a crop's masked pixels in a capacity-sized
+  // batch, isr_prep_queries_batch): each logit is exactly 0, each chunk sum the number of its keys (v_exp_f32(0) = 1 and sums
+  // of ones are exact), the maximum 0 at the range's first key.  The workgroup hands on what the loop below would have
+  // produced — corr_finish's inputs when it owns the whole key range, the range's partials otherwise (round 3: the key-split
+  // route computed these rows in full, so a crop batch cost twice as much with two key ranges as with one) — and leaves
+  // without touching the keys.
+  {
     bool nonzero = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) nonzero |= qn2[qb] != 0.f;
     if (!__syncthreads_or(nonzero ? 1 : 0)) {
-      const float kn2z = kn2_max(ws);
+      if (whole) {
+        const float kn2z = kn2_max(ws);
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
-        const int q = q0 + qb * 32 + r;
-        if (h == 0 && q < P)
-          corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, 16 * DK, 0.f, kn2z, ws, idx_out, logp_out, lse_out);
+        for (int qb = 0; qb < QB; ++qb) {
+          const int q = q0 + qb * 32 + r;
+          if (h == 0 && q < P)
+            corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, 16 * DK, 0.f, kn2z, ws, idx_out, logp_out, lse_out);
+        }
+      } else {
+        const int zc0 = split * range_chunks;
+        const int zk0 = zc0 * kChunk, zk1 = min(N, zk0 + range_chunks * kChunk);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const int q = q0 + qb * 32 + r;
+          if (h != 0 || q >= P) continue;
+          for (int c = zc0; c * kChunk < zk1; ++c) ws.plc[(size_t)c * P + q] = (float)(min(zk1, (c + 1) * kChunk) - c * kChunk);
+          const size_t off = (size_t)split * P + q;
+          ws.pm[off] = 0.f;
+          ws.pm2[off] = zk1 - zk0 > 1 ? 0.f : -__builtin_inff();
+          ws.pbi[off] = zk0;
+          ws.pbad[off] = 0;
+        }
       }
       if (tid == 0) ws.flags[blockIdx.y * gridDim.x + blockIdx.x] = 0;
       if (probe && tid == 0) { ws.clk[0] = 0; ws.clk[1] = 0; }

@@ -452,3 +452,26 @@ def test_corr_f32_split_route_equals_chain_route(cuda0, oracle_lib, P, N, D):
             sl = ops.corr_argmax(Qs[lo:lo + n], K, want_lse=True)
             for a, b in zip(sl, full):
                 assert torch.equal(a, b[lo:lo + n])
+
+
+@pytest.mark.parametrize("kind", ["bf16_log2", "f32"])
+def test_corr_result_is_independent_of_the_number_of_key_ranges(cuda0, kind):
+    """The planner's choice of key ranges (cost model; ISR_TUNE_K1_SPLIT forces it) changes which workgroup computes a chunk,
+    never a chunk's arithmetic: idx, logp and lse bit for bit for 1, 2, 3, 5 and the automatic number of ranges — P large
+    enough that one range is a legal plan, zero rows (crop-batch padding) included."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    g = torch.Generator(device=cuda0).manual_seed(5)
+    P, N, D = 6000, 33000, 12 if kind == "f32" else 16
+    K = torch.randn(N, D, device=cuda0, generator=g)
+    K = 5.0 * K / K.norm(dim=1, keepdim=True)
+    Q = 1.2 * K[torch.randint(N, (P,), device=cuda0, generator=g)] + 0.3 * torch.randn(P, D, device=cuda0, generator=g)
+    Q[1000:3500] = 0.0
+    if kind == "bf16_log2":
+        Q, K = ops.prescale_queries_log2(Q), K.bfloat16()
+    call = lambda: ops.corr_argmax(Q, K, want_lse=True, log2_prescaled=(kind == "bf16_log2"))
+    auto = call()
+    for ns in (1, 2, 3, 5):
+        with ops.tuning(k1_split=ns):
+            got = call()
+        for a, b in zip(got, auto):
+            assert torch.equal(a, b), ns
