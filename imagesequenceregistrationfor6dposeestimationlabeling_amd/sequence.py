@@ -372,24 +372,49 @@ def pick_by_chamfer(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.nda
     return idx, val
 
 
+def chamfer_pairs_owned(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.ndarray, t_gt_all: np.ndarray,
+                        lo: int, hi: int) -> torch.Tensor:
+    """The device part of the sharded pick: the Chamfer values of the consecutive pairs (i, i+1), i in [lo, hi)
+    (verfication.py:70-102) as a (hi - lo,) f64 device tensor.  A pair's value is a function of the two images'
+    poses only, whichever block it is evaluated in."""
+    if hi <= lo:
+        return torch.empty(0, dtype=torch.float64, device=pc1.device)
+    Rp = poses_all.reshape(-1, 3, 4)[lo:hi + 1, :, :3].cpu().numpy()
+    # rotation block of [R2|T2] inv([R1|T1]) (verfication.py:9-19) for every owned pair at once
+    Rg = np.asarray(R_gt_all, np.float64)
+    Rrel = np.einsum("nij,nkj->nik", Rg[lo + 1:hi + 1], Rg[lo:hi]) if _orthonormal(Rg[lo:hi]) else np.stack(
+        [registration.calculate_relative_pose(R_gt_all[i], t_gt_all[i], R_gt_all[i + 1], t_gt_all[i + 1])[0]
+         for i in range(lo, hi)])
+    return registration.chamfer_pairs(pc1, Rp, Rrel)
+
+
 def pick_by_chamfer_table(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: np.ndarray, t_gt_all: np.ndarray,
                           n_total: int) -> tuple[int, float, np.ndarray]:
     """pick_by_chamfer, also returning the full chamferdis table (n - 1,) f64 as a NumPy array."""
     rank, size = shard.world()
     lo, hi = shard.owned_pairs(n_total, rank, size)
-    if hi > lo:
-        Rp = poses_all.reshape(-1, 3, 4)[lo:hi + 1, :, :3].cpu().numpy()
-        # rotation block of [R2|T2] inv([R1|T1]) (verfication.py:9-19) for every owned pair at once
-        Rg = np.asarray(R_gt_all, np.float64)
-        Rrel = np.einsum("nij,nkj->nik", Rg[lo + 1:hi + 1], Rg[lo:hi]) if _orthonormal(Rg[lo:hi]) else np.stack(
-            [registration.calculate_relative_pose(R_gt_all[i], t_gt_all[i], R_gt_all[i + 1], t_gt_all[i + 1])[0]
-             for i in range(lo, hi)])
-        ch = registration.chamfer_pairs(pc1, Rp, Rrel)
-    else:
-        ch = torch.empty(0, dtype=torch.float64, device=pc1.device)
+    ch = chamfer_pairs_owned(pc1, poses_all, R_gt_all, t_gt_all, lo, hi)
     table = shard.allreduce_min_table(ch, lo, n_total - 1).cpu().numpy()
     idx, val = shard.first_min(table)
     return idx, val, table
+
+
+def vote_rows(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, lo: int, hi: int, chunk: int = 4096):
+    """The device part of the row-sharded vote (choosePose.py:98-107, 121-138): rows [lo, hi) of
+        error[i][j] = ADDS(modelVerts, gt_rel[i][j], pred_rel[i][j]) < 0.1 * diameter
+    Returns (error rows (hi - lo, n) bool device tensor, their int32 row sums (hi - lo, 1))."""
+    n = len(R_gt)
+    v = registration._dev(model_verts, torch.float32)
+    sp = registration._dev(surface_pts, torch.float32)
+    Rg, tg = registration._dev(R_gt, torch.float64), registration._dev(t_gt, torch.float64)     # arrays or tensors
+    Rp, tp = registration._dev(R_pred, torch.float64), registration._dev(t_pred, torch.float64)
+    gt_rel = ops.rel_pose_table(Rg, tg, 0, lo, hi).reshape(-1, 12)        # (rows * n, 12) f64, [R_i^T R_j | t_j - t_i]
+    pr_rel = ops.rel_pose_table(Rp, tp, 0, lo, hi).reshape(-1, 12)
+    parts = [ops.nn_batched(v, sp, gt_rel[s0:s0 + chunk], pr_rel[s0:s0 + chunk]).sum_d
+             for s0 in range(0, (hi - lo) * n, chunk)]
+    adds = torch.cat(parts).reshape(hi - lo, n) / v.shape[0]
+    err_d = adds < 0.1 * float(diameter)
+    return err_d, err_d.sum(dim=1, dtype=torch.int32)[:, None]
 
 
 def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, top: int = 50, chunk: int = 4096):
@@ -406,17 +431,7 @@ def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diam
     lo, hi = shard.block_range(n, rank, size)
     dev = registration.device()
     if hi > lo:
-        v = registration._dev(model_verts, torch.float32)
-        sp = registration._dev(surface_pts, torch.float32)
-        Rg, tg = registration._dev(R_gt, torch.float64), registration._dev(t_gt, torch.float64)     # arrays or tensors
-        Rp, tp = registration._dev(R_pred, torch.float64), registration._dev(t_pred, torch.float64)
-        gt_rel = ops.rel_pose_table(Rg, tg, 0, lo, hi).reshape(-1, 12)        # (rows * n, 12) f64, [R_i^T R_j | t_j - t_i]
-        pr_rel = ops.rel_pose_table(Rp, tp, 0, lo, hi).reshape(-1, 12)
-        parts = [ops.nn_batched(v, sp, gt_rel[s0:s0 + chunk], pr_rel[s0:s0 + chunk]).sum_d
-                 for s0 in range(0, (hi - lo) * n, chunk)]
-        adds = torch.cat(parts).reshape(hi - lo, n) / v.shape[0]
-        err_d = adds < 0.1 * float(diameter)
-        sums_local = err_d.sum(dim=1, dtype=torch.int32)[:, None]
+        err_d, sums_local = vote_rows(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, lo, hi, chunk)
         err = err_d.to(torch.float64).cpu().numpy()
     else:
         err = np.zeros((0, n))

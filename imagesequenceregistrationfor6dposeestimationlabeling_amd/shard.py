@@ -41,6 +41,30 @@ def owned_pairs(n: int, rank: int, size: int) -> tuple[int, int]:
 INF_BITS = 0x7FF0000000000000     # +inf as f64 bits: the identity of the MIN reduction below
 
 
+def min_table_image(local: torch.Tensor, lo: int, n_items: int, dev=None) -> torch.Tensor:
+    """One rank's contribution to the MIN reduction: the (n_items,) int64 table holding the bit patterns of the
+    f64 values of the items [lo, lo + len(local)) it owns and +inf everywhere else."""
+    local = local.to(torch.float64).reshape(-1)
+    if lo < 0 or lo + local.numel() > n_items:
+        raise ValueError(f"items [{lo}, {lo + local.numel()}) do not fit a table of {n_items}")
+    dev = local.device if dev is None else dev
+    table = torch.full((n_items,), INF_BITS, dtype=torch.int64, device=dev)
+    if local.numel():
+        table[lo:lo + local.numel()] = local.to(dev).view(torch.int64)
+    return table
+
+
+def merge_min_tables(tables) -> torch.Tensor:
+    """What all_reduce(MIN) leaves on every rank, computed in one process from the ranks' min_table_image()
+    contributions (elementwise integer minimum, in any order): the rehearsal of an N-rank reduction on a box that
+    has one GPU.  Returns the (n_items,) f64 table."""
+    tables = list(tables)
+    out = tables[0].clone()
+    for t in tables[1:]:
+        out = torch.minimum(out, t.to(out.device))
+    return out.view(torch.float64)
+
+
 def allreduce_min_table(local: torch.Tensor, lo: int, n_items: int) -> torch.Tensor:
     """Every rank contributes the f64 values of the items [lo, lo + len(local)) it owns; ONE all-reduce(MIN)
     gives every rank the whole (n_items,) table — the reference's `chamferdis` list (verfication.py:61-102) —
@@ -56,10 +80,7 @@ def allreduce_min_table(local: torch.Tensor, lo: int, n_items: int) -> torch.Ten
         if lo != 0 or local.numel() != n_items:
             raise ValueError("a single rank owns every item")
         return local
-    dev = _coll_device()
-    table = torch.full((n_items,), INF_BITS, dtype=torch.int64, device=dev)
-    if local.numel():
-        table[lo:lo + local.numel()] = local.to(dev).view(torch.int64)
+    table = min_table_image(local, lo, n_items, _coll_device())
     dist.all_reduce(table, op=dist.ReduceOp.MIN)
     return table.view(torch.float64)
 

@@ -1,0 +1,112 @@
+"""BASELINE configs[2] on ONE GPU: "T-LESS obj 1, 512 images sharded 8 x MI355X, RCCL min-Chamfer reduce".
+
+The multi-GPU run itself is the driver's; what a one-GPU box can prove is that the 8-way decomposition returns the
+unsharded answer at the configuration's own size.  512 predicted poses, the 20 000-point cloud of bench.py:
+  * the 511-pair Chamfer pick (verfication.py:61-108) evaluated as the eight `shard.owned_pairs` blocks through the
+    device part of `sequence.pick_by_chamfer_table` (`chamfer_pairs_owned`), each block turned into the rank's
+    contribution exactly as `shard.allreduce_min_table` builds it (`min_table_image`) and merged by the elementwise
+    integer minimum an all-reduce(MIN) computes (`merge_min_tables`): the merged table must be the unsharded call's
+    bit for bit, equal the f64 cKDTree oracle on EVERY pair (1e-4 mm; the seven block-straddling pairs named), and
+    give the same first minimum;
+  * the 512 x 512 ADD-S vote (choosePose.py:121-151) as eight row blocks (`vote_rows`): row sums merged as the
+    all-gather would, equal to the unsharded rows, sampled rows (block edges included) equal to the oracle's loop with
+    the reference's own sklearn KDTree(leaf_size=2), same chosen image and top-50 list."""
+import numpy as np
+import pytest
+import torch
+
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+N_IMAGES, RANKS = 512, 8
+
+
+def _poses(rng, n, fail=(5, 300, 509)):
+    """Predictions as a registration leaves them: most within a few hundredths of a degree, an eighth two degrees
+    off, a few failures with unrelated orientations; one pair made the clear winner away from index 0."""
+    Rg, tg = synth.random_poses(rng, n)
+    deg = np.full(n, 0.03)
+    deg[rng.choice(n, n // 8, replace=False)] = 2.0
+    P = [synth.perturb_pose(rng, Rg[i], tg[i], deg[i], 0.5) for i in range(n)]
+    Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
+    for i in fail:
+        Rp[i] = synth.random_poses(rng, 1)[0][0]
+    return Rg, tg, Rp, tp
+
+
+def test_pick_n512_as_eight_blocks_equals_unsharded_and_oracle(cuda0):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence, shard
+    from oracle import registration_oracle as ro
+    n = N_IMAGES
+    pc = synth.tless_like(np.random.default_rng(20240), 20000)          # bench.make_model's cloud
+    Rg, tg, Rp, tp = _poses(np.random.default_rng(512), n)
+    # a planted first minimum on a block boundary (images 191 | 192 = ranks 2 | 3): the pair's two clouds coincide
+    # when R2pred = R1pred^T R_rel (verfication.py:83-85 as written: pc R1pred^T R_rel against pc R2pred)
+    Rp[192] = Rp[191].T @ (Rg[192] @ Rg[191].T)
+    pc_d = torch.from_numpy(pc).to(cuda0)
+    poses = torch.from_numpy(np.concatenate([Rp, tp[:, :, None]], 2).reshape(n, 12)).to(cuda0)
+
+    full = sequence.chamfer_pairs_owned(pc_d, poses, Rg, tg, 0, n - 1)
+    assert full.shape == (n - 1,) and full.dtype == torch.float64
+    contributions, covered = [], np.zeros(n - 1, int)
+    for r in range(RANKS):
+        lo, hi = shard.owned_pairs(n, r, RANKS)
+        covered[lo:hi] += 1
+        ch = sequence.chamfer_pairs_owned(pc_d, poses, Rg, tg, lo, hi)
+        contributions.append(shard.min_table_image(ch, lo, n - 1, torch.device("cpu")))
+    assert (covered == 1).all()                                        # every pair has exactly one owner
+    merged = shard.merge_min_tables(contributions)
+    assert torch.equal(merged, full.cpu()), "the merged 8-block table differs from the unsharded one"
+    # merge order must not matter (an all-reduce does not promise one)
+    assert torch.equal(shard.merge_min_tables(contributions[::-1]), merged)
+    table = merged.numpy()
+    straddling = [shard.block_range(n, r, RANKS)[1] - 1 for r in range(RANKS - 1)]
+    assert straddling == [63, 127, 191, 255, 319, 383, 447]
+    P64 = pc.astype(np.float64)
+    ref = np.array([ro.chamfer(P64.dot(Rp[i + 1]),
+                               P64.dot(Rp[i].T).dot(ro.calculate_relative_pose(Rg[i], tg[i], Rg[i + 1], tg[i + 1])[0]))
+                    for i in range(n - 1)])
+    np.testing.assert_allclose(table[straddling], ref[straddling], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(table, ref, atol=1e-4, rtol=0)
+    idx, val = shard.first_min(table)
+    assert idx == int(np.argmin(ref)) == 191
+    assert abs(val - ref[191]) < 1e-4
+
+
+def test_vote_n512_as_eight_row_blocks(cuda0):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence, shard
+    from oracle import registration_oracle as ro
+    n = N_IMAGES
+    rng = np.random.default_rng(20240)
+    S = synth.tless_like(rng, 20000)
+    V = synth.tless_like(rng, 1000)
+    diam = synth.diameter(S)
+    Rg, tg = synth.random_poses(rng, n)
+    deg = rng.choice([0.5, 4.0, 9.0, 14.0], size=n)
+    tr = rng.choice([1.0, 1.0, 1.0, 10.0], size=n)
+    bad = [3, 129, 400]
+    deg[bad], tr[bad] = 90.0, 40.0
+    P = [synth.perturb_pose(rng, Rg[i], tg[i], deg[i], tr[i]) for i in range(n)]
+    Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
+
+    img, top, err = sequence.vote_choose_image(V, S, Rg, tg, Rp, tp, diam)       # unsharded: all 262 144 items
+    assert err.shape == (n, n) and 0.1 < err.mean() < 0.95
+    sums_blocks, rows_blocks = [], []
+    for r in range(RANKS):
+        lo, hi = shard.block_range(n, r, RANKS)
+        e, s = sequence.vote_rows(V, S, Rg, tg, Rp, tp, diam, lo, hi)
+        rows_blocks.append(e.cpu().numpy().astype(np.float64))
+        sums_blocks.append(s.cpu().numpy()[:, 0])
+    sums = np.concatenate(sums_blocks).astype(np.float64)                        # what allgather_rows concatenates
+    assert np.array_equal(np.concatenate(rows_blocks), err)
+    assert np.array_equal(sums, err.sum(1))
+    assert img == int(np.argmax(sums)) and img not in bad
+    assert list(top) == list(np.argsort(-sums, kind="stable")[:50])
+    # sampled rows against the reference's own KD-tree formulation, block edges included
+    rows = [0, 63, 64, 255, 256, 300, 511]
+    gt_rel, pr_rel = ro.rel_pose_table(Rg, tg), ro.rel_pose_table(Rp, tp)
+    cols = np.unique(np.concatenate([np.arange(0, n, 7), [63, 64, 511], bad]))
+    rerr, radds = ro.vote(V.astype(np.float64), S.astype(np.float64), gt_rel[rows][:, cols], pr_rel[rows][:, cols], diam)
+    assert np.abs(radds - 0.1 * diam).min() > 1e-4                               # no sampled item sits on the threshold
+    assert np.array_equal(err[rows][:, cols], rerr)
