@@ -84,25 +84,34 @@ def parse_args():
     ap.add_argument("--verify", choices=("pick", "vote"), default="pick",
                     help="verification stage: 'pick' = consecutive-pair Chamfer pick (verfication.py:61-108, the headline); "
                          "'vote' = the n x n ADD-S vote whose top choice icp.py:37-39 reads (choosePose.py:121-151)")
+    ap.add_argument("--object", choices=("tless", "revolution"), default="tless",
+                    help="tless: the discrete-symmetric box with a boss (configs[1]/[2]); revolution: the continuous-symmetry "
+                         "surface of revolution of BASELINE configs[3], descriptors constant along the azimuth up to a weak term")
     ap.add_argument("--no-estimate-pose", action="store_true", help="skip the untimed estimate_pose / reference-shape timings")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed oracle re-computation of the last step")
     return ap.parse_args()
 
 
-def make_model(dev, N, D, tau=5.0):
+def make_model(dev, N, D, tau=5.0, obj="tless"):
     """Keys with |k| = tau.  tau sets how peaked the softmax is: at tau = 8 (SURVEY's first suggestion) a
     planted query beats the log-sum of the other 20 000 keys by > 30 nats, EVERY log-probability is 0
     to f32 rounding, and the top-80 % cut (strict `>` on exact ties, inference.py:282-290) keeps
     nothing — in the reference's own torch f32 log_softmax as much as here.  tau = 5 leaves a 10-nat
     margin: log-probabilities spread over 1e-6 .. 1e-2 and the cut does real work."""
     rng = np.random.default_rng(20240)
-    pts = synth.tless_like(rng, N)
-    g = torch.Generator(device=dev).manual_seed(777)
-    k = torch.randn(N, D, device=dev, generator=g)
-    keys_f32 = tau * k / k.norm(dim=1, keepdim=True)
-    cloud = synth.tless_like(rng, 4 * N)
+    solid = synth.revolution if obj == "revolution" else synth.tless_like
+    pts = solid(rng, N)
+    if obj == "revolution":
+        # configs[3]: keys of points on one parallel are nearly identical (synth.revolution_keys) — correspondences are
+        # ambiguous about the azimuth by construction, RANSAC sees a low inlier ratio
+        keys_f32 = torch.from_numpy(synth.revolution_keys(rng, pts, D, tau=tau)).to(dev)
+    else:
+        g = torch.Generator(device=dev).manual_seed(777)
+        k = torch.randn(N, D, device=dev, generator=g)
+        keys_f32 = tau * k / k.norm(dim=1, keepdim=True)
+    cloud = solid(rng, 4 * N)
     upper, lower = synth.split_halves(rng, cloud, N)
-    cad = synth.tless_like(rng, 5000)
+    cad = solid(rng, 5000)
     return keys_f32, torch.from_numpy(pts).to(dev), upper, lower, cad
 
 
@@ -251,6 +260,38 @@ def measure_nn(pts, dev, pairs=32):
             "counter_source": "profiles/nn_hbm_traffic.json (rocprofv3 --pmc, separate run)" if counter else None}
 
 
+def measure_ransac(dev, pts, Kcam, M=245760, H=4096, reps=5):
+    """K2 alone (BASELINE configs[3]'s hypothesis count): isr_ransac_score — every one of H P3P
+    hypotheses scored against M correspondences (0.8 x 640 x 480), HIP events on the launch stream.  The entry is
+    proj_matrix_kernel + ONE score_kernel launch + best_kernel + best_mask_kernel; score_kernel is > 95 % of it
+    (profiles/r04_k2_*).  FLOPs by the survey's convention: 30 per (hypothesis, correspondence); algorithmic bytes
+    20 M + 48 H + 4 H + M / 8."""
+    rng = np.random.default_rng(4)
+    R, t = synth.random_poses(rng, 1)
+    p3d, p2d, _ = synth.pnp_case(rng, pts.cpu().numpy(), Kcam, R[0], t[0], M)
+    p3, p2 = torch.from_numpy(p3d).to(dev), torch.from_numpy(p2d).to(dev)
+    Rt, ok = ops.p3p_hypotheses(p3, p2, Kcam, H, seed=11)[:2]
+    n_inl, best, _ = ops.ransac_score(p3, p2, Kcam, Rt, ok, 2.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        n_inl, best, _ = ops.ransac_score(p3, p2, Kcam, Rt, ok, 2.0)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / reps
+    n_ok = int(ok.sum().item())
+    pairs = float(n_ok) * M                      # hypotheses whose P3P failed are skipped by the kernel: not counted
+    alg_bytes = 20.0 * M + 52.0 * H + M / 8.0
+    return {"kernel": "isr_ransac_score: proj_matrix_kernel + score_kernel (one launch, every hypothesis) + best_kernel + "
+                      "best_mask_kernel", "shape": f"H = {H} hypotheses ({n_ok} with a P3P solution) x M = {M} correspondences",
+            "ms": sec * 1e3, "hyp_corr_per_s": pairs / sec, "bound": "f32 VALU (30 FLOP per hypothesis-correspondence pair, "
+            "SURVEY 8(d))", "achieved": 30.0 * pairs / sec * 1e-12, "peak": PEAK_FP32_VALU * 1e-12, "unit": "TFLOP/s",
+            "frac": 30.0 * pairs / sec / PEAK_FP32_VALU, "algorithmic_bytes": alg_bytes,
+            "algorithmic_hbm_frac": alg_bytes / sec / 8.0e12, "best_hypothesis": int(best.item()),
+            "best_inliers": int(n_inl[int(best.item())].item())}
+
+
 def measure_k1_f32(Q_img, keys_f32, dev, log2_domain):
     """K1 at the reference's own precision (f32 descriptors, v_mfma_f32_32x32x2_f32: indices bit-exact vs
     the k-ordered fmaf chain) on ONE image of the workload, against the dense f32 matrix peak."""
@@ -310,12 +351,13 @@ def measure_nn_vote(cad_d, pts, dev, items=4096):
             "algorithmic_hbm_frac": alg_bytes / sec / 8.0e12}
 
 
-def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower, cad, max_pairs=63):
+def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower, cad, max_pairs=1023):
     """UNTIMED tail, rank 0: what the last timed step produced, recomputed by the CPU oracle (round-2 verdict:
     the bench's own pick / ICP / final Chamfer had never been compared with anything).
       * K1: the arg-max of 1 024 query rows of the first image against oracle/isr_oracle.c (exact bf16 products);
-      * pick: every consecutive-pair Chamfer value of the last step (up to `max_pairs` pairs, the picked one always
-        among them) against the f64 cKDTree oracle, and the same first minimum (verfication.py:61-108);
+      * pick: EVERY consecutive-pair Chamfer value of the last step (all n - 1 pairs up to `max_pairs` = 1 023, i.e. all
+        511 of configs[2]; beyond that a sample with the picked pair in it, and then `pick_idx_equal` is not reported —
+        only `pick_is_min_of_sampled`) against the f64 cKDTree oracle, and the same first minimum (verfication.py:61-108);
       * ICP + final Chamfer for the picked image (icp.py:83-117) against the oracle loop with exact f64 neighbours
         (cKDTree; the device flags near ties of its f32 search and decides them in f64: DESIGN.md K3/K4)."""
     from oracle import cbind, registration_oracle as ro
@@ -342,8 +384,11 @@ def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower,
         out["pairs_checked"] = int(len(sel))
         out["pairs_total"] = int(n - 1)
         out["chamfer_max_abs"] = float(np.max(np.abs(table[sel] - ref)))
-        out["pick_idx_equal"] = bool(sel[int(np.argmin(ref))] == picked) if len(sel) == n - 1 else bool(
-            abs(ref[list(sel).index(picked)] - ref.min()) == 0.0)
+        out["table_argmin_equals_pick"] = bool(int(np.argmin(table)) == picked)
+        if len(sel) == n - 1:
+            out["pick_idx_equal"] = bool(int(np.argmin(ref)) == picked)
+        else:
+            out["pick_is_min_of_sampled"] = bool(ref[list(sel).index(picked)] == ref.min())
     best = int(last["picked_image"])
     pose = poses[best]
     src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)
@@ -448,7 +493,7 @@ def main():
     P, N, D = args.width * args.height, args.keys, args.dim
     n_local, n_total = args.images, args.images * world
     Kcam = synth.camera(args.width, args.height)
-    keys_f32, pts, upper, lower, cad = make_model(dev, N, D, args.tau)
+    keys_f32, pts, upper, lower, cad = make_model(dev, N, D, args.tau, args.object)
     keys = keys_f32.bfloat16().contiguous()
     model = sequence.SequenceModel(keys=keys, pts=pts, log2_queries=args.k1 == "log2")
     cad_d = torch.from_numpy(cad).to(dev)
@@ -513,6 +558,7 @@ def main():
                 best, ch, table = sequence.pick_by_chamfer_table(pts, poses_all, R_gt, t_gt, n_total)
                 out.update(picked_pair=best, picked_image=best, pair_chamfer=ch, chamfer_table=table)
             st = status.cpu()
+            out.update(_poses_local=poses, _status_local=status)
             out.update(registered_this_rank=int(st.sum().item()), images_this_rank=int(st.numel()),
                        hypotheses_scored_mean=float(n_eval.float().mean().item()), icp_rank=owner_of(best),
                        poses_all=poses_all.cpu().numpy())
@@ -589,9 +635,10 @@ def main():
         k1_clock_mhz = ops.corr_clock_mhz()        # shader clock held under the kernel (s_memtime / s_memrealtime)
         k1_rechecked = ops.corr_recheck_count()
     # untimed region, rank 0: the brute-force NN rate at the Chamfer-pair shape and the exact-f32 K1 on one image
-    nn_live = f32_exact = nn_vote = None
+    nn_live = f32_exact = nn_vote = k2_live = None
     if rank == 0:
         nn_live = measure_nn(pts, dev)
+        k2_live = measure_ransac(dev, pts, Kcam, M=int(0.8 * P), H=max(args.itr, 4096))
         if args.verify == "vote":
             nn_vote = measure_nn_vote(cad_d, pts, dev, items=min(4096, n_local * n_total))
         f32_exact = measure_k1_f32(Q_all[0], keys_f32, dev, args.k1 == "log2")
@@ -608,6 +655,23 @@ def main():
         torch.distributed.broadcast(vals, src=last["icp_rank"])
         v = [float(x) for x in vals.cpu()]
         last.update(final_chamfer=v[0], icp_fitness=v[1], icp_rmse=v[2], rot_err_rad=v[3], trans_err_mm=v[4])
+    # untimed tail, every rank: the reference's per-image acceptance bookkeeping (inference.py:299-320, the T-LESS branch:
+    # ADD-S of the pose and of its rotation alone against 0.1 x diameter) for the last step's block, summed over ranks
+    acceptance = None
+    if args.ablate != "noverify":
+        acc = sequence.acceptance_counts(cad_d, pts, R_gt[lo:hi], t_gt[lo:hi], last["_poses_local"], last["_status_local"],
+                                         diameter, dataset="tless")
+        fin = np.isfinite(acc["final_error"])
+        cnt = torch.tensor([acc["workCT"], acc["rotWorkCT"], int(fin.sum()), n_local], dtype=torch.float64)
+        err_sum = torch.tensor([float(acc["final_error"][fin].sum())], dtype=torch.float64)
+        if world > 1:
+            both = torch.cat([cnt, err_sum]).to(shard._coll_device())
+            torch.distributed.all_reduce(both)
+            cnt, err_sum = both[:4].cpu(), both[4:].cpu()
+        acceptance = {"rule": "ADDS(modelVerts, gtR, gtT, R, T) < 0.1 * diameter (inference.py:300-312, T-LESS branch)",
+                      "diameter_mm": float(diameter), "workCT": int(cnt[0]), "rotWorkCT": int(cnt[1]),
+                      "registered": int(cnt[2]), "images": int(cnt[3]),
+                      "mean_adds_mm_of_registered": float(err_sum[0] / max(float(cnt[2]), 1.0))}
     # second short timed loop (untimed for `value`): the same step with EVERY hypothesis scored (confidence 1), so the
     # line carries the cv2-default figure and the score-everything one side by side
     all_hyp = None
@@ -633,12 +697,16 @@ def main():
         ncalls, nms, pairs = timing.get("nn_batched", (0, 0.0, 0.0))
         verification = ("consecutive-pair Chamfer pick (one f64 min-table all-reduce)" if args.verify == "pick" else
                         "n x n ADD-S vote, rows sharded (row-sum all-gather)")
-        last_pub = {k: v for k, v in last.items() if k not in ("poses_all", "chamfer_table")}
+        last_pub = {k: v for k, v in last.items() if k not in ("poses_all", "chamfer_table") and not k.startswith("_")}
         line = {
             "metric": "registered images/sec (T-LESS obj 1-like, synthetic) + final Chamfer error",
             "value": n_total * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            # what torch.distributed itself reports (not the flags): a SCALE record shows the backend saw N ranks
+            "dist": ({"initialized": True, "backend": torch.distributed.get_backend(),
+                      "world_size": torch.distributed.get_world_size(), "rank": torch.distributed.get_rank()}
+                     if torch.distributed.is_initialized() else {"initialized": False, "backend": None, "world_size": 1, "rank": 0}),
             "config": {"workload": (f"BASELINE configs[1]: {n_local} images/GPU, {args.width}x{args.height}x{D}-D bf16 "
                                     f"queries vs {N} keys; per image getCors + top-80% filter + PnP-RANSAC "
                                     f"(<= {args.itr} P3P hypotheses, adaptive at confidence {args.confidence}, 2 px); per step "
@@ -651,7 +719,8 @@ def main():
                        "step_overlap": ("none" if args.no_pipeline else
                                         "verification (all-gather, pick/vote, ICP, final Chamfer) of batch s "
                                         "overlaps the registration of batch s+1")},
-            "final_chamfer": last.get("final_chamfer"), "last_step": last_pub,
+            "final_chamfer": last.get("final_chamfer"), "last_step": last_pub, "acceptance": acceptance,
+            "object": args.object,
             "per_rank_ms_per_step": {"min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
                                      "all": [d / args.steps * 1e3 for d in dts]},
             "ransac_all_hypotheses": all_hyp,
@@ -676,6 +745,7 @@ def main():
                          "f32_exact": f32_exact},
             "roofline_nn": nn_live,
             "roofline_nn_vote": nn_vote,
+            "roofline_ransac": k2_live,
             # K3 is no longer one kernel at one rate: single-item calls (ICP steps, final Chamfer) scan every
             # target (nn_search_kernel, VALU-bound), the batched Chamfer pick runs the block-cooperative grid
             # search, which evaluates only the candidates near each query cell.  Reported: the rate in

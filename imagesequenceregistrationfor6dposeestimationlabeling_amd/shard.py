@@ -45,7 +45,7 @@ def min_table_image(local: torch.Tensor, lo: int, n_items: int, dev=None) -> tor
     """One rank's contribution to the MIN reduction: the (n_items,) int64 table holding the bit patterns of the
     f64 values of the items [lo, lo + len(local)) it owns and +inf everywhere else."""
     local = local.to(torch.float64).reshape(-1)
-    if lo < 0 or lo + local.numel() > n_items:
+    if local.numel() and (lo < 0 or lo + local.numel() > n_items):     # a rank that owns nothing may sit past the end
         raise ValueError(f"items [{lo}, {lo + local.numel()}) do not fit a table of {n_items}")
     dev = local.device if dev is None else dev
     table = torch.full((n_items,), INF_BITS, dtype=torch.int64, device=dev)

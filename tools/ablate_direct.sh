@@ -1,4 +1,6 @@
 #!/bin/bash
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # On the GPU box: timing-only ablations of corr_bf16_direct_kernel (rebuilds corr_argmax.hip with -D flags).
 cd "$GRAFT_REPO_ROOT"
 for v in "" "-DISR_ABL_DNOMAX" "-DISR_ABL_DNOEXP" "-DISR_ABL_DNOMAX -DISR_ABL_DNOEXP"; do

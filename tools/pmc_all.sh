@@ -1,4 +1,6 @@
 #!/bin/bash
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # HBM traffic from PMC counters (separate passes, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not
 # fit one pass) for K1 at the bench's launch sizes and for the brute-force NN shape of roofline_nn; writes
 # profiles/k1_hbm_traffic.json and profiles/nn_hbm_traffic.json.   bash tools/pmc_all.sh <scratch dir>

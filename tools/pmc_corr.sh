@@ -1,4 +1,6 @@
 #!/bin/bash
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # PMC passes over tools/time_corr.py (K1 alone).  Separate passes: SQ has 8 slots, TCC 4.
 # Usage on the GPU box: bash tools/pmc_corr.sh <outdir> [P N D]
 set -u

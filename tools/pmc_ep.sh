@@ -1,4 +1,6 @@
 #!/bin/bash
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # HBM traffic (PMC, separate passes as MI355X_MICROARCH.md prescribes) of the matrix-free estimate_pose kernels: bash tools/pmc_ep.sh <outdir>
 out=${1:-gpurun_out/pmc_ep}; R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

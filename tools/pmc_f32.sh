@@ -1,4 +1,6 @@
 #!/bin/bash
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # SQ counters of the exact-f32 K1 at the crop-batch shape: bash tools/pmc_f32.sh <outdir> [kernel-name substring]
 # (default substring: corr_bf16_direct_kernel<8 — the split route, which tools/time_corr_f32.py takes by default; corr_f32_kernel with
 # ISR_TUNE_K1_F32_CHAIN: run round 3's first half, profiles/r03_k1_f32_pmc.txt)

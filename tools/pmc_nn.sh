@@ -1,4 +1,6 @@
 #!/bin/bash
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # HBM traffic of the NN kernels (Chamfer-pair shape) from PMC counters: bash tools/pmc_nn.sh <outdir>
 set -u
 out=${1:-gpurun_out/pmc_nn}

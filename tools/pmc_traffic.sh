@@ -1,4 +1,6 @@
 #!/bin/bash
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # HBM traffic of K1 for a given launch size: bash tools/pmc_traffic.sh <outdir> P N D
 set -u
 out=$1; shift

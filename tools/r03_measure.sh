@@ -1,3 +1,5 @@
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 set -o pipefail
 python -m pytest tests -m gpu -q > gpurun_out/t_final.log 2>&1; tail -3 gpurun_out/t_final.log
 python bench.py --steps 20 > gpurun_out/r03_bench_n1.json 2> gpurun_out/r03_bench_n1.err && tail -c 200 gpurun_out/r03_bench_n1.json

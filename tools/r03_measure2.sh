@@ -1,3 +1,5 @@
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # final measurements of round 3 (second half): python suite, smoke, bench variants, rocprof of the bench.   bash tools/r03_measure2.sh
 set -o pipefail
 python -m pytest tests -m gpu -q > gpurun_out/t_final.log 2>&1; tail -3 gpurun_out/t_final.log

@@ -1,4 +1,6 @@
 #!/bin/bash
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 # On the GPU box: rebuild ransac.hip with different (correspondences per lane, hypotheses per block)
 # and time the score kernel alone.   bash tools/score_sweep.sh
 cd "$GRAFT_REPO_ROOT"
