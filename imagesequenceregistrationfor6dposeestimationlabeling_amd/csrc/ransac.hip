@@ -281,10 +281,18 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
     U[c] = p2d[2 * (size_t)mm]; V[c] = p2d[2 * (size_t)mm + 1];
   }
   const int lane = threadIdx.x & 63;
+  // Everything the loop branches on or counts with lives in scalar registers: the hypotheses' ok flags as one 32-bit
+  // mask, the lanes' validity as one ballot per correspondence slot, and each test as the AND of the two compares'
+  // own condition masks (a ballot of a bool expression costs a v_cndmask + v_cmp_ne per slot on top of the compares).
+  static_assert(kHC <= 32, "ok mask of a block's hypotheses is one 32-bit word");
+  const uint32_t okmask = (uint32_t)__ballot(lane < kHC && oks[lane < kHC ? lane : 0] != 0);
+  unsigned long long vmask[kCPL];
+#pragma unroll
+  for (int c = 0; c < kCPL; ++c) vmask[c] = __ballot(valid[c]);
+  int cntv = 0;  // lane j: this wave's count for hypothesis h0 + j (one v_writelane per hypothesis, one LDS atomic per wave)
   for (int h = h0; h < h1; ++h) {
-    if (!oks[h - h0]) continue;  // uniform
-    // the matrix once per hypothesis (three LDS broadcasts), then straight-line tests: `&`, not `&&` —
-    // short-circuit evaluation turned every test into two exec-masked branches with an LDS wait each
+    if (!((okmask >> (h - h0)) & 1u)) continue;  // uniform
+    // the matrix once per hypothesis (three LDS broadcasts), then straight-line tests
     const float4 r0 = *reinterpret_cast<const float4*>(&Ps[h - h0][0]);
     const float4 r1 = *reinterpret_cast<const float4*>(&Ps[h - h0][4]);
     const float4 r2 = *reinterpret_cast<const float4*>(&Ps[h - h0][8]);
@@ -298,11 +306,11 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
       const float ex = __builtin_fmaf(-U[c], z, x), ey = __builtin_fmaf(-V[c], z, y);
       const float e2 = __builtin_fmaf(ey, ey, ex * ex);
       const float lim = reperr * z;
-      const bool in = valid[c] & (z > 0.0f) & (e2 <= lim * lim);
-      c_wave += __popcll(__ballot(in));
+      c_wave += __popcll(__ballot(z > 0.0f) & __ballot(e2 <= lim * lim) & vmask[c]);
     }
-    if (lane == 0 && c_wave) atomicAdd(&cnt[h - h0], c_wave);
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(c_wave), "s"(h - h0));
   }
+  if (lane < kHC && cntv) atomicAdd(&cnt[lane], cntv);
   __syncthreads();
   if (threadIdx.x < h1 - h0 && cnt[threadIdx.x]) atomicAdd(&n_inl[h0 + threadIdx.x], cnt[threadIdx.x]);
 }

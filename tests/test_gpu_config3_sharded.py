@@ -84,7 +84,7 @@ def test_vote_n512_as_eight_row_blocks(cuda0):
     diam = synth.diameter(S)
     Rg, tg = synth.random_poses(rng, n)
     deg = rng.choice([0.5, 4.0, 9.0, 14.0], size=n)
-    tr = rng.choice([1.0, 1.0, 1.0, 10.0], size=n)
+    tr = rng.choice([1.0, 4.0, 8.0, 16.0], size=n)          # ~85 % of the items below 0.1 x diameter
     bad = [3, 129, 400]
     deg[bad], tr[bad] = 90.0, 40.0
     P = [synth.perturb_pose(rng, Rg[i], tg[i], deg[i], tr[i]) for i in range(n)]
@@ -108,5 +108,6 @@ def test_vote_n512_as_eight_row_blocks(cuda0):
     gt_rel, pr_rel = ro.rel_pose_table(Rg, tg), ro.rel_pose_table(Rp, tp)
     cols = np.unique(np.concatenate([np.arange(0, n, 7), [63, 64, 511], bad]))
     rerr, radds = ro.vote(V.astype(np.float64), S.astype(np.float64), gt_rel[rows][:, cols], pr_rel[rows][:, cols], diam)
-    assert np.abs(radds - 0.1 * diam).min() > 1e-4                               # no sampled item sits on the threshold
-    assert np.array_equal(err[rows][:, cols], rerr)
+    clear = np.abs(radds - 0.1 * diam) > 1e-4                                    # an item ON the threshold may go either way
+    assert clear.mean() > 0.99 and 0.05 < rerr.mean() < 0.95
+    assert np.array_equal(err[rows][:, cols][clear], rerr[clear])
