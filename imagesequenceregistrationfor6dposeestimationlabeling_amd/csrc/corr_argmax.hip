@@ -146,16 +146,76 @@ __device__ __forceinline__ LaneState merged_with_other_half(LaneState st) {
   return st;
 }
 
+// ------------------------------------------------------------------------- operand rows, MFMA chain
+// Plain layout (SP = 0): a row is DK 16-wide bf16 blocks, one fragment per block, one MFMA per block and tile.
+// Split layout (SP > 0, the exact-f32 route for D <= 16 SP): a row is the three bf16 PLANES x1 | x2 | x3 of an f32 row
+// (x = x1 + x2 + x3 exactly, 8 + 8 + 8 mantissa bits), SP blocks each; fragment p * SP + j = block j of plane p + 1.  A tile
+// is the six plane pairs down to 2^-16 — q1k3, q2k2, q1k2, q3k1, q2k1, q1k1 (q2k3, q3k2, q3k3 are 2^-24 relative and
+// dropped) — issued smallest first and so that every key plane's uses are contiguous (k3 is free after SP MFMAs, k2 after
+// 3 SP: their ds_reads for the next key sub-tile start early): 6 SP MFMAs from 3 SP + 3 SP fragments, where the round-3
+// form of the route multiplied the 96-wide rows [x1 x1 x2 x2 x1 x3] . [k1 k2 k1 k2 k3 k1] with 6 + 6 fragments at D <= 16.
+template <int DK, int SP>
+struct RowFrags {
+  static constexpr int NFR = SP ? 3 * SP : DK;     // fragments per operand row
+  static constexpr int NMF = SP ? 6 * SP : DK;     // matrix instructions per 32 x 32 tile
+  static constexpr int NQN = SP ? SP : DK;         // fragments that enter the norm of the margin test (plane 1)
+};
+
+template <int DK, int SP>
+__device__ __forceinline__ f32x16 tile_chain(const bf16x8 (&a)[RowFrags<DK, SP>::NFR], const bf16x8 (&b)[RowFrags<DK, SP>::NFR],
+                                             f32x16 c) {
+  if constexpr (SP == 0) {
+#pragma unroll
+    for (int s = 0; s < DK; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], c, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 * SP + j], b[j], c, 0, 0, 0);            // k3 q1
+#pragma unroll
+    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SP + j], b[SP + j], c, 0, 0, 0);           // k2 q2
+#pragma unroll
+    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SP + j], b[j], c, 0, 0, 0);                // k2 q1
+#pragma unroll
+    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[2 * SP + j], c, 0, 0, 0);            // k1 q3
+#pragma unroll
+    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[SP + j], c, 0, 0, 0);                // k1 q2
+#pragma unroll
+    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[j], c, 0, 0, 0);                     // k1 q1
+  }
+  return c;
+}
+
+// What the margin test's (D + 2) 2^-23 |q||k| must cover on the split route, with |q|, |k| the norms of plane 1 (within
+// 2^-8 of the f32 rows' norms): the f32 accumulation of n = 96 SP exact products whose absolute values sum to at most
+// 1.004 sum_d |q_d k_d| (Higham, u = 2^-23), the dropped pairs (<= 2^-25 relative), the residuals of the two three-way
+// splits and the rounding of q log2 e (<= 5 x 2^-24), and the rounding of the f32 chain the recheck decides by
+// (<= 16 SP x 2^-24): D_eff + 2 >= 1.03 (96 SP + 2) + 0.51 (16 SP + 5).
+constexpr int split_deff(int SP) { return (103 * (96 * SP + 2) + 51 * (16 * SP + 5)) / 100 + 1; }
+
 // ------------------------------------------------------------------------- key staging (LDS)
-// 128-key stages through an XOR-swizzled LDS image: coalesced 16-byte global loads,
-// conflict-free ds_read_b128 in MFMA A-operand layout.  Shared by the fallback and recheck kernels
-// (the direct kernel stages through a raw buffer descriptor, corr_direct.hpp).
-template <int DK>
+// Key stages through a swizzled LDS image: coalesced 16-byte global loads, conflict-free ds_read_b128 in MFMA
+// A-operand layout.  Shared by the fallback and recheck kernels (the direct kernel stages through a raw buffer
+// descriptor, corr_direct.hpp).  Rows of a power-of-two number of 16-byte chunks: XOR swizzle over the row.  Split rows
+// (6 SP chunks: a row starts 6 SP row (mod 16) sixteen-byte banks in, a pattern of period PD = 8 / SP rows): XOR inside each
+// plane's 2 SP chunks with (row / PD) % (2 SP) — the 16 rows of a ds_read_b128 phase then hit 16 distinct banks.
+template <int NCH, int SP>
+__device__ __forceinline__ constexpr int key_slot(int row, int c) {
+  if constexpr (SP == 0) {
+    constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;              // key rows per 256-byte LDS bank row
+    return c ^ ((row / RPB) & (NCH - 1));
+  } else {
+    constexpr int W = 2 * SP, PD = (SP >= 8) ? 1 : 8 / SP;
+    return (c / W) * W + ((c % W) ^ ((row / PD) & (W - 1)));
+  }
+}
+
+template <int DK, int SP = 0>
 struct KeyStage {
-  static constexpr int NCH = 2 * DK;                         // 16-byte chunks per key row
-  static constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;     // key rows per 256-byte LDS bank row
-  static constexpr int CHUNKS = kTK * NCH;                   // chunks per stage
+  static constexpr int NFR = RowFrags<DK, SP>::NFR;
+  static constexpr int NCH = 2 * NFR;                        // 16-byte chunks per key row
+  static constexpr int TK = (NCH <= 16) ? kTK : (NCH <= 32) ? 64 : 32;   // keys per LDS stage: two buffers within 64 KB
+  static constexpr int CHUNKS = TK * NCH;                    // chunks per stage
   static constexpr int NLD = (CHUNKS + kThreads - 1) / kThreads;
+  static_assert(SP != 0 || (NCH & (NCH - 1)) == 0, "plain rows: a power of two of 16-byte chunks");
   uint4 stg[NLD];
   __device__ __forceinline__ void gload(const uint16_t* __restrict__ K, int ldk, int key0, int k1) {
 #pragma unroll
@@ -173,15 +233,14 @@ struct KeyStage {
     for (int i = 0; i < NLD; ++i) {
       const int ci = threadIdx.x + i * kThreads;
       const int row = ci / NCH, c = ci % NCH;
-      if (ci < CHUNKS) lds[row * NCH + (c ^ ((row / RPB) & (NCH - 1)))] = stg[i];
+      if (ci < CHUNKS) lds[row * NCH + key_slot<NCH, SP>(row, c)] = stg[i];
     }
   }
-  static __device__ __forceinline__ void load_a(const uint4* lds, int sub, int r, int h, bf16x8 (&a)[DK]) {
+  static __device__ __forceinline__ void load_a(const uint4* lds, int sub, int r, int h, bf16x8 (&a)[NFR]) {
     const int row = sub * 32 + r;
-    const int sw = (row / RPB) & (NCH - 1);
 #pragma unroll
-    for (int s = 0; s < DK; ++s) {
-      const uint4 v = lds[row * NCH + ((2 * s + h) ^ sw)];
+    for (int s = 0; s < NFR; ++s) {
+      const uint4 v = lds[row * NCH + key_slot<NCH, SP>(row, 2 * s + h)];
       a[s] = *reinterpret_cast<const bf16x8*>(&v);
     }
   }
@@ -236,11 +295,12 @@ __device__ __forceinline__ void update_max_l2(f32x16& acc, L2State& st, f32x16& 
 // it leaves (chunk maximum, l_c relative to R_c = ceil(chunk maximum [* log2 e])) — the index of a
 // bad query is always decided by the exact recheck, so no arg-max is kept here.
 constexpr int kFallbackGrid = 1024;
-template <int DK, bool LOG2>
+template <int DK, bool LOG2, int SP = 0>
 __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, int qblocks, int nchunks, CorrWs ws) {
-  using KS = KeyStage<DK>;
+  using KS = KeyStage<DK, SP>;
+  constexpr int NFR = KS::NFR, TKS = KS::TK;
   __shared__ uint4 lds[2][KS::CHUNKS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
@@ -252,14 +312,14 @@ __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
   if (chunk >= nchunks) continue;                   // the last key range may hold fewer chunks
   const int q0 = (bx * kWaves + wave) * (kQB * 32);
 
-  bf16x8 bq[kQB][DK];
+  bf16x8 bq[kQB][NFR];
 #pragma unroll
   for (int qb = 0; qb < kQB; ++qb) {
     int row = q0 + qb * 32 + r;
     row = row < P ? row : P - 1;
     const uint16_t* src = Q + (size_t)row * ldq + 8 * h;
 #pragma unroll
-    for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+    for (int s = 0; s < NFR; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
   }
   LaneState st[kQB];
   L2State s2[kQB];
@@ -272,25 +332,23 @@ __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
   }
   const int k0 = chunk * kChunk;
   const int k1 = min(N, k0 + kChunk);
-  const int nstage = (k1 - k0 + kTK - 1) / kTK;
+  const int nstage = (k1 - k0 + TKS - 1) / TKS;
   KS ks;
   ks.gload(K, ldk, k0, k1);
   ks.lwrite(lds[0]);
   __syncthreads();
   for (int stage = 0; stage < nstage; ++stage) {
     const int buf = stage & 1;
-    if (stage + 1 < nstage) ks.gload(K, ldk, k0 + (stage + 1) * kTK, k1);
+    if (stage + 1 < nstage) ks.gload(K, ldk, k0 + (stage + 1) * TKS, k1);
 #pragma unroll
-    for (int sub = 0; sub < kTK / 32; ++sub) {
-      const int kb = k0 + stage * kTK + sub * 32;
+    for (int sub = 0; sub < TKS / 32; ++sub) {
+      const int kb = k0 + stage * TKS + sub * 32;
       if (kb < k1) {  // block-uniform
-        bf16x8 a[DK];
+        bf16x8 a[NFR];
         KS::load_a(lds[buf], sub, r, h, a);
 #pragma unroll
         for (int qb = 0; qb < kQB; ++qb) {
-          f32x16 acc = LOG2 ? cinit[qb] : splat16(0.f);
-#pragma unroll
-          for (int s = 0; s < DK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qb][s], acc, 0, 0, 0);
+          f32x16 acc = tile_chain<DK, SP>(a, bq[qb], LOG2 ? cinit[qb] : splat16(0.f));
           if (kb + 32 > k1) mask_tail(acc, kb + 4 * h, k1);
           if (LOG2) {
             update_max_l2(acc, s2[qb], cinit[qb]);
@@ -510,6 +568,22 @@ __global__ __launch_bounds__(256) void corr_split_f32_kernel(const float* __rest
   o[96] = 0; o[112] = 0;
 }
 
+// rows (R, ld) f32, D <= 16 SP -> (R, 48 SP) bf16: the planes [x1 | x2 | x3] of x * prescale, 16 SP columns each, zero beyond D
+template <int SP>
+__global__ __launch_bounds__(256) void corr_split3_f32_kernel(const float* __restrict__ X, int R, int D, int ld, float prescale,
+                                                              uint16_t* __restrict__ out) {
+  constexpr int W = 16 * SP;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)R * W) return;
+  const long row = i / W;
+  const int d = (int)(i % W);
+  const float x = d < D ? X[row * ld + d] * prescale : 0.f;     // prescale = 1 (keys): exact
+  float r1, r2, r3;
+  const uint16_t x1 = bf16_rne(x, &r1), x2 = bf16_rne(r1, &r2), x3 = bf16_rne(r2, &r3);
+  uint16_t* o = out + row * (3 * W) + d;
+  o[0] = x1; o[W] = x2; o[2 * W] = x3;
+}
+
 // ------------------------------------------------------------------------------ key norms
 // max_n |k_n|^2 for the error bound of the margin test, one partial per block; block 0 also zeroes
 // the recheck counter of this call.
@@ -694,11 +768,12 @@ __device__ __attribute__((noinline)) double chain_logit_f32(const float* __restr
   return (double)acc;
 }
 
-template <int DK>
+template <int DK, int SP = 0>
 __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int rsplit, double scale, F32Rows f32, CorrWs ws) {
-  using KS = KeyStage<DK>;
+  using KS = KeyStage<DK, SP>;
+  constexpr int NFR = KS::NFR, TKS = KS::TK;     // the key ranges below are cut in units of kTK keys, staged TKS at a time
   __shared__ uint4 lds[2][KS::CHUNKS];
   const int cnt = *ws.rcount;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -712,7 +787,7 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
   const int k1 = min(N, k0 + per * kTK);
   for (int g = slot; g * (kWaves * kQB * 32) < cnt; g += nslots) {   // block-uniform
     const int e0 = (g * kWaves + wave) * (kQB * 32);
-    bf16x8 bq[kQB][DK];
+    bf16x8 bq[kQB][NFR];
     float thr[kQB];
     int qrow[kQB];
     double best[kQB];
@@ -724,11 +799,11 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
       thr[qb] = e < cnt ? ws.qn2[qrow[qb]] : __builtin_inff();
       const uint16_t* src = Q + (size_t)qrow[qb] * ldq + 8 * h;
 #pragma unroll
-      for (int s = 0; s < DK; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+      for (int s = 0; s < NFR; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
       best[qb] = -__builtin_inf();
       bidx[qb] = -1;
     }
-    const int nstage = k1 > k0 ? (k1 - k0 + kTK - 1) / kTK : 0;
+    const int nstage = k1 > k0 ? (k1 - k0 + TKS - 1) / TKS : 0;
     KS ks;
     __syncthreads();                    // the previous group's last LDS reads are done
     if (nstage > 0) {
@@ -738,18 +813,16 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
     __syncthreads();
     for (int stage = 0; stage < nstage; ++stage) {
       const int buf = stage & 1;
-      if (stage + 1 < nstage) ks.gload(K, ldk, k0 + (stage + 1) * kTK, k1);
+      if (stage + 1 < nstage) ks.gload(K, ldk, k0 + (stage + 1) * TKS, k1);
 #pragma unroll
-      for (int sub = 0; sub < kTK / 32; ++sub) {
-        const int kb = k0 + stage * kTK + sub * 32;
+      for (int sub = 0; sub < TKS / 32; ++sub) {
+        const int kb = k0 + stage * TKS + sub * 32;
         if (kb < k1) {  // block-uniform
-          bf16x8 a[DK];
+          bf16x8 a[NFR];
           KS::load_a(lds[buf], sub, r, h, a);
 #pragma unroll
           for (int qb = 0; qb < kQB; ++qb) {
-            f32x16 acc = splat16(0.f);
-#pragma unroll
-            for (int s = 0; s < DK; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qb][s], acc, 0, 0, 0);
+            f32x16 acc = tile_chain<DK, SP>(a, bq[qb], splat16(0.f));
             if (kb + 32 > k1) mask_tail(acc, kb + 4 * h, k1);
             const float t = tile_max(acc);
             if (__any(t >= thr[qb])) {                    // rare
@@ -902,6 +975,16 @@ int slots_for(int dtype, int D) {
   return c;
 }
 
+int slots_split3(int sp) {
+  static int cache[5] = {0, 0, 0, 0, 0};
+  int& c = cache[sp];
+  if (c == 0)
+    c = sp == 1 ? resident_slots(corr_bf16_direct_kernel<3, kQB, false, 3, 1>)
+      : sp == 2 ? resident_slots(corr_bf16_direct_kernel<6, kQB, false, 6, 2>)
+                : resident_slots(corr_bf16_direct_kernel<12, kQB, false, 12, 4>);
+  return c;
+}
+
 // carve the workspace for the worst plan the call can take (the split bound does not depend on the device)
 size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   const int qblocks = (P + kWaves * kQB * 32 - 1) / (kWaves * kQB * 32);
@@ -935,7 +1018,25 @@ size_t carve_split(isr::Workspace& w, int P, int N, uint16_t** q2, uint16_t** k2
   return carve(w, P, N, ISR_DTYPE_BF16_LOG2, o);
 }
 
-constexpr int kSplitMaxD = 16;
+constexpr int kSplitMaxD = 16;    // round-3 form of the split route (96-wide rows on the generic direct kernel)
+constexpr int kSplit3MaxD = 64;   // three-plane form: SP = 1, 2, 4 blocks per plane
+
+// the three-plane split route: the two (rows, 48 SP) bf16 images, then a bf16 workspace
+size_t carve_split3(isr::Workspace& w, int P, int N, int SP, uint16_t** q3, uint16_t** k3, CorrWs* o) {
+  *q3 = w.take<uint16_t>((size_t)P * 48 * SP);
+  *k3 = w.take<uint16_t>((size_t)N * 48 * SP);
+  return carve(w, P, N, ISR_DTYPE_BF16_LOG2, o);
+}
+
+// which form an f32 call takes: 0 the f32-MFMA chain kernel, -1 the round-3 split (D <= 16), SP > 0 the three-plane split.
+// ISR_TUNE_K1_F32_CHAIN: 0 default (D <= 16: round-3 split, D <= 64: three planes), 1 chain kernel everywhere,
+// 2 three planes for D <= 16 as well (SP = 1).
+int f32_route(int D) {
+  const int t = isr::tuning(ISR_TUNE_K1_F32_CHAIN);
+  if (t == 1 || D > kSplit3MaxD) return 0;
+  if (D <= kSplitMaxD) return t == 2 ? 1 : -1;
+  return D <= 32 ? 2 : 4;
+}
 
 }  // namespace
 
@@ -948,6 +1049,12 @@ extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype
     isr::Workspace w2(nullptr, 0);
     uint16_t *q2, *k2;
     const size_t split = carve_split(w2, P, N, &q2, &k2, &o) + 256;
+    if (split > bytes) bytes = split;
+  }
+  if (dtype == ISR_DTYPE_F32 && D <= kSplit3MaxD) {                // the three-plane route (any knob setting: the size is a function of the shape)
+    isr::Workspace w3(nullptr, 0);
+    uint16_t *q3, *k3;
+    const size_t split = carve_split3(w3, P, N, D <= 0 ? 4 : D <= 16 ? 1 : D <= 32 ? 2 : 4, &q3, &k3, &o) + 256;
     if (split > bytes) bytes = split;
   }
   return bytes;
@@ -997,11 +1104,13 @@ extern "C" int isr_corr_argmax_recheck_count_f32(const void* ws_, size_t ws_byte
   ISR_REQUIRE(ws_ && count_host && P > 0 && N > 0 && D > 0, "isr_corr_argmax_recheck_count_f32: bad argument");
   ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, D, ISR_DTYPE_F32), "isr_corr_argmax_recheck_count_f32: workspace too small");
   *count_host = -1;
-  if (D > kSplitMaxD || isr::tuning(ISR_TUNE_K1_F32_CHAIN) != 0) return ISR_OK;
+  const int route = f32_route(D);
+  if (route == 0) return ISR_OK;
   isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
   uint16_t *q2, *k2;
   CorrWs ws;
-  carve_split(w, P, N, &q2, &k2, &ws);
+  if (route < 0) carve_split(w, P, N, &q2, &k2, &ws);
+  else carve_split3(w, P, N, route, &q2, &k2, &ws);
   hipStream_t stream = isr::as_stream(stream_);
   ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.rcount, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   ISR_CHECK_HIP(hipStreamSynchronize(stream));
@@ -1012,12 +1121,14 @@ namespace {
 
 // the bf16 kernels of one call (direct kernel, per-query fallback, finalize, exact recheck, merge).  f32.q != nullptr: the
 // split-f32 route — Q / K are the 128-wide split images, the recheck decides by the f32 chain of the original rows.
+// sp > 0: the three-plane split — Q / K are (rows, 48 sp) plane images, D = split_deff(sp) (the margin test's bound).
 int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int ldq, int ldk, bool log2, const CorrPlan& p,
-                const CorrWs& ws, int32_t* idx, float* logp, float* lse, F32Rows f32, float kn_inflate, hipStream_t stream) {
+                const CorrWs& ws, int32_t* idx, float* logp, float* lse, F32Rows f32, float kn_inflate, hipStream_t stream,
+                int sp = 0) {
   const dim3 grid(p.qblocks, p.nsplit);
   const int fin_blocks = (P + 255) / 256;
   const int fin_bf16 = (p.nsplit == 1 && fin_blocks > kFallbackGrid) ? kFallbackGrid : fin_blocks;   // one key range: list-driven
-  ISR_REQUIRE(D == 16 || D == 32 || D == 64 || D == 128,
+  ISR_REQUIRE(sp != 0 || D == 16 || D == 32 || D == 64 || D == 128,
               "isr_corr_argmax(bf16): D=%d must be 16, 32, 64 or 128 (zero-pad the columns)", D);
   ISR_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ((uintptr_t)q % 16 == 0) && ((uintptr_t)k % 16 == 0),
               "isr_corr_argmax(bf16): rows must be 16-byte aligned (ldq=%d ldk=%d)", ldq, ldk);
@@ -1027,7 +1138,7 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
   const int cgrid = (int)(((long)p.qblocks * p.nchunks < kFallbackGrid) ? (long)p.qblocks * p.nchunks : kFallbackGrid);   // fallback: strides over listed blocks x chunks
   const dim3 rgrid(16 * kRSplitGrid);   // workgroups = key ranges (by list length, <= 64) x slots striding over the groups of 256 listed queries
   const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
-  corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, kn_inflate, ws);
+  corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, sp ? 16 * sp : D, ldk, kn_inflate, ws);   // three planes: |k1|^2
 #define ISR_LAUNCH_BF16(DKv)                                                                                  \
   do {                                                                                                        \
     if (log2) {                                                                                               \
@@ -1047,6 +1158,23 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     }                                                                                                         \
     corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);  \
   } while (0)
+#define ISR_LAUNCH_SPLIT3(SPv)                                                                                                    \
+  do {                                                                                                                            \
+    corr_bf16_direct_kernel<3 * SPv, kQB, false, 3 * SPv, SPv><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, \
+                                                                                               ws, idx, logp, lse);                \
+    corr_bf16_kernel<3 * SPv, true, SPv><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,         \
+                                                                          p.nchunks, ws);                                          \
+    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);         \
+    corr_recheck_kernel<3 * SPv, SPv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);            \
+  } while (0)
+  if (sp) {          // three-plane split route (log2 domain, f32 originals decide the recheck)
+    switch (sp) {
+      case 1: ISR_LAUNCH_SPLIT3(1); break;
+      case 2: ISR_LAUNCH_SPLIT3(2); break;
+      default: ISR_LAUNCH_SPLIT3(4); break;
+    }
+  } else
+#undef ISR_LAUNCH_SPLIT3
   if (f32.q) {       // split-f32 route: 128-wide rows whose last two blocks are zero, log2 domain
     corr_bf16_direct_kernel<8, kQB, false, 6><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws, idx, logp, lse);
     corr_bf16_kernel<8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
@@ -1081,7 +1209,30 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     return ISR_ERR_WORKSPACE;
   }
   hipStream_t stream = isr::as_stream(stream_);
-  if (dtype == ISR_DTYPE_F32 && D <= kSplitMaxD && isr::tuning(ISR_TUNE_K1_F32_CHAIN) == 0) {
+  const int route = dtype == ISR_DTYPE_F32 ? f32_route(D) : 0;
+  if (route > 0) {
+    // three-plane split route: exact indices and f32-accurate sums from the bf16 matrix cores at D <= 64 (RowFrags' header)
+    const int sp = route;
+    isr::Workspace w(ws_, ws_bytes);
+    uint16_t *q3, *k3;
+    CorrWs ws;
+    carve_split3(w, P, N, sp, &q3, &k3, &ws);
+    const CorrPlan p = make_plan(P, N, slots_split3(sp), kWaves * kQB * 32);
+    const float* qf = static_cast<const float*>(Q);
+    const float* kf = static_cast<const float*>(K);
+    const unsigned gq = (unsigned)(((long)P * 16 * sp + 255) / 256), gk = (unsigned)(((long)N * 16 * sp + 255) / 256);
+    switch (sp) {
+      case 1: corr_split3_f32_kernel<1><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3);
+              corr_split3_f32_kernel<1><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3); break;
+      case 2: corr_split3_f32_kernel<2><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3);
+              corr_split3_f32_kernel<2><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3); break;
+      default: corr_split3_f32_kernel<4><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3);
+               corr_split3_f32_kernel<4><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3); break;
+    }
+    return launch_bf16(q3, k3, P, N, split_deff(sp), 48 * sp, 48 * sp, true, p, ws, idx, logp, lse, F32Rows{qf, kf, ldq, ldk, D},
+                       1.f, stream, sp);
+  }
+  if (route < 0) {
     // split route: exact indices and f32-accurate sums from the bf16 matrix cores (corr_split_f32_kernel's header)
     isr::Workspace w(ws_, ws_bytes);
     uint16_t *q2, *k2;

@@ -50,7 +50,9 @@ __device__ __forceinline__ float tile_max(const f32x16& acc) {
 //   element.  Maxima are raw logits in either case.
 // DKU <= DK: the 16-wide blocks that can be non-zero (the split-f32 route stores 8 blocks of which the last two are zero
 // padding: their MFMAs would add exact zeros, so they are not issued — same bits, 6 instead of 8 matrix instructions per tile).
-template <int DK, int QB, bool NAT, int DKU = DK>
+// SP > 0: split rows (RowFrags / tile_chain in corr_argmax.hip): three planes of SP blocks per operand row, 6 SP matrix
+// instructions per tile; DK = 3 SP, DKU unused.
+template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0>
 __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
@@ -58,18 +60,28 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   // 16-byte chunks staged per key row: all 2 DK of them, or — DKU < DK, the split-f32 route's rows with trailing zero blocks —
   // only the 2 DKU that can be non-zero (12 for DKU = 6: a quarter less key traffic, which is what bounds that route: its
   // 256-byte key rows do not fit the L2, profiles/r03_estimate_pose_hbm_traffic.txt).
-  constexpr int NCH = 2 * DKU;
+  using RF = RowFrags<DKU, SP>;
+  constexpr int NFR = RF::NFR, NMF = RF::NMF;
+  static_assert(SP == 0 || DK == 3 * SP, "split rows: DK counts the 3 SP blocks of a row");
+  constexpr int NCH = 2 * NFR;
   constexpr bool POW2 = (NCH & (NCH - 1)) == 0;
   constexpr int RPB = (NCH >= 16) ? 1 : 16 / NCH;
-  constexpr int CHUNKS = kTK * NCH;
+  constexpr int TKS = (NCH <= 16) ? kTK : 64;        // keys per LDS stage (24-chunk rows: two 24 KB buffers, two workgroups per CU)
+  constexpr int CSTAGES = kChunk / TKS;              // stages per canonical chunk
+  constexpr int CHUNKS = TKS * NCH;
   constexpr int NLD = CHUNKS / kThreads;
   static_assert(CHUNKS % kThreads == 0, "every thread stages the same number of chunks");
-  static_assert(POW2 || NCH == 12, "LDS chunk placement is written for a power of two or 12 chunks per row");
+  static_assert(SP != 0 || POW2 || NCH == 12, "LDS chunk placement is written for a power of two or 12 chunks per row");
+  static_assert(NCH <= 24, "wider rows need a shorter stage");
   __shared__ uint4 lds[2][CHUNKS];
   // where chunk c of key row `row` lives inside the row's NCH slots: an XOR swizzle for power-of-two rows; for 12-chunk rows a
   // rotation by (row / 4) % 4 — a row starts 12 row (mod 16) sixteen-byte banks in, which only depends on row % 4, and the
   // rotation separates the four rows of every such class: the 16 lanes of a ds_read_b128 phase hit 16 distinct banks.
-  auto slot = [](int row, int c) { return POW2 ? (c ^ ((row / RPB) & (NCH - 1))) : (c + ((row >> 2) & 3)) % NCH; };
+  // split rows: key_slot<NCH, SP> (XOR inside each plane, corr_argmax.hip).
+  auto slot = [](int row, int c) {
+    if constexpr (SP != 0) return key_slot<NCH, SP>(row, c);
+    else return POW2 ? (c ^ ((row / RPB) & (NCH - 1))) : (c + ((row >> 2) & 3)) % NCH;
+  };
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
@@ -80,14 +92,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   const long long t_sclk0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
   const long long t_ref0 = probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
 
-  bf16x8 bq[QB][DKU];
+  bf16x8 bq[QB][NFR];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     int row = q0 + qb * 32 + r;
     row = row < P ? row : P - 1;
     const uint16_t* src = Q + (size_t)row * ldq + 8 * h;
 #pragma unroll
-    for (int s = 0; s < DKU; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+    for (int s = 0; s < NFR; ++s) bq[qb][s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
   }
   // ONE key range (gridDim.y == 1: every launch whose query blocks alone fill the chip): this workgroup sees
   // every chunk of its queries, adds the chunk sums in f64 in ascending order itself — the very operations
@@ -99,7 +111,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   for (int qb = 0; qb < QB; ++qb) {
     float n2 = 0.f;
 #pragma unroll
-    for (int s = 0; s < DKU; ++s)
+    for (int s = 0; s < RF::NQN; ++s)          // split rows: plane 1 (split_deff covers what the other planes add)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float v = __uint_as_float((uint32_t)(uint16_t)bq[qb][s][e] << 16);
@@ -120,6 +132,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     bool nonzero = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) nonzero |= qn2[qb] != 0.f;
+    if constexpr (SP != 0) {                    // an f32 number too small for plane 1 still lives in planes 2 and 3
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+        for (int s = SP; s < NFR; ++s)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) nonzero |= (bq[qb][s][e] & 0x7FFF) != 0;
+    }
     if (!__syncthreads_or(nonzero ? 1 : 0)) {
       if (whole) {
         const float kn2z = kn2_max(ws);
@@ -127,7 +147,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         for (int qb = 0; qb < QB; ++qb) {
           const int q = q0 + qb * 32 + r;
           if (h == 0 && q < P)
-            corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, 16 * DK, 0.f, kn2z, ws, idx_out, logp_out, lse_out);
+            corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, SP ? split_deff(SP) : 16 * DK, 0.f, kn2z, ws, idx_out, logp_out, lse_out);
         }
       } else {
         const int zc0 = split * range_chunks;
@@ -158,8 +178,8 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   const int c0 = split * range_chunks;                 // first canonical chunk of this key range
   const int k0 = c0 * kChunk;
   const int k1 = min(N, k0 + range_chunks * kChunk);
-  const int nstage = (k1 - k0 + kTK - 1) / kTK;
-  const int nfull = (k1 - k0) / kTK;                  // stages whose kTK keys all exist
+  const int nstage = (k1 - k0 + TKS - 1) / TKS;
+  const int nfull = (k1 - k0) / TKS;                  // stages whose TKS keys all exist
 
   // Key rows come through a raw buffer descriptor over this key range: one 32-bit offset per load,
   // and rows beyond the range read as zero in hardware (no predicates in the loop).
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   }
   uint4 stg[NLD];
   auto gload = [&](int stage) {
-    const int so = stage * kTK * ldk * 2;
+    const int so = stage * TKS * ldk * 2;
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
       const auto v = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[i] + so, 0, 0);
@@ -191,11 +211,13 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   // A fragments of key sub-tile `sub` of LDS buffer `buf`.  One register set: a fragment's ds_read
   // for the NEXT sub-tile is issued right behind the last MFMA that reads the current one, i.e. one
   // whole item (~300 cycles) before the MFMA that needs it.
-  bf16x8 a[DKU];
+  bf16x8 a[NFR];
   auto load_a = [&](int buf, int sub) {
     const int row = sub * 32 + r;
 #pragma unroll
-    for (int s = 0; s < DKU; ++s) {
+    for (int i = 0; i < NFR; ++i) {
+      // split rows: in the order tile_chain lets go of the planes — k3, then k2, then k1
+      const int s = SP ? (2 - i / (SP ? SP : 1)) * SP + i % (SP ? SP : 1) : i;
       const uint4 v = lds[buf][row * NCH + slot(row, 2 * s + h)];
       a[s] = *reinterpret_cast<const bf16x8*>(&v);
     }
@@ -204,16 +226,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   // Software pipeline: item w's epilogue runs under item w + 1's MFMAs.  The stage barrier sits two
   // items before the stage's end (every LDS read of the stage has been issued by then), so the next
   // stage's first fragments are a full item ahead too.
-  constexpr int NSUB = kTK / 32, NW = NSUB * QB;
+  constexpr int NSUB = TKS / 32, NW = NSUB * QB;
   static_assert(QB == 2 && NSUB % 2 == 0, "item schedule below is written for two query blocks per wave");
   gload(0);
   lwrite(0);
   __syncthreads();
   load_a(0, 0);
   f32x16 acc[2];
-  acc[0] = splat16(0.f);
-#pragma unroll
-  for (int s = 0; s < DKU; ++s) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[0][s], acc[0], 0, 0, 0);
+  acc[0] = tile_chain<DKU, SP>(a, bq[0], splat16(0.f));
 
   auto stage_body = [&](int stage, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
@@ -230,14 +250,12 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         __syncthreads();
 #endif
       }
-      const int kb = k0 + stage * kTK + sub * 32;
+      const int kb = k0 + stage * TKS + sub * 32;
       if (FULL || kb < k1) {  // block-uniform
         if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], kb + 4 * h, k1);
         const f32x16& cur = acc[w & 1];
         f32x16& nxt = acc[(w + 1) & 1];
-        nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], bq[qbn][0], splat16(0.f), 0, 0, 0);
-#pragma unroll
-        for (int s = 1; s < DKU; ++s) nxt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bq[qbn][s], nxt, 0, 0, 0);
+        nxt = tile_chain<DKU, SP>(a, bq[qbn], splat16(0.f));
         if (qb == 0) {                                    // the chain above was the fragments' last reader
           if (w == NW - 2) { if (has_next) load_a(buf ^ 1, 0); }
           else load_a(buf, sub + 1);
@@ -266,11 +284,13 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         // ties the item's results to a fixed point of the instruction stream: a stage is one basic
         // block, and without it instruction selection sinks all eight epilogues below all eight MFMA
         // chains (eight tiles live, 243 VGPRs, nothing overlapped).
-        constexpr int G = ((NAT ? 60 : 44) + DKU - 1) / DKU;
+        constexpr int G = ((NAT ? 60 : 44) + NMF - 1) / NMF;
 #pragma unroll
-        for (int s = 0; s < DKU; ++s) {
+        for (int s = 0; s < NMF; ++s) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (qb == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // this fragment's next ds_read
+          // this fragment's next ds_read; split rows: behind the last reader of a k3, k2 or k1 fragment (load_a's order)
+          const bool frees = SP == 0 || s < SP || (s >= 2 * SP && s < 3 * SP) || s >= 5 * SP;
+          if (qb == 0 && frees) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
         }
         asm volatile("" : "+v"(nxt), "+v"(st[qb].l), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   for (int qb = 0; qb < QB; ++qb) over[qb] = false;
   int stage = 0;
   for (int c = c0; stage < nstage; ++c) {
-    const int send = min(nstage, stage + kChunkStages);
+    const int send = min(nstage, stage + CSTAGES);
     const int sfull = min(nfull, send);
     for (; stage < sfull; ++stage) stage_body(stage, std::true_type{});
     if (stage < send) { stage_body(stage, std::false_type{}); ++stage; }   // only a range's last stage is partial
@@ -312,14 +332,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     int cand = T;
     float cmax = -__builtin_inff(), c2 = -__builtin_inff();
     unsigned long long todo = __ballot(true);
-    auto fetch = [&](int kb, bf16x8 (&dst)[DKU]) {
+    auto fetch = [&](int kb, bf16x8 (&dst)[NFR]) {
       int row = kb + r;
       row = row < N ? row : N - 1;
       const uint16_t* src = K + (size_t)row * ldk + 8 * h;
 #pragma unroll
-      for (int s = 0; s < DKU; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
+      for (int s = 0; s < NFR; ++s) dst[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
     };
-    bf16x8 a0[DKU], a1[DKU];
+    bf16x8 a0[NFR], a1[NFR];
     int kb_cur = __shfl(T, __ffsll(todo) - 1, 64);
     fetch(kb_cur, a0);
     while (true) {                                        // wave-uniform trip count (<= 32)
@@ -330,9 +350,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         kb_nxt = __shfl(T, __ffsll(todo) - 1, 64);
         fetch(kb_nxt, a1);                                // in flight under this tile's MFMAs
       }
-      f32x16 c = splat16(0.f);
-#pragma unroll
-      for (int s = 0; s < DKU; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[s], bq[qb][s], c, 0, 0, 0);
+      f32x16 c = tile_chain<DKU, SP>(a0, bq[qb], splat16(0.f));
       if (kb_cur + 32 > k1) mask_tail(c, kb_cur + 4 * h, k1);
       if (T == kb_cur) {
         // the two largest of this lane's 16 rows (with multiplicity) and the lowest row of the largest
@@ -350,7 +368,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       }
       if (!more) break;
 #pragma unroll
-      for (int s = 0; s < DKU; ++s) a0[s] = a1[s];
+      for (int s = 0; s < NFR; ++s) a0[s] = a1[s];
       kb_cur = kb_nxt;
     }
     // runner-up of the query inside this key range.  The lane that owns the winner contributes its
@@ -401,7 +419,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       if (over[qb]) ws.qn2[q] = qn2[qb];
     }
     if (!over[qb])
-      corr_finish<NAT ? 2 : 1>(q, st[qb].m, st[qb].m2, st[qb].tb, false, st[qb].L, 0.0, 16 * DK, qn2[qb], kn2, ws, idx_out,
-                               logp_out, lse_out);
+      corr_finish<NAT ? 2 : 1>(q, st[qb].m, st[qb].m2, st[qb].tb, false, st[qb].L, 0.0, SP ? split_deff(SP) : 16 * DK, qn2[qb], kn2,
+                               ws, idx_out, logp_out, lse_out);
   }
 }

@@ -272,6 +272,23 @@ def corr_recheck_count() -> int:
     return int(out.value)
 
 
+def corr_recheck_count_f32(D: int) -> int:
+    """Diagnostics: the length of the f32-chain recheck list of the last f32 corr_argmax call with D columns, under the
+    knob setting still in force (-1 when that call took the f32-MFMA chain kernel).  Synchronises the current stream."""
+    import ctypes
+    if _last_corr is None:
+        return -1
+    ws, P, N, dtype, dev = _last_corr
+    if dtype != _capi.DTYPE_F32:
+        return -1
+    out = ctypes.c_int32(-1)
+    with torch.cuda.device(dev):
+        rc = lib().isr_corr_argmax_recheck_count_f32(ptr(ws), ws.numel(), P, N, int(D), ctypes.addressof(out),
+                                                     current_stream(dev))
+    check(rc, "isr_corr_argmax_recheck_count_f32")
+    return int(out.value)
+
+
 def select_top(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500, n_dev: torch.Tensor | None = None):
     """isr_select_top: keep (P,) i32 (first M entries valid, ascending), M_dev (1,) i32, thr (1,) f32.
     n_dev: (1,) i32 on the device — only the first n_dev values are the input (isr_select_top_dev)."""

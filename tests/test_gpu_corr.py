@@ -454,6 +454,92 @@ def test_corr_f32_split_route_equals_chain_route(cuda0, oracle_lib, P, N, D):
                 assert torch.equal(a, b[lo:lo + n])
 
 
+@pytest.mark.parametrize("P,N,D,chain", [(300, 31, 17, 0), (1000, 4097, 24, 0), (777, 12289, 33, 0), (5000, 20000, 64, 0),
+                                         (513, 4096, 40, 0), (6000, 33000, 64, 0), (2000, 9000, 32, 0), (64, 128, 48, 0),
+                                         (1000, 4097, 12, 2), (5000, 20000, 16, 2), (777, 12289, 5, 2)])
+def test_corr_f32_three_plane_route_equals_chain_route(cuda0, oracle_lib, P, N, D, chain):
+    """f32 descriptors with 16 < D <= 64 (round 4): each operand row kept as its three bf16 planes x1 | x2 | x3, the six
+    plane pairs down to 2^-16 issued as 6 D/16 bf16 matrix instructions per tile from 3 + 3 D/16 fragments, margin test with
+    the bound split_deff() covers, recheck by the f32 fmaf chain of the original rows.  Indices = the f32-MFMA chain kernel's
+    (ISR_TUNE_K1_F32_CHAIN = 1) = the oracle's, with duplicate keys (one pair across a canonical chunk boundary), an exact
+    tie, zero rows, a spiked and a negated query; logp / lse within 3e-6 of the chain kernel's relative to the logit scale;
+    slices at odd offsets and forced key-range counts reproduce their rows bit for bit.  chain = 2: the same three-plane
+    form for D <= 16 (SP = 1) instead of round 3's 96-wide rows."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    g = torch.Generator(device=cuda0).manual_seed(P + N + D)
+    K = torch.randn(N, D, device=cuda0, generator=g) * (2.0 * (12.0 / max(D, 12)) ** 0.5)      # |k|^2 ~ 48 whatever D
+    K[N // 2] = K[0]
+    if N > 4200:
+        K[4100] = K[3]
+    gt = torch.randint(N, (P,), device=cuda0, generator=g)
+    Q = K[gt] * 1.5 + 0.5 * (12.0 / max(D, 12)) ** 0.5 * torch.randn(P, D, device=cuda0, generator=g)
+    Q[::7] = 0.0
+    Q[1] *= 20.0
+    Q[2] = -Q[2]
+    Q[3] = K[0] * 1.5                                                      # exact tie between key 0 and its duplicate
+    if P >= 1000:
+        Q[512:768] = 0.0                                                   # one whole workgroup of zero rows
+    with ops.tuning(k1_f32_chain=1):
+        want = ops.corr_argmax(Q, K, want_lse=True)
+    with ops.tuning(k1_f32_chain=chain):
+        got = ops.corr_argmax(Q, K, want_lse=True)
+        rechecked = ops.corr_recheck_count_f32(D)
+    assert torch.equal(got[0], want[0])
+    assert 0 <= rechecked < max(64, P // 4)          # the margin test certifies the bulk
+    scale = 1.0 + float(want[2].abs().max())
+    assert float((got[1] - want[1]).abs().max()) < 3e-6 * scale and float((got[2] - want[2]).abs().max()) < 3e-6 * scale
+    o = oracle_lib.corr_argmax_f32(Q[:256].cpu().numpy(), K.cpu().numpy())
+    assert np.array_equal(got[0][:256].cpu().numpy(), o["idx"])
+    if P > 300:
+        Kn = 5.0 * K / K.norm(dim=1, keepdim=True)
+        Qs = 1.2 * Kn[gt] + 0.3 * (12.0 / max(D, 12)) ** 0.5 * torch.randn(P, D, device=cuda0, generator=g)
+        Qs[::5] = 0.0
+        with ops.tuning(k1_f32_chain=chain):
+            full = ops.corr_argmax(Qs, Kn, want_lse=True)
+            assert float(full[2].max()) * 1.4427 < 100.0
+            for lo, n in ((37, 200), (0, 300)):
+                sl = ops.corr_argmax(Qs[lo:lo + n], Kn, want_lse=True)
+                for a, b in zip(sl, full):
+                    assert torch.equal(a, b[lo:lo + n])
+            for ns in (1, 2, 3):
+                with ops.tuning(k1_split=ns):
+                    sp = ops.corr_argmax(Qs, Kn, want_lse=True)
+                for a, b in zip(sp, full):
+                    assert torch.equal(a, b), ns
+        with ops.tuning(k1_f32_chain=1):
+            ref = ops.corr_argmax(Qs, Kn, want_lse=True)
+        assert torch.equal(full[0], ref[0])
+
+
+@pytest.mark.parametrize("D", [12, 32])
+def test_corr_f32_chain_kernel_all_zero_workgroups(cuda0, oracle_lib, D):
+    """corr_f32_kernel's early exit for a workgroup whose 256 queries are all zero (ISR_TUNE_K1_F32_CHAIN = 1: since the split
+    routes became the default nothing else reaches it): with one key range and with several (ISR_TUNE_K1_SPLIT 1, 2, 3) the
+    zero workgroups' outputs — key 0, logp = lse-consistent -ln N — are bit for bit those of a zero row inside a mixed
+    workgroup, and the non-zero rows are the oracle's."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    g = torch.Generator(device=cuda0).manual_seed(40 + D)
+    P, N = 1536, 9000
+    K = torch.randn(N, D, device=cuda0, generator=g) * (12.0 / D) ** 0.5
+    Q = 1.5 * K[torch.randint(N, (P,), device=cuda0, generator=g)] + 0.3 * torch.randn(P, D, device=cuda0, generator=g)
+    Q[256:768] = 0.0                     # two whole workgroups
+    Q[1000] = 0.0                        # a zero row in a mixed workgroup
+    outs = []
+    for ns in (1, 2, 3):
+        with ops.tuning(k1_f32_chain=1, k1_split=ns):
+            outs.append(ops.corr_argmax(Q, K, want_lse=True))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a, b)
+    idx, logp, lse = outs[0]
+    assert int(idx[256:768].abs().max()) == 0 and int(idx[1000]) == 0
+    assert torch.equal(logp[256:768], logp[1000].expand(512)) and torch.equal(lse[256:768], lse[1000].expand(512))
+    assert abs(float(logp[1000]) + np.log(N)) < 1e-5 and abs(float(lse[1000]) - np.log(N)) < 1e-5
+    rows = np.r_[0:64, 250:262, 760:776, 995:1005]
+    o = oracle_lib.corr_argmax_f32(Q[rows].cpu().numpy(), K.cpu().numpy())
+    assert np.array_equal(idx[rows].cpu().numpy(), o["idx"])
+
+
 @pytest.mark.parametrize("kind", ["bf16_log2", "f32"])
 def test_corr_result_is_independent_of_the_number_of_key_ranges(cuda0, kind):
     """The planner's choice of key ranges (cost model; ISR_TUNE_K1_SPLIT forces it) changes which workgroup computes a chunk,
