@@ -185,41 +185,72 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   // and rows beyond the range read as zero in hardware (no predicates in the loop).
   const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<uint16_t*>(K + (size_t)k0 * ldk), 0, (k1 - k0) * ldk * 2, 0x00020000);
+  // Split rows go global -> LDS without a register stop (buffer_load ... lds: a wave instruction fills 64 consecutive
+  // 16-byte units of the stage image, so the swizzle sits on the SOURCE side — unit u of the image takes the chunk that
+  // belongs there, key_slot being its own inverse inside a plane): 24 staging registers and the ds_write pass less in a
+  // kernel whose 24 + 12 operand fragments leave none to spare.
+  constexpr bool DMA = SP != 0;
   int koff[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
     const int ci = tid + i * kThreads;
-    koff[i] = ((ci / NCH) * ldk + 8 * (ci % NCH)) * 2;
+    koff[i] = DMA ? ((ci / NCH) * ldk + 8 * slot(ci / NCH, ci % NCH)) * 2 : ((ci / NCH) * ldk + 8 * (ci % NCH)) * 2;
   }
-  uint4 stg[NLD];
+  uint4 stg[DMA ? 1 : NLD];
   auto gload = [&](int stage) {
     const int so = stage * TKS * ldk * 2;
+    if constexpr (DMA) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass of this template rejects the LDS address-space cast (and then drops the kernel's stub)
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const auto v = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[i] + so, 0, 0);
-      stg[i] = *reinterpret_cast<const uint4*>(&v);
+      for (int i = 0; i < NLD; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)&lds[stage & 1][i * kThreads + wave * 64],
+                                                 16, koff[i] + so, 0, 0, 0);
+#endif
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[i] + so, 0, 0);
+        stg[i] = *reinterpret_cast<const uint4*>(&v);
+      }
     }
   };
   auto lwrite = [&](int buf) {
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int ci = tid + i * kThreads;
-      const int row = ci / NCH, c = ci % NCH;
-      lds[buf][row * NCH + slot(row, c)] = stg[i];
+      for (int i = 0; i < NLD; ++i) {
+        const int ci = tid + i * kThreads;
+        const int row = ci / NCH, c = ci % NCH;
+        lds[buf][row * NCH + slot(row, c)] = stg[i];
+      }
     }
   };
   // A fragments of key sub-tile `sub` of LDS buffer `buf`.  One register set: a fragment's ds_read
   // for the NEXT sub-tile is issued right behind the last MFMA that reads the current one, i.e. one
   // whole item (~300 cycles) before the MFMA that needs it.
   bf16x8 a[NFR];
-  auto load_a = [&](int buf, int sub) {
-    const int row = sub * 32 + r;
+  // split rows: block j of every plane sits at the lane's rb[j] plus a compile-time offset (the XOR term of key_slot depends
+  // on r alone: 32 rows are a multiple of its period) — one address register per block, the rest in the ds_read's immediate
+  int rb[SP ? SP : 1];
+  if constexpr (SP != 0) {
 #pragma unroll
-    for (int i = 0; i < NFR; ++i) {
-      // split rows: in the order tile_chain lets go of the planes — k3, then k2, then k1
-      const int s = SP ? (2 - i / (SP ? SP : 1)) * SP + i % (SP ? SP : 1) : i;
-      const uint4 v = lds[buf][row * NCH + slot(row, 2 * s + h)];
-      a[s] = *reinterpret_cast<const bf16x8*>(&v);
+    for (int j = 0; j < SP; ++j) rb[j] = r * NCH + slot(r, 2 * j + h);
+  }
+  auto load_a = [&](int buf, int sub) {
+    if constexpr (SP != 0) {
+      const uint4* lp = &lds[0][0] + buf * CHUNKS;
+#pragma unroll
+      for (int i = 0; i < NFR; ++i) {
+        const int pl = 2 - i / SP, j = i % SP;        // in the order tile_chain lets go of the planes: k3, then k2, then k1
+        const uint4 v = lp[rb[j] + sub * 32 * NCH + pl * 2 * SP];
+        a[pl * SP + j] = *reinterpret_cast<const bf16x8*>(&v);
+      }
+    } else {
+      const int row = sub * 32 + r;
+#pragma unroll
+      for (int s = 0; s < NFR; ++s) {
+        const uint4 v = lds[buf][row * NCH + slot(row, 2 * s + h)];
+        a[s] = *reinterpret_cast<const bf16x8*>(&v);
+      }
     }
   };
 
@@ -230,6 +261,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   static_assert(QB == 2 && NSUB % 2 == 0, "item schedule below is written for two query blocks per wave");
   gload(0);
   lwrite(0);
+  if constexpr (DMA) { if (nstage > 1) gload(1); }     // DMA: stage s + 2 is requested in the last item of stage s
   __syncthreads();
   load_a(0, 0);
   f32x16 acc[2];
@@ -239,7 +271,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     constexpr bool FULL = decltype(full_tag)::value;
     const int buf = stage & 1;
     const bool has_next = stage + 1 < nstage;
-    if (has_next) gload(stage + 1);
+    if constexpr (!DMA) { if (has_next) gload(stage + 1); }
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
       const int sub = w / QB, qb = w % QB;
@@ -250,7 +282,78 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         __syncthreads();
 #endif
       }
+      // DMA: every wave is past the barrier above, so nobody reads this stage's buffer any more: the stage after the next
+      // goes into it now, a whole stage ahead of the barrier that publishes it (the compiler drains the DMA counter in front
+      // of the next ds_read, an item away)
+      if constexpr (DMA) { if (w == NW - 1 && stage + 2 < nstage) gload(stage + 2); }
       const int kb = k0 + stage * TKS + sub * 32;
+      if constexpr (SP != 0) {
+        // Split rows: an item is six phases — the six plane pairs of tile_chain, SP matrix instructions each — fenced by
+        // sched_barriers; each phase carries its share of the previous item's epilogue (the maxima, then four exp + add at
+        // a time, in register order: the canonical sum) and, in the items that read fragments last, the ds_reads of the
+        // key plane it has just let go of (k3 after phase 0, k2 after phase 2, k1 after phase 5).
+        if (FULL || kb < k1) {  // block-uniform
+          if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], kb + 4 * h, k1);
+          const f32x16& cur = acc[w & 1];
+          f32x16& nxt = acc[(w + 1) & 1];
+          const bool reload = qb == 0 && (w != NW - 2 || has_next);
+          const int rbuf = (w == NW - 2) ? (buf ^ 1) : buf, rsub = (w == NW - 2) ? 0 : sub + 1;
+          auto reads = [&](int pl) {
+            if (reload) {
+              const uint4* lp = &lds[0][0] + rbuf * CHUNKS;
+#pragma unroll
+              for (int j = 0; j < SP; ++j) {
+                const uint4 v = lp[rb[j] + rsub * 32 * NCH + pl * 2 * SP];
+                a[pl * SP + j] = *reinterpret_cast<const bf16x8*>(&v);
+              }
+            }
+          };
+          float l = st[qb].l;
+          auto exps = [&](int i0) {
+#pragma unroll
+            for (int i = i0; i < i0 + 4; ++i) l += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
+          };
+          f32x16 c = splat16(0.f);
+#pragma unroll
+          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 * SP + j], bq[qbn][j], c, 0, 0, 0);            // k3 q1
+          reads(2);
+          {
+            const float t = tile_max(cur);
+            st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);
+            st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;
+            st[qb].m = fmaxf(st[qb].m, t);
+          }
+          asm volatile("" : "+v"(c), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SP + j], bq[qbn][SP + j], c, 0, 0, 0);           // k2 q2
+          exps(0);
+          asm volatile("" : "+v"(c), "+v"(l));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SP + j], bq[qbn][j], c, 0, 0, 0);                // k2 q1
+          reads(1);
+          exps(4);
+          asm volatile("" : "+v"(c), "+v"(l));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bq[qbn][2 * SP + j], c, 0, 0, 0);            // k1 q3
+          exps(8);
+          asm volatile("" : "+v"(c), "+v"(l));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bq[qbn][SP + j], c, 0, 0, 0);                // k1 q2
+          exps(12);
+          asm volatile("" : "+v"(c), "+v"(l));
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bq[qbn][j], c, 0, 0, 0);                     // k1 q1
+          reads(0);
+          st[qb].l = l;
+          nxt = c;
+          asm volatile("" : "+v"(nxt), "+v"(st[qb].l));
+        }
+      } else
       if (FULL || kb < k1) {  // block-uniform
         if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], kb + 4 * h, k1);
         const f32x16& cur = acc[w & 1];
@@ -288,9 +391,8 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
 #pragma unroll
         for (int s = 0; s < NMF; ++s) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          // this fragment's next ds_read; split rows: behind the last reader of a k3, k2 or k1 fragment (load_a's order)
-          const bool frees = SP == 0 || s < SP || (s >= 2 * SP && s < 3 * SP) || s >= 5 * SP;
-          if (qb == 0 && frees) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          // this fragment's next ds_read
+          if (qb == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
         }
         asm volatile("" : "+v"(nxt), "+v"(st[qb].l), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
