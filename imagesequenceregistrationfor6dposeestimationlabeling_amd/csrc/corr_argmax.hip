@@ -35,7 +35,8 @@
 
 namespace {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) short;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;     // eight 16-bit operand elements (bf16, or f16 on the F16 routes)
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kThreads = 256;
@@ -68,7 +69,15 @@ struct CorrWs {
   int32_t* rlist;   // (P) queries to decide exactly
   double* rval;     // (rsplit, P) exact best value per recheck key range and list entry
   int32_t* ridx;    // (rsplit, P)
+  // launch gates (nullable): the f16-plane route of an f32 call runs unless a descriptor was too large for f16 (`skip` set by
+  // its split kernel), in which case the f32-MFMA chain kernels behind it run instead (`only`): no host round trip decides.
+  const int32_t* skip;   // leave at once when *skip != 0
+  const int32_t* only;   // leave at once when *only == 0
 };
+
+__device__ __forceinline__ bool gated_off(const CorrWs& ws) {
+  return (ws.skip && *ws.skip != 0) || (ws.only && *ws.only == 0);
+}
 
 struct LaneState {
   float m;    // running max logit
@@ -154,34 +163,54 @@ __device__ __forceinline__ LaneState merged_with_other_half(LaneState st) {
 // dropped) — issued smallest first and so that every key plane's uses are contiguous (k3 is free after SP MFMAs, k2 after
 // 3 SP: their ds_reads for the next key sub-tile start early): 6 SP MFMAs from 3 SP + 3 SP fragments, where the round-3
 // form of the route multiplied the 96-wide rows [x1 x1 x2 x2 x1 x3] . [k1 k2 k1 k2 k3 k1] with 6 + 6 fragments at D <= 16.
-template <int DK, int SP>
+// F16 (with SP > 0): the planes are f16 — x1 = f16(x), x2s = f16((x - x1) 2^11), x1s = f16(x1 2^-11) — and a tile is the
+// THREE pairs k1s q2s, k2s q1s, k1 q1 (x = x1 + x2 to 2^-22: 11 + 11 mantissa bits; the dropped k2 q2 is 2^-22 relative):
+// half the matrix instructions of the bf16 planes, which is what bounds that kernel (MFMA busy 0.87 at D = 64).  The 2^11 /
+// 2^-11 pair keeps the residual plane out of the subnormals; where x1s does become subnormal (|x1| < 2^-3) its rounding
+// error is at most 2^-25 ABSOLUTE — v_mfma_f32_32x32x16_f16 keeps subnormal inputs on gfx950 (tools/mfma_f16_denorm.hip) —
+// which the margin test carries as an extra absolute term (split_eabs).  |x| must stay below 65 504: the split kernel raises
+// a flag otherwise and the call falls through to the f32-MFMA chain kernels (CorrWs::skip / only).
+template <int DK, int SP, bool F16 = false>
 struct RowFrags {
-  static constexpr int NFR = SP ? 3 * SP : DK;     // fragments per operand row
-  static constexpr int NMF = SP ? 6 * SP : DK;     // matrix instructions per 32 x 32 tile
-  static constexpr int NQN = SP ? SP : DK;         // fragments that enter the norm of the margin test (plane 1)
+  static constexpr int NFR = SP ? 3 * SP : DK;                 // fragments per operand row
+  static constexpr int NMF = SP ? (F16 ? 3 : 6) * SP : DK;     // matrix instructions per 32 x 32 tile
+  static constexpr int NQN = SP ? SP : DK;                     // fragments that enter the norm of the margin test (plane 1)
+  // split rows, phase by phase: key plane, query plane, the key plane whose last reader the phase is (-1: none), and the
+  // slice [E0[ph], E0[ph + 1]) of the previous tile's 16 exp + add the phase carries (the maxima ride in phase 0)
+  static constexpr int NPH = F16 ? 3 : 6;
+  static constexpr int PA[6] = {2, 1, F16 ? 0 : 1, 0, 0, 0};
+  static constexpr int PB[6] = {F16 ? 1 : 0, F16 ? 2 : 1, 0, 2, 1, 0};
+  static constexpr int RD[6] = {2, F16 ? 1 : -1, F16 ? 0 : 1, -1, -1, 0};
+  static constexpr int E0[7] = {0, F16 ? 4 : 0, F16 ? 10 : 4, F16 ? 16 : 8, 12, 16, 16};
 };
 
-template <int DK, int SP>
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int DK, int SP, bool F16 = false>
 __device__ __forceinline__ f32x16 tile_chain(const bf16x8 (&a)[RowFrags<DK, SP>::NFR], const bf16x8 (&b)[RowFrags<DK, SP>::NFR],
                                              f32x16 c) {
+  using RF = RowFrags<DK, SP, F16>;
   if constexpr (SP == 0) {
 #pragma unroll
     for (int s = 0; s < DK; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], c, 0, 0, 0);
   } else {
 #pragma unroll
-    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 * SP + j], b[j], c, 0, 0, 0);            // k3 q1
+    for (int ph = 0; ph < RF::NPH; ++ph)
 #pragma unroll
-    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SP + j], b[SP + j], c, 0, 0, 0);           // k2 q2
-#pragma unroll
-    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SP + j], b[j], c, 0, 0, 0);                // k2 q1
-#pragma unroll
-    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[2 * SP + j], c, 0, 0, 0);            // k1 q3
-#pragma unroll
-    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[SP + j], c, 0, 0, 0);                // k1 q2
-#pragma unroll
-    for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[j], c, 0, 0, 0);                     // k1 q1
+      for (int j = 0; j < SP; ++j) c = mfma16<F16>(a[RF::PA[ph] * SP + j], b[RF::PB[ph] * SP + j], c);
   }
   return c;
+}
+
+// one 16-bit operand element as f32
+template <bool F16>
+__device__ __forceinline__ float elem_f32(uint16_t v) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return __uint_as_float((uint32_t)v << 16);
 }
 
 // What the margin test's (D + 2) 2^-23 |q||k| must cover on the split route, with |q|, |k| the norms of plane 1 (within
@@ -190,6 +219,12 @@ __device__ __forceinline__ f32x16 tile_chain(const bf16x8 (&a)[RowFrags<DK, SP>:
 // splits and the rounding of q log2 e (<= 5 x 2^-24), and the rounding of the f32 chain the recheck decides by
 // (<= 16 SP x 2^-24): D_eff + 2 >= 1.03 (96 SP + 2) + 0.51 (16 SP + 5).
 constexpr int split_deff(int SP) { return (103 * (96 * SP + 2) + 51 * (16 * SP + 5)) / 100 + 1; }
+// The same for the f16 planes: n = 48 SP exact products, their absolute values summing to <= 1.001 sum_d |q_d k_d|; the dropped
+// k2 q2 and the roundings of the two residual planes (3 x 2^-22 = 12 x 2^-24); q log2 e (1); the f32 chain (16 SP):
+// D_eff + 2 >= 1.002 (48 SP + 2) + 0.501 (13 + 16 SP).  And absolutely, for subnormal x1s elements, 2^-25 (|k|_1 + |q|_1)
+// <= split_eabs(SP) (|k| + |q|) with split_eabs = 1.01 x 2^-25 sqrt(16 SP).
+constexpr int split_deff_f16(int SP) { return (1002 * (48 * SP + 2) + 501 * (13 + 16 * SP)) / 1000 + 1; }
+constexpr float split_eabs(int SP) { return (SP == 1 ? 4.04f : SP == 2 ? 5.72f : 8.08f) * 2.98023223876953125e-08f; }
 
 // ------------------------------------------------------------------------- key staging (LDS)
 // Key stages through a swizzled LDS image: coalesced 16-byte global loads, conflict-free ds_read_b128 in MFMA
@@ -295,7 +330,7 @@ __device__ __forceinline__ void update_max_l2(f32x16& acc, L2State& st, f32x16& 
 // it leaves (chunk maximum, l_c relative to R_c = ceil(chunk maximum [* log2 e])) — the index of a
 // bad query is always decided by the exact recheck, so no arg-max is kept here.
 constexpr int kFallbackGrid = 1024;
-template <int DK, bool LOG2, int SP = 0>
+template <int DK, bool LOG2, int SP = 0, bool F16 = false>
 __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, int qblocks, int nchunks, CorrWs ws) {
@@ -304,6 +339,7 @@ __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
   __shared__ uint4 lds[2][KS::CHUNKS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
+  if (gated_off(ws)) return;
   const int nlisted = ws.rcount[1];
   for (int item = blockIdx.x; item < nlisted * range_chunks; item += gridDim.x) {   // block-uniform
   const int ent = ws.blist[item / range_chunks];
@@ -348,7 +384,7 @@ __global__ __launch_bounds__(kThreads, 1) void corr_bf16_kernel(
         KS::load_a(lds[buf], sub, r, h, a);
 #pragma unroll
         for (int qb = 0; qb < kQB; ++qb) {
-          f32x16 acc = tile_chain<DK, SP>(a, bq[qb], LOG2 ? cinit[qb] : splat16(0.f));
+          f32x16 acc = tile_chain<DK, SP, F16>(a, bq[qb], LOG2 ? cinit[qb] : splat16(0.f));
           if (kb + 32 > k1) mask_tail(acc, kb + 4 * h, k1);
           if (LOG2) {
             update_max_l2(acc, s2[qb], cinit[qb]);
@@ -398,6 +434,7 @@ __global__ __launch_bounds__(kThreads) void corr_f32_kernel(
     int range_chunks, CorrWs ws) {
   constexpr int KS = DP / 2;
   constexpr int LD = DP + 1;  // odd dword stride: conflict-free ds_read_b32 down a column
+  if (gated_off(ws)) return;
   constexpr int TKF = (DP <= 64) ? kTK : 32;     // keys per LDS stage (D = 128: 2 x 32 x 129 x 4 B = 33 KB)
   __shared__ float lds[2][TKF * LD];
 
@@ -584,12 +621,34 @@ __global__ __launch_bounds__(256) void corr_split3_f32_kernel(const float* __res
   o[0] = x1; o[W] = x2; o[2 * W] = x3;
 }
 
+// rows (R, ld) f32, D <= 16 SP -> (R, 48 SP) f16 planes [x1 | x2s | x1s] of x * prescale (RowFrags' header): x1 = f16(x),
+// x2s = f16((x - x1) 2^11), x1s = f16(x1 2^-11); *ovf is raised when an |x| does not fit f16
+template <int SP>
+__global__ __launch_bounds__(256) void corr_split2h_f32_kernel(const float* __restrict__ X, int R, int D, int ld, float prescale,
+                                                               uint16_t* __restrict__ out, int32_t* __restrict__ ovf) {
+  constexpr int W = 16 * SP;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)R * W) return;
+  const long row = i / W;
+  const int d = (int)(i % W);
+  const float x = d < D ? X[row * ld + d] * prescale : 0.f;
+  if (!(fabsf(x) <= 65000.f)) { *ovf = 1; }                    // also NaN
+  const _Float16 x1 = (_Float16)x;                              // v_cvt_f16_f32: round to nearest even
+  const float r = x - (float)x1;                                // exact
+  const _Float16 x2s = (_Float16)(r * 2048.f);
+  const _Float16 x1s = (_Float16)((float)x1 * 4.8828125e-4f);   // exact unless subnormal (|x1| < 2^-3): then <= 2^-25 off
+  uint16_t* o = out + row * (3 * W) + d;
+  o[0] = __builtin_bit_cast(uint16_t, x1); o[W] = __builtin_bit_cast(uint16_t, x2s); o[2 * W] = __builtin_bit_cast(uint16_t, x1s);
+}
+
 // ------------------------------------------------------------------------------ key norms
 // max_n |k_n|^2 for the error bound of the margin test, one partial per block; block 0 also zeroes
 // the recheck counter of this call.
+template <bool F16 = false>
 __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __restrict__ K, int N, int D,
                                                            int ldk, float inflate, CorrWs ws) {
   __shared__ float red[4];
+  if (gated_off(ws)) return;
   float mx = 0.f;
   for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += kKnBlocks * 256) {
     const uint16_t* row = K + (size_t)n * ldk;
@@ -599,7 +658,7 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
       const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float lo = __uint_as_float(w[j] << 16), hi = __uint_as_float(w[j] & 0xFFFF0000u);
+        const float lo = elem_f32<F16>((uint16_t)(w[j] & 0xFFFFu)), hi = elem_f32<F16>((uint16_t)(w[j] >> 16));
         s = __builtin_fmaf(lo, lo, s);
         s = __builtin_fmaf(hi, hi, s);
       }
@@ -635,7 +694,7 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
 // code, same f64 operations: the two routes give bit-identical outputs): log-probability and lse from the
 // canonical sum, then the margin test.
 template <int MODE>
-__device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, bool anybad, double L, double Rf, int D,
+__device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, bool anybad, double L, double Rf, int D, float eabs,
                                             float qn2, float kn2, const CorrWs& ws, int32_t* __restrict__ idx,
                                             float* __restrict__ logp, float* __restrict__ lse) {
   const double ln2 = 0.6931471805599453094;
@@ -657,7 +716,9 @@ __device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, b
   // 4 600 of the 5 625 rows of a typical crop, each re-scanned against all keys.)
   if (MODE != 0 && qn2 == 0.f && !anybad) return;
   if (MODE != 0) {
-    const double eps = (double)(D + 2) * 1.1920928955078125e-7 * sqrt((double)qn2 * (double)kn2) * 1.0001;
+    // eabs (f16 planes only): what subnormal plane elements add absolutely, eabs (|q| + |k|)
+    const double eps = (double)(D + 2) * 1.1920928955078125e-7 * sqrt((double)qn2 * (double)kn2) * 1.0001 +
+                       (double)eabs * (sqrt((double)qn2) + sqrt((double)kn2));
     const double margin = (double)G1 - (double)G2;
     if (anybad || !(margin > 2.0 * eps)) {
       // exact winner x* >= exact(winner) >= G1 - eps, so its MFMA logit is >= G1 - 2 eps; bad ranges carry
@@ -679,9 +740,10 @@ __device__ __forceinline__ float kn2_max(const CorrWs& ws) {      // every lane 
 #include "corr_direct.hpp"   // corr_bf16_direct_kernel: the VALU-minimal bf16 loop (log2 and natural units)
 
 template <int MODE>
-__global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, int nsplit, int range_chunks,
+__global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, float eabs, int nsplit, int range_chunks,
                                                             int nchunks, CorrWs ws, int32_t* __restrict__ idx,
                                                             float* __restrict__ logp, float* __restrict__ lse) {
+  if (gated_off(ws)) return;
   // bf16, ONE key range: the direct kernel finished its good queries itself; only workgroups that hold a bad
   // query (the same 256-query blocks there and here) have anything left to do
   // (there the grid is a fixed one striding over the direct kernel's list of such blocks: nothing listed, nothing done)
@@ -719,7 +781,7 @@ __global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, int ns
     if ((double)R > Rf) { L = L * exp2(Rf - (double)R) + l; Rf = R; }
     else L += l * exp2((double)R - Rf);
   }
-  corr_finish<MODE>(q, G1, G2, bi, anybad, L, Rf, D, MODE != 0 ? ws.qn2[q] : 0.f, kn2, ws, idx, logp, lse);
+  corr_finish<MODE>(q, G1, G2, bi, anybad, L, Rf, D, eabs, MODE != 0 ? ws.qn2[q] : 0.f, kn2, ws, idx, logp, lse);
   }  // query blocks
 }
 
@@ -768,13 +830,14 @@ __device__ __attribute__((noinline)) double chain_logit_f32(const float* __restr
   return (double)acc;
 }
 
-template <int DK, int SP = 0>
+template <int DK, int SP = 0, bool F16 = false>
 __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int rsplit, double scale, F32Rows f32, CorrWs ws) {
   using KS = KeyStage<DK, SP>;
   constexpr int NFR = KS::NFR, TKS = KS::TK;     // the key ranges below are cut in units of kTK keys, staged TKS at a time
   __shared__ uint4 lds[2][KS::CHUNKS];
+  if (gated_off(ws)) return;
   const int cnt = *ws.rcount;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
@@ -822,7 +885,7 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
           KS::load_a(lds[buf], sub, r, h, a);
 #pragma unroll
           for (int qb = 0; qb < kQB; ++qb) {
-            f32x16 acc = tile_chain<DK, SP>(a, bq[qb], splat16(0.f));
+            f32x16 acc = tile_chain<DK, SP, F16>(a, bq[qb], splat16(0.f));
             if (kb + 32 > k1) mask_tail(acc, kb + 4 * h, k1);
             const float t = tile_max(acc);
             if (__any(t >= thr[qb])) {                    // rare
@@ -861,6 +924,7 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
 // list entry e: best over the recheck key ranges (ascending: ties keep the lower key) -> idx[rlist[e]]
 __global__ __launch_bounds__(256) void corr_recheck_merge_kernel(int P, int N, int rsplit, CorrWs ws,
                                                                  int32_t* __restrict__ idx) {
+  if (gated_off(ws)) return;
   const int cnt = *ws.rcount;
   const int rs = recheck_ranges(cnt, P, rsplit, (N + kTK - 1) / kTK);
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < cnt; e += gridDim.x * blockDim.x) {
@@ -975,13 +1039,19 @@ int slots_for(int dtype, int D) {
   return c;
 }
 
-int slots_split3(int sp) {
-  static int cache[5] = {0, 0, 0, 0, 0};
-  int& c = cache[sp];
-  if (c == 0)
-    c = sp == 1 ? resident_slots(corr_bf16_direct_kernel<3, kQB, false, 3, 1>)
-      : sp == 2 ? resident_slots(corr_bf16_direct_kernel<6, kQB, false, 6, 2>)
-                : resident_slots(corr_bf16_direct_kernel<12, kQB, false, 12, 4>);
+int slots_planes(int sp, bool f16) {
+  static int cache[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+  int& c = cache[f16 ? 1 : 0][sp];
+  if (c == 0) {
+    if (f16)
+      c = sp == 1 ? resident_slots(corr_bf16_direct_kernel<3, kQB, false, 3, 1, true>)
+        : sp == 2 ? resident_slots(corr_bf16_direct_kernel<6, kQB, false, 6, 2, true>)
+                  : resident_slots(corr_bf16_direct_kernel<12, kQB, false, 12, 4, true>);
+    else
+      c = sp == 1 ? resident_slots(corr_bf16_direct_kernel<3, kQB, false, 3, 1>)
+        : sp == 2 ? resident_slots(corr_bf16_direct_kernel<6, kQB, false, 6, 2>)
+                  : resident_slots(corr_bf16_direct_kernel<12, kQB, false, 12, 4>);
+  }
   return c;
 }
 
@@ -1008,6 +1078,8 @@ size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   o->rlist = bf16 ? w.take<int32_t>(P) : nullptr;
   o->rval = bf16 ? w.take<double>((size_t)rs * P) : nullptr;
   o->ridx = bf16 ? w.take<int32_t>((size_t)rs * P) : nullptr;
+  o->skip = nullptr;
+  o->only = nullptr;
   return w.off;
 }
 
@@ -1019,23 +1091,35 @@ size_t carve_split(isr::Workspace& w, int P, int N, uint16_t** q2, uint16_t** k2
 }
 
 constexpr int kSplitMaxD = 16;    // round-3 form of the split route (96-wide rows on the generic direct kernel)
-constexpr int kSplit3MaxD = 64;   // three-plane form: SP = 1, 2, 4 blocks per plane
+constexpr int kSplit3MaxD = 64;   // plane forms: SP = 1, 2, 4 blocks per plane
 
-// the three-plane split route: the two (rows, 48 SP) bf16 images, then a bf16 workspace
-size_t carve_split3(isr::Workspace& w, int P, int N, int SP, uint16_t** q3, uint16_t** k3, CorrWs* o) {
-  *q3 = w.take<uint16_t>((size_t)P * 48 * SP);
-  *k3 = w.take<uint16_t>((size_t)N * 48 * SP);
-  return carve(w, P, N, ISR_DTYPE_BF16_LOG2, o);
+// How an f32 call runs.  kind: 0 the f32-MFMA chain kernel; 1 round 3's 96-wide split (D <= 16); 2 three bf16 planes;
+// 3 f16 planes (gated: falls through to the chain kernel when a descriptor does not fit f16).  ISR_TUNE_K1_F32_CHAIN:
+// 0 default (f16 planes for D <= 64), 1 chain kernel everywhere, 2 bf16 planes for every D <= 64, 3 f16 planes (= default),
+// 4 round 3's 96-wide split for D <= 16 (bf16 planes above).
+struct F32Route { int kind, sp; };
+F32Route f32_route(int D) {
+  const int t = isr::tuning(ISR_TUNE_K1_F32_CHAIN);
+  if (t == 1 || D > kSplit3MaxD) return {0, 0};
+  const int sp = D <= 16 ? 1 : D <= 32 ? 2 : 4;
+  if (t == 4 && D <= kSplitMaxD) return {1, 0};
+  if (t == 2 || t == 4) return {2, sp};
+  return {3, sp};
 }
 
-// which form an f32 call takes: 0 the f32-MFMA chain kernel, -1 the round-3 split (D <= 16), SP > 0 the three-plane split.
-// ISR_TUNE_K1_F32_CHAIN: 0 default (D <= 16: round-3 split, D <= 64: three planes), 1 chain kernel everywhere,
-// 2 three planes for D <= 16 as well (SP = 1).
-int f32_route(int D) {
-  const int t = isr::tuning(ISR_TUNE_K1_F32_CHAIN);
-  if (t == 1 || D > kSplit3MaxD) return 0;
-  if (D <= kSplitMaxD) return t == 2 ? 1 : -1;
-  return D <= 32 ? 2 : 4;
+// the plane routes: the two (rows, 48 SP) 16-bit images and a gate word, then a bf16 workspace; gated (f16 planes): the
+// f32 workspace of the chain kernels behind it as well
+size_t carve_planes(isr::Workspace& w, int P, int N, int SP, bool gated, uint16_t** q3, uint16_t** k3, int32_t** gate, CorrWs* o,
+                    CorrWs* chain) {
+  *q3 = w.take<uint16_t>((size_t)P * 48 * SP);
+  *k3 = w.take<uint16_t>((size_t)N * 48 * SP);
+  *gate = w.take<int32_t>(4);
+  carve(w, P, N, ISR_DTYPE_BF16_LOG2, o);
+  if (gated) {
+    CorrWs tmp;
+    carve(w, P, N, ISR_DTYPE_F32, chain ? chain : &tmp);
+  }
+  return w.off;
 }
 
 }  // namespace
@@ -1051,10 +1135,11 @@ extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype
     const size_t split = carve_split(w2, P, N, &q2, &k2, &o) + 256;
     if (split > bytes) bytes = split;
   }
-  if (dtype == ISR_DTYPE_F32 && D <= kSplit3MaxD) {                // the three-plane route (any knob setting: the size is a function of the shape)
+  if (dtype == ISR_DTYPE_F32 && D <= kSplit3MaxD) {                // the plane routes (any knob setting: the size is a function of the shape)
     isr::Workspace w3(nullptr, 0);
     uint16_t *q3, *k3;
-    const size_t split = carve_split3(w3, P, N, D <= 0 ? 4 : D <= 16 ? 1 : D <= 32 ? 2 : 4, &q3, &k3, &o) + 256;
+    int32_t* gate;
+    const size_t split = carve_planes(w3, P, N, D <= 0 ? 4 : D <= 16 ? 1 : D <= 32 ? 2 : 4, true, &q3, &k3, &gate, &o, nullptr) + 256;
     if (split > bytes) bytes = split;
   }
   return bytes;
@@ -1104,13 +1189,14 @@ extern "C" int isr_corr_argmax_recheck_count_f32(const void* ws_, size_t ws_byte
   ISR_REQUIRE(ws_ && count_host && P > 0 && N > 0 && D > 0, "isr_corr_argmax_recheck_count_f32: bad argument");
   ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, D, ISR_DTYPE_F32), "isr_corr_argmax_recheck_count_f32: workspace too small");
   *count_host = -1;
-  const int route = f32_route(D);
-  if (route == 0) return ISR_OK;
+  const F32Route route = f32_route(D);
+  if (route.kind == 0) return ISR_OK;
   isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
   uint16_t *q2, *k2;
+  int32_t* gate;
   CorrWs ws;
-  if (route < 0) carve_split(w, P, N, &q2, &k2, &ws);
-  else carve_split3(w, P, N, route, &q2, &k2, &ws);
+  if (route.kind == 1) carve_split(w, P, N, &q2, &k2, &ws);
+  else carve_planes(w, P, N, route.sp, route.kind == 3, &q2, &k2, &gate, &ws, nullptr);
   hipStream_t stream = isr::as_stream(stream_);
   ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.rcount, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   ISR_CHECK_HIP(hipStreamSynchronize(stream));
@@ -1122,9 +1208,11 @@ namespace {
 // the bf16 kernels of one call (direct kernel, per-query fallback, finalize, exact recheck, merge).  f32.q != nullptr: the
 // split-f32 route — Q / K are the 128-wide split images, the recheck decides by the f32 chain of the original rows.
 // sp > 0: the three-plane split — Q / K are (rows, 48 sp) plane images, D = split_deff(sp) (the margin test's bound).
+// f16: the planes are f16 (RowFrags), eabs the margin test's absolute term.
 int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int ldq, int ldk, bool log2, const CorrPlan& p,
                 const CorrWs& ws, int32_t* idx, float* logp, float* lse, F32Rows f32, float kn_inflate, hipStream_t stream,
-                int sp = 0) {
+                int sp = 0, bool f16 = false) {
+  const float eabs = (sp && f16) ? split_eabs(sp) : 0.f;
   const dim3 grid(p.qblocks, p.nsplit);
   const int fin_blocks = (P + 255) / 256;
   const int fin_bf16 = (p.nsplit == 1 && fin_blocks > kFallbackGrid) ? kFallbackGrid : fin_blocks;   // one key range: list-driven
@@ -1138,7 +1226,8 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
   const int cgrid = (int)(((long)p.qblocks * p.nchunks < kFallbackGrid) ? (long)p.qblocks * p.nchunks : kFallbackGrid);   // fallback: strides over listed blocks x chunks
   const dim3 rgrid(16 * kRSplitGrid);   // workgroups = key ranges (by list length, <= 64) x slots striding over the groups of 256 listed queries
   const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
-  corr_keynorm_kernel<<<kKnBlocks, 256, 0, stream>>>(k, N, sp ? 16 * sp : D, ldk, kn_inflate, ws);   // three planes: |k1|^2
+  if (f16) corr_keynorm_kernel<true><<<kKnBlocks, 256, 0, stream>>>(k, N, 16 * sp, ldk, kn_inflate, ws);
+  else corr_keynorm_kernel<false><<<kKnBlocks, 256, 0, stream>>>(k, N, sp ? 16 * sp : D, ldk, kn_inflate, ws);   // planes: |k1|^2
 #define ISR_LAUNCH_BF16(DKv)                                                                                  \
   do {                                                                                                        \
     if (log2) {                                                                                               \
@@ -1146,39 +1235,42 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
                                                                               p.range_chunks, ws, idx, logp, lse); \
       corr_bf16_kernel<DKv, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,      \
                                                                   p.nchunks, ws);  \
-      corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
+      corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
     } else {                                                                                                  \
       corr_bf16_direct_kernel<DKv, kQB, true><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,           \
                                                                              p.range_chunks, ws, idx, logp, lse); \
       corr_bf16_kernel<DKv, false><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,     \
                                                                    p.nchunks, ws); \
-      corr_finalize_kernel<2><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, \
+      corr_finalize_kernel<2><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
     }                                                                                                         \
     corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);  \
   } while (0)
-#define ISR_LAUNCH_SPLIT3(SPv)                                                                                                    \
+#define ISR_LAUNCH_PLANES(SPv, F16v)                                                                                              \
   do {                                                                                                                            \
-    corr_bf16_direct_kernel<3 * SPv, kQB, false, 3 * SPv, SPv><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, \
-                                                                                               ws, idx, logp, lse);                \
-    corr_bf16_kernel<3 * SPv, true, SPv><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,         \
-                                                                          p.nchunks, ws);                                          \
-    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);         \
-    corr_recheck_kernel<3 * SPv, SPv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);            \
+    corr_bf16_direct_kernel<3 * SPv, kQB, false, 3 * SPv, SPv, F16v><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,          \
+                                                                                                     p.range_chunks, ws, idx, logp, lse); \
+    corr_bf16_kernel<3 * SPv, true, SPv, F16v><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,   \
+                                                                                p.nchunks, ws);                                    \
+    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);   \
+    corr_recheck_kernel<3 * SPv, SPv, F16v><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);      \
   } while (0)
-  if (sp) {          // three-plane split route (log2 domain, f32 originals decide the recheck)
-    switch (sp) {
-      case 1: ISR_LAUNCH_SPLIT3(1); break;
-      case 2: ISR_LAUNCH_SPLIT3(2); break;
-      default: ISR_LAUNCH_SPLIT3(4); break;
+  if (sp) {          // plane routes (log2 domain, f32 originals decide the recheck)
+    switch (sp * 2 + (f16 ? 1 : 0)) {
+      case 2: ISR_LAUNCH_PLANES(1, false); break;
+      case 3: ISR_LAUNCH_PLANES(1, true); break;
+      case 4: ISR_LAUNCH_PLANES(2, false); break;
+      case 5: ISR_LAUNCH_PLANES(2, true); break;
+      case 8: ISR_LAUNCH_PLANES(4, false); break;
+      default: ISR_LAUNCH_PLANES(4, true); break;
     }
   } else
-#undef ISR_LAUNCH_SPLIT3
+#undef ISR_LAUNCH_PLANES
   if (f32.q) {       // split-f32 route: 128-wide rows whose last two blocks are zero, log2 domain
     corr_bf16_direct_kernel<8, kQB, false, 6><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws, idx, logp, lse);
     corr_bf16_kernel<8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
-    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
+    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
     corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
   } else
   switch (D) {
@@ -1190,6 +1282,24 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
 #undef ISR_LAUNCH_BF16
   corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, N, p.rsplit, ws, idx);
   ISR_CHECK_LAUNCH("corr bf16 kernels");
+  return ISR_OK;
+}
+
+// the f32-MFMA chain kernels of one call
+int launch_f32_chain(const float* q, const float* k, int P, int N, int D, int ldq, int ldk, const CorrPlan& p, const CorrWs& ws,
+                     int32_t* idx, float* logp, float* lse, hipStream_t stream) {
+  ISR_REQUIRE(D <= 128, "isr_corr_argmax(f32): D=%d > 128", D);
+  const dim3 grid(p.qblocks, p.nsplit);
+  const int fin_blocks = (P + 255) / 256;
+  const float eabs = 0.f;
+  if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+  else if (D <= 12) corr_f32_kernel<12><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);   // the reference's 12-D descriptors: 6 k-steps, not 8
+  else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+  else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+  else if (D <= 64) corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+  else corr_f32_kernel<128><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+  corr_finalize_kernel<0><<<fin_blocks, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
+  ISR_CHECK_LAUNCH("corr f32 kernels");
   return ISR_OK;
 }
 
@@ -1209,31 +1319,48 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     return ISR_ERR_WORKSPACE;
   }
   hipStream_t stream = isr::as_stream(stream_);
-  const int route = dtype == ISR_DTYPE_F32 ? f32_route(D) : 0;
-  if (route > 0) {
-    // three-plane split route: exact indices and f32-accurate sums from the bf16 matrix cores at D <= 64 (RowFrags' header)
-    const int sp = route;
+  const F32Route route = dtype == ISR_DTYPE_F32 ? f32_route(D) : F32Route{0, 0};
+  if (route.kind >= 2) {
+    // plane routes: exact indices and f32-accurate sums from the 16-bit matrix cores at D <= 64 (RowFrags' header)
+    const int sp = route.sp;
+    const bool f16 = route.kind == 3;
     isr::Workspace w(ws_, ws_bytes);
     uint16_t *q3, *k3;
-    CorrWs ws;
-    carve_split3(w, P, N, sp, &q3, &k3, &ws);
-    const CorrPlan p = make_plan(P, N, slots_split3(sp), kWaves * kQB * 32);
+    int32_t* gate;
+    CorrWs ws, cws;
+    carve_planes(w, P, N, sp, f16, &q3, &k3, &gate, &ws, &cws);
+    const CorrPlan p = make_plan(P, N, slots_planes(sp, f16), kWaves * kQB * 32);
     const float* qf = static_cast<const float*>(Q);
     const float* kf = static_cast<const float*>(K);
     const unsigned gq = (unsigned)(((long)P * 16 * sp + 255) / 256), gk = (unsigned)(((long)N * 16 * sp + 255) / 256);
+#define ISR_SPLIT_PLANES(SPv)                                                                              \
+  do {                                                                                                     \
+    if (f16) {                                                                                             \
+      corr_split2h_f32_kernel<SPv><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3, gate);               \
+      corr_split2h_f32_kernel<SPv><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3, gate);                  \
+    } else {                                                                                               \
+      corr_split3_f32_kernel<SPv><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3);                      \
+      corr_split3_f32_kernel<SPv><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3);                         \
+    }                                                                                                      \
+  } while (0)
+    if (f16) ISR_CHECK_HIP(hipMemsetAsync(gate, 0, sizeof(int32_t), stream));
     switch (sp) {
-      case 1: corr_split3_f32_kernel<1><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3);
-              corr_split3_f32_kernel<1><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3); break;
-      case 2: corr_split3_f32_kernel<2><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3);
-              corr_split3_f32_kernel<2><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3); break;
-      default: corr_split3_f32_kernel<4><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3);
-               corr_split3_f32_kernel<4><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3); break;
+      case 1: ISR_SPLIT_PLANES(1); break;
+      case 2: ISR_SPLIT_PLANES(2); break;
+      default: ISR_SPLIT_PLANES(4); break;
     }
-    return launch_bf16(q3, k3, P, N, split_deff(sp), 48 * sp, 48 * sp, true, p, ws, idx, logp, lse, F32Rows{qf, kf, ldq, ldk, D},
-                       1.f, stream, sp);
+#undef ISR_SPLIT_PLANES
+    if (f16) ws.skip = gate;
+    const int rc = launch_bf16(q3, k3, P, N, f16 ? split_deff_f16(sp) : split_deff(sp), 48 * sp, 48 * sp, true, p, ws, idx, logp, lse,
+                               F32Rows{qf, kf, ldq, ldk, D}, 1.f, stream, sp, f16);
+    if (rc != ISR_OK || !f16) return rc;
+    // behind the gate: the f32-MFMA chain kernels, which leave at once unless a descriptor did not fit f16
+    cws.only = gate;
+    return launch_f32_chain(qf, kf, P, N, D, ldq, ldk, make_plan(P, N, slots_for(ISR_DTYPE_F32, D), kWaves * kQB * 32), cws, idx,
+                            logp, lse, stream);
   }
-  if (route < 0) {
-    // split route: exact indices and f32-accurate sums from the bf16 matrix cores (corr_split_f32_kernel's header)
+  if (route.kind == 1) {
+    // round 3's split route: 96-wide rows on the generic direct kernel (corr_split_f32_kernel's header)
     isr::Workspace w(ws_, ws_bytes);
     uint16_t *q2, *k2;
     CorrWs ws;
@@ -1249,24 +1376,9 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
   isr::Workspace w(ws_, ws_bytes);
   CorrWs ws;
   carve(w, P, N, dtype, &ws);
-  const dim3 grid(p.qblocks, p.nsplit);
-  const int fin_blocks = (P + 255) / 256;
-
   if (dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2) {
     return launch_bf16(static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), P, N, D, ldq, ldk,
                        dtype == ISR_DTYPE_BF16_LOG2, p, ws, idx, logp, lse, F32Rows{nullptr, nullptr, 0, 0, 0}, 1.f, stream);
-  } else {
-    ISR_REQUIRE(D <= 128, "isr_corr_argmax(f32): D=%d > 128", D);
-    const float* q = static_cast<const float*>(Q);
-    const float* k = static_cast<const float*>(K);
-    if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-    else if (D <= 12) corr_f32_kernel<12><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);   // the reference's 12-D descriptors: 6 k-steps, not 8
-    else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-    else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-    else if (D <= 64) corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-    else corr_f32_kernel<128><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-    corr_finalize_kernel<0><<<fin_blocks, 256, 0, stream>>>(P, D, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
-    ISR_CHECK_LAUNCH("corr f32 kernels");
   }
-  return ISR_OK;
+  return launch_f32_chain(static_cast<const float*>(Q), static_cast<const float*>(K), P, N, D, ldq, ldk, p, ws, idx, logp, lse, stream);
 }

@@ -51,8 +51,8 @@ __device__ __forceinline__ float tile_max(const f32x16& acc) {
 // DKU <= DK: the 16-wide blocks that can be non-zero (the split-f32 route stores 8 blocks of which the last two are zero
 // padding: their MFMAs would add exact zeros, so they are not issued — same bits, 6 instead of 8 matrix instructions per tile).
 // SP > 0: split rows (RowFrags / tile_chain in corr_argmax.hip): three planes of SP blocks per operand row, 6 SP matrix
-// instructions per tile; DK = 3 SP, DKU unused.
-template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0>
+// instructions per tile (3 SP with f16 planes, F16); DK = 3 SP, DKU unused.
+template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0, bool F16 = false>
 __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
@@ -60,8 +60,13 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   // 16-byte chunks staged per key row: all 2 DK of them, or — DKU < DK, the split-f32 route's rows with trailing zero blocks —
   // only the 2 DKU that can be non-zero (12 for DKU = 6: a quarter less key traffic, which is what bounds that route: its
   // 256-byte key rows do not fit the L2, profiles/r03_estimate_pose_hbm_traffic.txt).
-  using RF = RowFrags<DKU, SP>;
+  using RF = RowFrags<DKU, SP, F16>;
   constexpr int NFR = RF::NFR, NMF = RF::NMF;
+  static_assert(!F16 || SP != 0, "f16 operands exist as split planes only");
+  // the margin test's bound: plain rows (D + 2) 2^-23 |q||k|; split rows split_deff / split_deff_f16 (+ the absolute term)
+  constexpr int DEFF = SP ? (F16 ? split_deff_f16(SP) : split_deff(SP)) : 16 * DK;
+  constexpr float EABS = (SP && F16) ? split_eabs(SP ? SP : 1) : 0.f;
+  if (gated_off(ws)) return;
   static_assert(SP == 0 || DK == 3 * SP, "split rows: DK counts the 3 SP blocks of a row");
   constexpr int NCH = 2 * NFR;
   constexpr bool POW2 = (NCH & (NCH - 1)) == 0;
@@ -114,7 +119,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
     for (int s = 0; s < RF::NQN; ++s)          // split rows: plane 1 (split_deff covers what the other planes add)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float v = __uint_as_float((uint32_t)(uint16_t)bq[qb][s][e] << 16);
+        const float v = elem_f32<F16>((uint16_t)bq[qb][s][e]);
         n2 = __builtin_fmaf(v, v, n2);
       }
     n2 += __shfl_xor(n2, 32, 64);
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         for (int qb = 0; qb < QB; ++qb) {
           const int q = q0 + qb * 32 + r;
           if (h == 0 && q < P)
-            corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, SP ? split_deff(SP) : 16 * DK, 0.f, kn2z, ws, idx_out, logp_out, lse_out);
+            corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, DEFF, EABS, 0.f, kn2z, ws, idx_out, logp_out, lse_out);
         }
       } else {
         const int zc0 = split * range_chunks;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   __syncthreads();
   load_a(0, 0);
   f32x16 acc[2];
-  acc[0] = tile_chain<DKU, SP>(a, bq[0], splat16(0.f));
+  acc[0] = tile_chain<DKU, SP, F16>(a, bq[0], splat16(0.f));
 
   auto stage_body = [&](int stage, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
@@ -288,10 +293,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       if constexpr (DMA) { if (w == NW - 1 && stage + 2 < nstage) gload(stage + 2); }
       const int kb = k0 + stage * TKS + sub * 32;
       if constexpr (SP != 0) {
-        // Split rows: an item is six phases — the six plane pairs of tile_chain, SP matrix instructions each — fenced by
-        // sched_barriers; each phase carries its share of the previous item's epilogue (the maxima, then four exp + add at
-        // a time, in register order: the canonical sum) and, in the items that read fragments last, the ds_reads of the
-        // key plane it has just let go of (k3 after phase 0, k2 after phase 2, k1 after phase 5).
+        // Split rows: an item is its plane pairs as phases (RowFrags: six with bf16 planes, three with f16 planes), SP matrix
+        // instructions each, fenced by sched_barriers; each phase carries its share of the previous item's epilogue (the
+        // maxima, then a slice of the 16 exp + add in register order: the canonical sum) and, in the items that read
+        // fragments last, the ds_reads of the key plane it has just let go of.
         if (FULL || kb < k1) {  // block-uniform
           if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], kb + 4 * h, k1);
           const f32x16& cur = acc[w & 1];
@@ -309,46 +314,25 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
             }
           };
           float l = st[qb].l;
-          auto exps = [&](int i0) {
-#pragma unroll
-            for (int i = i0; i < i0 + 4; ++i) l += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
-          };
           f32x16 c = splat16(0.f);
 #pragma unroll
-          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2 * SP + j], bq[qbn][j], c, 0, 0, 0);            // k3 q1
-          reads(2);
-          {
-            const float t = tile_max(cur);
-            st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);
-            st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;
-            st[qb].m = fmaxf(st[qb].m, t);
+          for (int ph = 0; ph < RF::NPH; ++ph) {
+#pragma unroll
+            for (int j = 0; j < SP; ++j) c = mfma16<F16>(a[RF::PA[ph] * SP + j], bq[qbn][RF::PB[ph] * SP + j], c);
+            if (RF::RD[ph] >= 0) reads(RF::RD[ph]);
+            if (ph == 0) {
+              const float t = tile_max(cur);
+              st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);   // second largest of {m, m2, t} (m2 <= m)
+              st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;                     // strict: the first tile to reach m keeps it
+              st[qb].m = fmaxf(st[qb].m, t);
+            }
+#pragma unroll
+            for (int i = RF::E0[ph]; i < RF::E0[ph + 1]; ++i) l += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
+            if (ph + 1 < RF::NPH) {
+              asm volatile("" : "+v"(c), "+v"(l), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
+              __builtin_amdgcn_sched_barrier(0);
+            }
           }
-          asm volatile("" : "+v"(c), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SP + j], bq[qbn][SP + j], c, 0, 0, 0);           // k2 q2
-          exps(0);
-          asm volatile("" : "+v"(c), "+v"(l));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[SP + j], bq[qbn][j], c, 0, 0, 0);                // k2 q1
-          reads(1);
-          exps(4);
-          asm volatile("" : "+v"(c), "+v"(l));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bq[qbn][2 * SP + j], c, 0, 0, 0);            // k1 q3
-          exps(8);
-          asm volatile("" : "+v"(c), "+v"(l));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bq[qbn][SP + j], c, 0, 0, 0);                // k1 q2
-          exps(12);
-          asm volatile("" : "+v"(c), "+v"(l));
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int j = 0; j < SP; ++j) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], bq[qbn][j], c, 0, 0, 0);                     // k1 q1
-          reads(0);
           st[qb].l = l;
           nxt = c;
           asm volatile("" : "+v"(nxt), "+v"(st[qb].l));
@@ -358,7 +342,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], kb + 4 * h, k1);
         const f32x16& cur = acc[w & 1];
         f32x16& nxt = acc[(w + 1) & 1];
-        nxt = tile_chain<DKU, SP>(a, bq[qbn], splat16(0.f));
+        nxt = tile_chain<DKU, SP, F16>(a, bq[qbn], splat16(0.f));
         if (qb == 0) {                                    // the chain above was the fragments' last reader
           if (w == NW - 2) { if (has_next) load_a(buf ^ 1, 0); }
           else load_a(buf, sub + 1);
@@ -452,7 +436,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         kb_nxt = __shfl(T, __ffsll(todo) - 1, 64);
         fetch(kb_nxt, a1);                                // in flight under this tile's MFMAs
       }
-      f32x16 c = tile_chain<DKU, SP>(a0, bq[qb], splat16(0.f));
+      f32x16 c = tile_chain<DKU, SP, F16>(a0, bq[qb], splat16(0.f));
       if (kb_cur + 32 > k1) mask_tail(c, kb_cur + 4 * h, k1);
       if (T == kb_cur) {
         // the two largest of this lane's 16 rows (with multiplicity) and the lowest row of the largest
@@ -521,7 +505,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       if (over[qb]) ws.qn2[q] = qn2[qb];
     }
     if (!over[qb])
-      corr_finish<NAT ? 2 : 1>(q, st[qb].m, st[qb].m2, st[qb].tb, false, st[qb].L, 0.0, SP ? split_deff(SP) : 16 * DK, qn2[qb], kn2,
+      corr_finish<NAT ? 2 : 1>(q, st[qb].m, st[qb].m2, st[qb].tb, false, st[qb].L, 0.0, DEFF, EABS, qn2[qb], kn2,
                                ws, idx_out, logp_out, lse_out);
   }
 }

@@ -65,7 +65,7 @@ int isr_device_count(void);
 #define ISR_TUNE_NN_TILE_SQ 6    /* 0 default | query cell scale x 1000 */
 #define ISR_TUNE_NN_TILE_TB 7    /* 0 default | 64 | 128 | 256 threads per workgroup */
 #define ISR_TUNE_EP_WSUM_VALU 8  /* 0 (default) the sampler's chunk sums form their logits on the f32 MFMA | 1 on VALU fma chains (same bits) */
-#define ISR_TUNE_K1_F32_CHAIN 9  /* f32 queries: 0 (default) the split routes on the bf16 matrix cores with an exact f32-chain recheck (D <= 16: 96-wide rows; D <= 64: three planes) | 1 the f32-MFMA chain kernel | 2 three planes for D <= 16 too */
+#define ISR_TUNE_K1_F32_CHAIN 9  /* f32 queries, D <= 64: 0 / 3 (default) f16 planes on the matrix cores, exact f32-chain recheck, falls through to the chain kernel when a descriptor does not fit f16 | 1 the f32-MFMA chain kernel | 2 three bf16 planes | 4 round 3 96-wide rows (D <= 16) */
 #define ISR_TUNE_K1_SPLIT 10     /* 0 (default) K1 picks its number of key ranges | n > 0 forced (capped); results do not depend on it */
 #define ISR_TUNE_COUNT 11
 int isr_tuning_set(int knob, int value);

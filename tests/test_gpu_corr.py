@@ -456,15 +456,17 @@ def test_corr_f32_split_route_equals_chain_route(cuda0, oracle_lib, P, N, D):
 
 @pytest.mark.parametrize("P,N,D,chain", [(300, 31, 17, 0), (1000, 4097, 24, 0), (777, 12289, 33, 0), (5000, 20000, 64, 0),
                                          (513, 4096, 40, 0), (6000, 33000, 64, 0), (2000, 9000, 32, 0), (64, 128, 48, 0),
-                                         (1000, 4097, 12, 2), (5000, 20000, 16, 2), (777, 12289, 5, 2)])
+                                         (1000, 4097, 12, 0), (5000, 20000, 16, 0), (777, 12289, 5, 0),
+                                         (1000, 4097, 24, 2), (5000, 20000, 64, 2), (777, 12289, 33, 2), (2000, 9000, 32, 2),
+                                         (1000, 4097, 12, 2), (5000, 20000, 16, 2), (777, 12289, 5, 4)])
 def test_corr_f32_three_plane_route_equals_chain_route(cuda0, oracle_lib, P, N, D, chain):
-    """f32 descriptors with 16 < D <= 64 (round 4): each operand row kept as its three bf16 planes x1 | x2 | x3, the six
-    plane pairs down to 2^-16 issued as 6 D/16 bf16 matrix instructions per tile from 3 + 3 D/16 fragments, margin test with
-    the bound split_deff() covers, recheck by the f32 fmaf chain of the original rows.  Indices = the f32-MFMA chain kernel's
-    (ISR_TUNE_K1_F32_CHAIN = 1) = the oracle's, with duplicate keys (one pair across a canonical chunk boundary), an exact
-    tie, zero rows, a spiked and a negated query; logp / lse within 3e-6 of the chain kernel's relative to the logit scale;
-    slices at odd offsets and forced key-range counts reproduce their rows bit for bit.  chain = 2: the same three-plane
-    form for D <= 16 (SP = 1) instead of round 3's 96-wide rows."""
+    """f32 descriptors with D <= 64 on the 16-bit matrix cores (round 4), both plane forms (RowFrags in corr_argmax.hip):
+    chain = 0, the default — f16 planes x1 | x2s | x1s, three plane pairs per 16-wide block; chain = 2 — bf16 planes
+    x1 | x2 | x3, six plane pairs; chain = 4 — round 3's 96-wide rows (D <= 16).  Each with its margin test and the recheck
+    by the f32 fmaf chain of the original rows.  Indices = the f32-MFMA chain kernel's (ISR_TUNE_K1_F32_CHAIN = 1) = the
+    oracle's, with duplicate keys (one pair across a canonical chunk boundary), an exact tie, zero rows (a whole workgroup
+    of them), a spiked and a negated query; logp / lse within 3e-6 of the chain kernel's relative to the logit scale;
+    slices at odd offsets and forced key-range counts reproduce their rows bit for bit."""
     from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
     g = torch.Generator(device=cuda0).manual_seed(P + N + D)
     K = torch.randn(N, D, device=cuda0, generator=g) * (2.0 * (12.0 / max(D, 12)) ** 0.5)      # |k|^2 ~ 48 whatever D
@@ -538,6 +540,36 @@ def test_corr_f32_chain_kernel_all_zero_workgroups(cuda0, oracle_lib, D):
     rows = np.r_[0:64, 250:262, 760:776, 995:1005]
     o = oracle_lib.corr_argmax_f32(Q[rows].cpu().numpy(), K.cpu().numpy())
     assert np.array_equal(idx[rows].cpu().numpy(), o["idx"])
+
+
+@pytest.mark.parametrize("where", ["query", "key", "nan"])
+def test_corr_f32_f16_planes_fall_through_when_a_descriptor_does_not_fit_f16(cuda0, oracle_lib, where):
+    """The default f32 route keeps f16 planes; an |x| >= 65 000 (or a NaN) anywhere raises the gate word in its split kernel,
+    every kernel of the route leaves at once and the f32-MFMA chain kernels queued behind it produce the call's outputs —
+    the bits of an ISR_TUNE_K1_F32_CHAIN = 1 call, with no host round trip in between."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    g = torch.Generator(device=cuda0).manual_seed(77)
+    P, N, D = 1500, 9000, 24
+    K = torch.randn(N, D, device=cuda0, generator=g) * 0.7
+    Q = 1.5 * K[torch.randint(N, (P,), device=cuda0, generator=g)] + 0.2 * torch.randn(P, D, device=cuda0, generator=g)
+    if where == "query":
+        Q[17, 3] = 7.0e4 / 1.4426950408889634 * 1.01           # the query planes hold q log2 e
+    elif where == "key":
+        K[8000, 5] = -1.0e5
+    else:
+        Q[40, 0] = float("nan")
+    with ops.tuning(k1_f32_chain=1):
+        want = ops.corr_argmax(Q, K, want_lse=True)
+    got = ops.corr_argmax(Q, K, want_lse=True)
+    rows = torch.ones(P, dtype=torch.bool, device=cuda0)
+    if where == "nan":
+        rows[40] = False                                        # a NaN row's outputs are unspecified on every route
+    for a, b in zip(got, want):
+        assert torch.equal(a[rows], b[rows])
+    clean = torch.arange(100, 164, device=cuda0)
+    o = oracle_lib.corr_argmax_f32(Q[clean].cpu().numpy(), K.cpu().numpy())
+    if where != "key":                                          # the oracle's softmax overflows with the 1e5 key, the indices do not
+        assert np.array_equal(got[0][clean].cpu().numpy(), o["idx"])
 
 
 @pytest.mark.parametrize("kind", ["bf16_log2", "f32"])

@@ -8,7 +8,7 @@ export ISR_PMC_KERNEL="corr_bf16_direct_kernel<$(( (ISR_PMC_D + 15) / 16 * 3 ))"
 [ "$ISR_PMC_D" -gt 32 ] && export ISR_PMC_KERNEL="corr_bf16_direct_kernel<12"
 cd /tmp && export TMPDIR=/tmp
 mkdir -p "$R/$out"
-pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$R/$out/$name" -- python3 "$R/tools/time_corr_f32.py" $ISR_PMC_P $ISR_PMC_N $ISR_PMC_D 0 > "$R/$out/$name.log" 2>&1; }
+pass() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d "$R/$out/$name" -- python3 "$R/tools/time_corr_f32.py" $ISR_PMC_P $ISR_PMC_N $ISR_PMC_D ${ISR_PMC_ROUTE:-0} > "$R/$out/$name.log" 2>&1; }
 pass sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
 pass sq2 SQ_INSTS_VALU_TRANS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU
 pass sq3 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_BRANCH SQ_VALU_MFMA_COEXEC_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VMEM GRBM_GUI_ACTIVE

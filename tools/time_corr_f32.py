@@ -1,12 +1,12 @@
 """K1 exact-f32 path alone: python tools/time_corr_f32.py [P N D [chain]]  (default: the crop-batch shape, 128 x 2 195 rows,
-80 000 keys, D = 12).  chain = ISR_TUNE_K1_F32_CHAIN for the run (0 default routes, 1 f32-MFMA chain kernel, 2 three planes at
-D <= 16); without it every route that applies to D is timed."""
+80 000 keys, D = 12).  chain = ISR_TUNE_K1_F32_CHAIN for the run (0 default = f16 planes, 1 f32-MFMA chain kernel, 2 bf16 planes,
+4 round 3's 96-wide rows at D <= 16); without it every route that applies to D is timed."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
 P, N, D = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (280960, 80000, 12)
-routes = [int(sys.argv[4])] if len(sys.argv) > 4 else ([0, 2, 1] if D <= 16 else [0, 1])
+routes = [int(sys.argv[4])] if len(sys.argv) > 4 else ([0, 2, 4, 1] if D <= 16 else [0, 2, 1])
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
 K = torch.randn(N, D, device=dev, generator=g)
