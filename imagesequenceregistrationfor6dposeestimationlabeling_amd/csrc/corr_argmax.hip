@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void corr_split2h_f32_kernel(const float* __re
   const long row = i / W;
   const int d = (int)(i % W);
   const float x = d < D ? X[row * ld + d] * prescale : 0.f;
-  if (!(fabsf(x) <= 65000.f)) { *ovf = 1; }                    // also NaN
+  if (fabsf(x) > 65000.f) *ovf = 1;                            // (finite descriptors are a precondition of every route)
   const _Float16 x1 = (_Float16)x;                              // v_cvt_f16_f32: round to nearest even
   const float r = x - (float)x1;                                // exact
   const _Float16 x2s = (_Float16)(r * 2048.f);

@@ -542,9 +542,10 @@ def test_corr_f32_chain_kernel_all_zero_workgroups(cuda0, oracle_lib, D):
     assert np.array_equal(idx[rows].cpu().numpy(), o["idx"])
 
 
-@pytest.mark.parametrize("where", ["query", "key", "nan"])
+@pytest.mark.parametrize("where", ["query", "key"])
 def test_corr_f32_f16_planes_fall_through_when_a_descriptor_does_not_fit_f16(cuda0, oracle_lib, where):
-    """The default f32 route keeps f16 planes; an |x| >= 65 000 (or a NaN) anywhere raises the gate word in its split kernel,
+    """The default f32 route keeps f16 planes; an |x| >= 65 000 anywhere raises the gate word in its split kernel (finite
+    descriptors are a precondition of K1 on every route: corr_argmax.hip is built with -fno-honor-nans),
     every kernel of the route leaves at once and the f32-MFMA chain kernels queued behind it produce the call's outputs —
     the bits of an ISR_TUNE_K1_F32_CHAIN = 1 call, with no host round trip in between."""
     from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
@@ -554,18 +555,13 @@ def test_corr_f32_f16_planes_fall_through_when_a_descriptor_does_not_fit_f16(cud
     Q = 1.5 * K[torch.randint(N, (P,), device=cuda0, generator=g)] + 0.2 * torch.randn(P, D, device=cuda0, generator=g)
     if where == "query":
         Q[17, 3] = 7.0e4 / 1.4426950408889634 * 1.01           # the query planes hold q log2 e
-    elif where == "key":
-        K[8000, 5] = -1.0e5
     else:
-        Q[40, 0] = float("nan")
+        K[8000, 5] = -1.0e5
     with ops.tuning(k1_f32_chain=1):
         want = ops.corr_argmax(Q, K, want_lse=True)
     got = ops.corr_argmax(Q, K, want_lse=True)
-    rows = torch.ones(P, dtype=torch.bool, device=cuda0)
-    if where == "nan":
-        rows[40] = False                                        # a NaN row's outputs are unspecified on every route
     for a, b in zip(got, want):
-        assert torch.equal(a[rows], b[rows])
+        assert torch.equal(a, b)
     clean = torch.arange(100, 164, device=cuda0)
     o = oracle_lib.corr_argmax_f32(Q[clean].cpu().numpy(), K.cpu().numpy())
     if where != "key":                                          # the oracle's softmax overflows with the 1e5 key, the indices do not
