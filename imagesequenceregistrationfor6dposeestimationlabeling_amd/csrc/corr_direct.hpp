@@ -266,7 +266,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   static_assert(QB == 2 && NSUB % 2 == 0, "item schedule below is written for two query blocks per wave");
   gload(0);
   lwrite(0);
-  if constexpr (DMA) { if (nstage > 1) gload(1); }     // DMA: stage s + 2 is requested in the last item of stage s
+  if constexpr (DMA) {                                 // DMA: stage s + 2 is requested in the last item of stage s
+    if (nstage > 1) gload(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
   load_a(0, 0);
   f32x16 acc[2];
@@ -283,6 +286,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       const int qbn = (w + 1) % QB;
       if (w == NW - 2) {                                  // block-uniform
         if (has_next) lwrite(buf ^ 1);
+        // DMA: this wave's pieces of the next stage (requested NW - 1 items ago) must have LANDED before the barrier
+        // publishes the buffer — the compiler does not order a buffer_load ... lds against the ds_reads behind the
+        // barrier by itself (the f16 instantiation had no vmcnt wait in its loop at all: results changed from call to call)
+        if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef ISR_ABL_NOBARRIER  // timing-only ablation: what the stage barrier costs (results are wrong without it)
         __syncthreads();
 #endif

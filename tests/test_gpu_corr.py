@@ -542,6 +542,29 @@ def test_corr_f32_chain_kernel_all_zero_workgroups(cuda0, oracle_lib, D):
     assert np.array_equal(idx[rows].cpu().numpy(), o["idx"])
 
 
+@pytest.mark.parametrize("D,chain", [(64, 0), (64, 2), (32, 0), (12, 0), (12, 2)])
+def test_corr_f32_plane_routes_repeat_bit_for_bit(cuda0, D, chain):
+    """Six calls on a chip-filling shape (the keys reach the LDS by buffer_load ... lds, stage s + 2 in flight under stage
+    s + 1: a missing wait between a DMA piece landing and the barrier that publishes it shows as outputs that change from
+    call to call — round 4's first f16 build did exactly that at this size and passed every small-shape test)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    g = torch.Generator(device=cuda0).manual_seed(3 * D + chain)
+    P, N = 150000, 20000
+    K = torch.randn(N, D, device=cuda0, generator=g)
+    K = 5.0 * K / K.norm(dim=1, keepdim=True)
+    Q = K[torch.randint(N, (P,), device=cuda0, generator=g)] + 0.3 * (12.0 / max(D, 12)) ** 0.5 * torch.randn(P, D, device=cuda0, generator=g)
+    with ops.tuning(k1_f32_chain=chain):
+        first = ops.corr_argmax(Q, K, want_lse=True)
+        for _ in range(5):
+            again = ops.corr_argmax(Q, K, want_lse=True)
+            for a, b in zip(again, first):
+                assert torch.equal(a, b)
+    with ops.tuning(k1_f32_chain=1):
+        ref = ops.corr_argmax(Q, K, want_lse=True)
+    assert torch.equal(first[0], ref[0])
+    assert float((first[1] - ref[1]).abs().max()) < 2e-5 and float((first[2] - ref[2]).abs().max()) < 2e-4
+
+
 @pytest.mark.parametrize("where", ["query", "key"])
 def test_corr_f32_f16_planes_fall_through_when_a_descriptor_does_not_fit_f16(cuda0, oracle_lib, where):
     """The default f32 route keeps f16 planes; an |x| >= 65 000 anywhere raises the gate word in its split kernel (finite

@@ -101,28 +101,79 @@ def test_p3p_samples_vs_oracle(cuda0):
     uv3 = torch.from_numpy(np.stack([pix[:, :3] % res, pix[:, :3] // res], -1).astype(np.float64)).to(cuda0)
     all_roots, n_roots = ops.p3p_all_roots(X3, uv3, Ks)
     n_roots = n_roots.cpu().numpy()
-    same_count = picked_equal = count_differs = 0
+    all_roots = all_roots.cpu().numpy().reshape(S, 4, 3, 4)
+    from tests import p3p_classify as pc
+    same_sets = picked_equal = n_with = 0
+    classes, detail = {}, []
     for i in range(S):
         if len(set(ci[i].tolist())) < 4:
             assert not ok[i]
             continue
         p2d = np.stack([pix[i] % res, pix[i] // res], -1).astype(np.float64)
-        sols = eo.p3p_sorted(s["pts"][ks[i]].astype(np.float64), p2d, Ks)
-        if len(sols) != n_roots[i]:
-            # rounded pixels make some of these 3-point problems marginal: a root pair about to merge is found by one
-            # solver and not the other (root SETS on exact problems: tests/test_gpu_ransac.py::test_p3p_root_sets_...)
-            count_differs += 1
+        Xi = s["pts"][ks[i]].astype(np.float64)
+        sols = eo.p3p_sorted(Xi, p2d, Ks)
+        dev_roots = [(all_roots[i, j][:, :3], all_roots[i, j][:, 3]) for j in range(n_roots[i])]
+        mm = pc.measures(Xi[:3], p2d[:3], Ks, dev_roots, sols)
+        c = pc.explain(mm)
+        if c:
+            # rounded pixels make some of these 3-point problems marginal (root SETS on exact problems:
+            # tests/test_gpu_ransac.py::test_p3p_root_sets_...): every such case must be one of the named degeneracies
+            classes[c] = classes.get(c, 0) + 1
+            detail.append((i, c, mm["sliver_img"], mm["sliver_obj"], mm["unmatched"]))
             continue
-        same_count += 1
+        same_sets += 1
         assert bool(sols) == bool(ok[i]), i
         if not sols:
             continue
+        n_with += 1
         R, t = sols[int((int(pk[i]) * len(sols)) >> 32)]
         picked_equal += int(synth.rot_angle(R, poses[i][:, :3]) < 1e-5 and np.linalg.norm(t - poses[i][:, 3]) < 1e-3)
-    # same number of roots -> the same ordering by the 4th point and the same Philox pick, up to 4th-point-error ties
-    n_with = sum(1 for i in range(S) if len(set(ci[i].tolist())) == 4 and n_roots[i] > 0)
-    assert picked_equal >= same_count - (S - n_with) - 4, (picked_equal, same_count, count_differs)
-    assert count_differs <= 0.07 * S, count_differs
+    # the same root set -> the same ordering by the 4th point and the same Philox pick, up to 4th-point-error ties
+    assert picked_equal >= n_with - 4, (picked_equal, n_with, classes)
+    assert not (set(classes) & {"unexplained", "invalid"}), [d for d in detail if d[1] in ("unexplained", "invalid")]
+    assert sum(classes.values()) <= 0.07 * S, classes
+
+
+def test_p3p_disagreements_on_degenerate_problems_are_all_explained(cuda0):
+    """The classifier of tests/p3p_classify.py on problems built to be marginal: three pixels of a coarse lattice that are
+    collinear, coincide pairwise or span a sliver; object triangles with two nearly equal vertices.  The device solver and
+    the oracle's may return different root sets there — every such case must fall into a named class, none 'unexplained' and
+    none 'invalid' (a returned root that does not reproject its own three points), and on the well-conditioned control
+    problems of the same scene the two root sets must agree."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, pose_est_surf as pes
+    from oracle import pnp_oracle as po
+    from tests import p3p_classify as pc
+    s = _scene(6)
+    res = 32
+    Ks = pes._k_scaled(s["K"], 3)
+    rng = np.random.default_rng(31)
+    uv = synth.project(Ks, s["R"], s["t"], s["pts"])
+    good = np.nonzero((uv[:, 0] > 1) & (uv[:, 0] < res - 2) & (uv[:, 1] > 1) & (uv[:, 1] < res - 2))[0]
+    S = 1200
+    ks = rng.choice(good, (S, 3))
+    px = np.rint(uv[ks]).astype(np.float64)                      # (S, 3, 2) lattice pixels
+    X = s["pts"][ks].astype(np.float64)
+    kind = np.arange(S) % 4
+    px[kind == 1, 2] = px[kind == 1, 1]                          # two samples on one pixel
+    a = kind == 2                                                # three collinear pixels
+    px[a, 2] = 2 * px[a, 1] - px[a, 0]
+    b = kind == 3                                                # two object points a hair apart
+    X[b, 2] = X[b, 1] + 1e-3 * rng.normal(size=(int(b.sum()), 3))
+    roots, n_roots = ops.p3p_all_roots(torch.from_numpy(X).to(cuda0), torch.from_numpy(px).to(cuda0), Ks)
+    roots, n_roots = roots.cpu().numpy().reshape(S, 4, 3, 4), n_roots.cpu().numpy()
+    by_kind = {k: {} for k in range(4)}
+    bad = []
+    for i in range(S):
+        dev_roots = [(roots[i, j][:, :3], roots[i, j][:, 3]) for j in range(n_roots[i])]
+        mm = pc.measures(X[i], px[i], Ks, dev_roots, po.p3p_grunert(X[i], px[i], Ks))
+        c = pc.explain(mm) or "agree"
+        by_kind[int(kind[i])][c] = by_kind[int(kind[i])].get(c, 0) + 1
+        if c in ("unexplained", "invalid"):
+            bad.append((i, int(kind[i]), c, mm["sliver_img"], mm["sliver_obj"], mm["unmatched"]))
+    assert not bad, bad[:5]
+    assert by_kind[0].get("agree", 0) >= 0.93 * int((kind == 0).sum()), by_kind        # the control problems
+    for k in (1, 2, 3):                                                                 # degenerate by construction
+        assert set(by_kind[k]) <= {"agree", "sliver", "double", "grazing"}, by_kind
 
 
 def test_prune_on_device_vs_reference_expressions(cuda0):
@@ -239,6 +290,11 @@ def test_estimate_pose_end_to_end(cuda0):
     assert synth.rot_angle(o3[0][b3].cpu().numpy().astype(np.float64), s["R"]) < 0.5
 
 
+def po_project(K, R, t, X4):
+    from oracle import pnp_oracle as po
+    return po.project(K, np.asarray(R, np.float64), np.asarray(t, np.float64), np.asarray(X4, np.float64))[0][0]
+
+
 def _scene_ref(seed=7, r=224, e=12, m=80000, f=700.0):
     return synth.crop_scene(seed, r, e, m, f)
 
@@ -309,22 +365,40 @@ def test_estimate_pose_reference_size_stage_by_stage(cuda0, avg_queries):
     pk = eo.picks(S, seed)
     all_roots, n_roots = ops.p3p_all_roots(torch.from_numpy(X[:, :3]).to(cuda0), torch.from_numpy(p2d[:, :3]).to(cuda0), Ks)
     n_roots = n_roots.cpu().numpy()
-    sub = np.arange(0, S, 4)                                          # every 4th sample through the NumPy P3P
-    root_count_differs = pick_differs = 0
+    # Every 4th sample through the NumPy P3P.  Round-3 verdict: the old bounds (root counts may differ on 7 % of the samples,
+    # picks on 1 %) explained nothing.  Now every disagreement between the two ROOT SETS (matched root by root to 1e-5 rad /
+    # 1e-3 mm) is classified by tests/p3p_classify.py — sliver triangle, a root pair about to merge, a root at the edge of
+    # the positive-depth condition — and none may stay unexplained or be an invalid root; where the sets agree the picked
+    # root (the reference's random pick among the roots ordered by the 4th point's error, poseEstSurf.py:137-143) must be
+    # the same unless the two candidates' 4th-point errors tie to 1e-9 relative.
+    from tests import p3p_classify as pc
+    all_roots = all_roots.cpu().numpy().reshape(S, 4, 3, 4)
+    sub = np.arange(0, S, 4)
+    classes, pick_differs, pick_ties, n_solved = {}, 0, 0, 0
     for i in sub:
         if len(set(got_idx[i].tolist())) < 4:
             assert not ok[i]
             continue
         sols = eo.p3p_sorted(X[i], p2d[i], Ks)
-        if len(sols) != n_roots[i]:
-            root_count_differs += 1                                   # a root pair about to merge / a sliver triangle
+        dev_roots = [(all_roots[i, j][:, :3], all_roots[i, j][:, 3]) for j in range(n_roots[i])]
+        mm = pc.measures(X[i, :3], p2d[i, :3], Ks, dev_roots, sols)
+        c = pc.explain(mm)
+        if c:
+            classes[c] = classes.get(c, 0) + 1
             continue
         assert bool(sols) == bool(ok[i]), i
         if sols:
+            n_solved += 1
             Rr, tr = sols[int((int(pk[i]) * len(sols)) >> 32)]
-            pick_differs += int(not (synth.rot_angle(Rr, poses[i][:, :3]) < 1e-5 and np.linalg.norm(tr - poses[i][:, 3]) < 1e-3))
-    assert root_count_differs <= 0.07 * len(sub), root_count_differs
-    assert pick_differs <= 0.01 * len(sub), pick_differs              # 4th-point-error ties between two roots
+            if not (synth.rot_angle(Rr, poses[i][:, :3]) < 1e-5 and np.linalg.norm(tr - poses[i][:, 3]) < 1e-3):
+                e4 = sorted(float(np.sum((po_project(Ks, R_, t_, X[i, 3:4]) - p2d[i, 3]) ** 2)) for R_, t_ in sols)
+                gaps = [(b - a) / max(b, 1e-300) for a, b in zip(e4, e4[1:])]
+                pick_differs += 1
+                pick_ties += int(min(gaps) < 1e-9)
+    assert n_solved > 0.9 * len(sub)
+    assert not (set(classes) & {"unexplained", "invalid"}), classes
+    assert sum(classes.values()) <= 0.005 * len(sub), classes          # measured: 0 of 2 500 on either branch
+    assert pick_differs == pick_ties <= 0.002 * len(sub), (pick_differs, pick_ties)
     # ---- stage 5: pruning masks and the ordered selection (:147-177) from the device's poses
     nrm_d = torch.from_numpy(s["normals"].astype(np.float64)).to(cuda0)
     dist, sm, nm, keep, kidx, nk, Rt32 = pes.prune(corr_idx, poses_d, ok_d, pts_d, nrm_d, res, m, Ks[0, 0], s["diameter"], 0.1,

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 4: whole GPU suite, then the bench line
+set -eo pipefail
+: "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r04
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r04/t_all.log 2>&1 || { tail -40 gpurun_out/r04/t_all.log; exit 1; }
+tail -3 gpurun_out/r04/t_all.log
+timeout -k 10 600 python bench.py --steps 10 > gpurun_out/r04/bench_n1.json 2> gpurun_out/r04/bench_n1.err || { tail -20 gpurun_out/r04/bench_n1.err; exit 1; }
+python - <<'PY'
+import json; d=json.loads(open("gpurun_out/r04/bench_n1.json").read().strip().splitlines()[-1])
+print({k: d[k] for k in ("value","ms_per_step")}); print(d["roofline"]["f32_exact"]); print(d["roofline_ransac"]); print(d.get("reference_shape")); print(d.get("estimate_pose"))
+PY
