@@ -294,36 +294,40 @@ def measure_ransac(dev, pts, Kcam, M=245760, H=4096, reps=5):
 
 def measure_k1_f32(Q_img, keys_f32, dev, log2_domain):
     """K1 at the reference's own precision (f32 descriptors, the reference's f32 matmul, inference.py:142-149) on ONE image
-    of the workload.  Default route at D <= 64 since round 4: the three-plane split on the bf16 matrix cores (every f32
-    number as three bf16 planes, six plane pairs per 16-wide block, margin test + recheck by the f32 fmaf chain: the
-    indices of the chain kernel, bit for bit) — priced against the f32 matrix peak, the rate a plain f32 GEMM could reach;
-    beside it the f32-MFMA chain kernel (ISR_TUNE_K1_F32_CHAIN = 1), the only route in round 3 for D > 16."""
+    of the workload.  Default route at D <= 64 since round 4: every f32 number as f16 planes x1 | x2s | x1s, three plane
+    pairs per 16-wide block on the f16 matrix cores, margin test + recheck by the f32 fmaf chain — the indices of the chain
+    kernel bit for bit, log-probabilities to f32 accuracy — priced against the f32 matrix peak (what a plain f32 GEMM could
+    reach) and, as matrix instructions actually issued, against the 16-bit peak.  Beside it the bf16-plane form (six plane
+    pairs, ISR_TUNE_K1_F32_CHAIN = 2) and the f32-MFMA chain kernel (= 1), round 3's only route for D > 16."""
     q = Q_img.float() / (ops.LOG2E if log2_domain else 1.0)
     D = q.shape[1]
     flop = 2.0 * q.shape[0] * keys_f32.shape[0] * D
 
-    def timed_ms(reps=2):
-        ops.corr_argmax(q, keys_f32)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            out = ops.corr_argmax(q, keys_f32)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps, out
+    def timed(chain, reps=3):
+        with ops.tuning(k1_f32_chain=chain):
+            ops.corr_argmax(q, keys_f32)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                out = ops.corr_argmax(q, keys_f32)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps, out, ops.corr_recheck_count_f32(D)
 
-    ms, out = timed_ms()
-    rechecked = ops.corr_recheck_count_f32(D)
-    with ops.tuning(k1_f32_chain=1):
-        ms_chain, out_chain = timed_ms()
-    split = rechecked >= 0
-    return {"kernel": ("corr_bf16_direct_kernel<SP> (three-plane split of f32 rows on the bf16 MFMA, exact f32-chain recheck)"
-                       if split else "corr_f32_kernel (exact f32 MFMA path)"),
+    ms, out, rechecked = timed(0)
+    ms_bf, out_bf, _ = timed(2)
+    ms_chain, out_chain, _ = timed(1)
+    planes = rechecked >= 0
+    Dp = 16 if D <= 16 else 32 if D <= 32 else 64
+    return {"kernel": ("corr_bf16_direct_kernel<.., SP, F16> (f16 planes of the f32 rows, 3 plane pairs per block, exact f32-chain "
+                       "recheck)" if planes else "corr_f32_kernel (exact f32 MFMA path)"),
             "ms_per_image": ms, "achieved": flop / (ms * 1e-3) * 1e-12, "peak": PEAK_FP32_MFMA * 1e-12, "unit": "TFLOP/s",
             "frac": flop / (ms * 1e-3) / PEAK_FP32_MFMA,
-            "bf16_mfma_flop_frac": (6.0 * flop / (ms * 1e-3) / PEAK_BF16_MFMA) if split else None,
+            "matrix_instruction_flop_frac_of_16bit_peak": (3.0 * flop * Dp / D / (ms * 1e-3) / PEAK_BF16_MFMA) if planes else None,
             "queries_decided_by_f32_chain_recheck": rechecked,
+            "bf16_planes": {"ms_per_image": ms_bf, "frac": flop / (ms_bf * 1e-3) / PEAK_FP32_MFMA,
+                            "idx_equal": bool(torch.equal(out[0], out_bf[0]))},
             "f32_mfma_chain_kernel": {"ms_per_image": ms_chain, "achieved": flop / (ms_chain * 1e-3) * 1e-12,
                                       "frac": flop / (ms_chain * 1e-3) / PEAK_FP32_MFMA},
             "idx_equal_chain_kernel": bool(torch.equal(out[0], out_chain[0])),

@@ -699,17 +699,14 @@ __device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, b
                                             float* __restrict__ logp, float* __restrict__ lse) {
   const double ln2 = 0.6931471805599453094;
   // <= 0 like log_softmax (the sum contains the maximum's own term); rounding can leave it a few 1e-6 above
-  double lp, ls;
-  if (MODE == 1) {
-    lp = fmin(0.0, -(log(L) + (Rf - (double)G1) * ln2));
-    ls = (double)G1 * ln2 - lp;
-  } else {
-    lp = fmin(0.0, -(log(L) + (Rf * ln2 - (double)G1)));
-    ls = (double)G1 - lp;
-  }
+  // lse = ln L + Rf ln 2 from the canonical sum alone (round 4: it used to be formed as maximum - logp, which tied its last bit
+  // to the maximum; an lse-only call — idx == nullptr — has no maximum, and must return the same bits)
+  const double lnL = log(L);
+  const double lp = (MODE == 1) ? fmin(0.0, -(lnL + (Rf - (double)G1) * ln2)) : fmin(0.0, -(lnL + (Rf * ln2 - (double)G1)));
+  if (lse) lse[q] = (float)(lnL + Rf * ln2);
+  if (!idx) return;                       // lse-only call: no index to certify
   idx[q] = bi;
   if (logp) logp[q] = (float)lp;
-  if (lse) lse[q] = (float)ls;
   // The zero vector (a padding row of a capacity-sized crop batch, isr_prep_queries_batch): every product is an exact
   // zero, every logit is exactly 0, the arg-max is the lowest key — which is what `bi` already holds — and there is
   // nothing an exact recheck could decide differently.  (With eps = 0 the margin test below would list every such row:
@@ -1213,6 +1210,7 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
                 const CorrWs& ws, int32_t* idx, float* logp, float* lse, F32Rows f32, float kn_inflate, hipStream_t stream,
                 int sp = 0, bool f16 = false) {
   const float eabs = (sp && f16) ? split_eabs(sp) : 0.f;
+  const bool lse_only = idx == nullptr;      // no maxima, no recovery, no recheck (LSE instantiations where they exist)
   const dim3 grid(p.qblocks, p.nsplit);
   const int fin_blocks = (P + 255) / 256;
   const int fin_bf16 = (p.nsplit == 1 && fin_blocks > kFallbackGrid) ? kFallbackGrid : fin_blocks;   // one key range: list-driven
@@ -1231,6 +1229,10 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
 #define ISR_LAUNCH_BF16(DKv)                                                                                  \
   do {                                                                                                        \
     if (log2) {                                                                                               \
+      if (lse_only && DKv <= 2)   /* LSE kernels where both copies of their loop fit the registers: D <= 32 */ \
+        corr_bf16_direct_kernel<DKv, kQB, false, DKv, 0, false, (DKv <= 2)><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, \
+                                                                              p.range_chunks, ws, idx, logp, lse); \
+      else                                                                                                    \
       corr_bf16_direct_kernel<DKv, kQB, false><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,          \
                                                                               p.range_chunks, ws, idx, logp, lse); \
       corr_bf16_kernel<DKv, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,      \
@@ -1245,16 +1247,21 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
       corr_finalize_kernel<2><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
     }                                                                                                         \
-    corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);  \
+    if (!lse_only) corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);  \
   } while (0)
 #define ISR_LAUNCH_PLANES(SPv, F16v)                                                                                              \
   do {                                                                                                                            \
+    if (lse_only && F16v && SPv <= 2)                                                                                             \
+      corr_bf16_direct_kernel<3 * SPv, kQB, false, 3 * SPv, SPv, F16v, (F16v && SPv <= 2)><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,  \
+                                                                                                     p.range_chunks, ws, idx, logp, lse); \
+    else                                                                                                                          \
     corr_bf16_direct_kernel<3 * SPv, kQB, false, 3 * SPv, SPv, F16v><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,          \
                                                                                                      p.range_chunks, ws, idx, logp, lse); \
     corr_bf16_kernel<3 * SPv, true, SPv, F16v><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,   \
                                                                                 p.nchunks, ws);                                    \
     corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);   \
-    corr_recheck_kernel<3 * SPv, SPv, F16v><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);      \
+    if (!lse_only)                                                                                                                \
+      corr_recheck_kernel<3 * SPv, SPv, F16v><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);    \
   } while (0)
   if (sp) {          // plane routes (log2 domain, f32 originals decide the recheck)
     switch (sp * 2 + (f16 ? 1 : 0)) {
@@ -1271,7 +1278,7 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     corr_bf16_direct_kernel<8, kQB, false, 6><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws, idx, logp, lse);
     corr_bf16_kernel<8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
     corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
-    corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
+    if (!lse_only) corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
   } else
   switch (D) {
     case 16: ISR_LAUNCH_BF16(1); break;
@@ -1280,7 +1287,7 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     default: ISR_LAUNCH_BF16(8); break;
   }
 #undef ISR_LAUNCH_BF16
-  corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, N, p.rsplit, ws, idx);
+  if (!lse_only) corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, N, p.rsplit, ws, idx);
   ISR_CHECK_LAUNCH("corr bf16 kernels");
   return ISR_OK;
 }
@@ -1308,7 +1315,8 @@ int launch_f32_chain(const float* q, const float* k, int P, int N, int D, int ld
 extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
                                int dtype, int32_t* idx, float* logp, float* lse, void* ws_,
                                size_t ws_bytes, isr_stream_t stream_) {
-  ISR_REQUIRE(Q && K && idx, "isr_corr_argmax: null pointer");
+  ISR_REQUIRE(Q && K && (idx || (lse && !logp)),
+              "isr_corr_argmax: null pointer (idx may be null only for an lse-only call: logp null, lse given)");
   ISR_REQUIRE(P > 0 && N > 0 && D > 0, "isr_corr_argmax: P=%d N=%d D=%d must be positive", P, N, D);
   ISR_REQUIRE(ldq >= D && ldk >= D, "isr_corr_argmax: ldq=%d ldk=%d < D=%d", ldq, ldk, D);
   ISR_REQUIRE(dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2 || dtype == ISR_DTYPE_F32,

@@ -52,7 +52,13 @@ __device__ __forceinline__ float tile_max(const f32x16& acc) {
 // padding: their MFMAs would add exact zeros, so they are not issued — same bits, 6 instead of 8 matrix instructions per tile).
 // SP > 0: split rows (RowFrags / tile_chain in corr_argmax.hip): three planes of SP blocks per operand row, 6 SP matrix
 // instructions per tile (3 SP with f16 planes, F16); DK = 3 SP, DKU unused.
-template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0, bool F16 = false>
+// LSE: the caller wants the log-sum-exp only (pose_refine.py:56's denominator image, estimate_pose's row sums): no maxima
+// are tracked (12 of the 44 VALU instructions of a tile), no row is recovered, nothing is rechecked.  What the maximum did for
+// the RANGE of the sum — a query is redone with a per-query reference when its maximum is below kLow — is decided from the
+// Cauchy-Schwarz bound instead: |s'| <= |q||k|_max < kLseBound puts every term inside [2^-99, 2^99] and the maximum above kLow;
+// a query that fails the bound goes to the fallback as a bad one does.  The sums, and with them lse, are the full kernel's bits.
+constexpr float kLseBound2 = 99.f * 99.f;
+template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0, bool F16 = false, bool LSE = false>
 __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
@@ -152,7 +158,8 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         for (int qb = 0; qb < QB; ++qb) {
           const int q = q0 + qb * 32 + r;
           if (h == 0 && q < P)
-            corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, DEFF, EABS, 0.f, kn2z, ws, idx_out, logp_out, lse_out);
+            corr_finish<NAT ? 2 : 1>(q, 0.f, 0.f, 0, false, (double)N, 0.0, DEFF, EABS, 0.f, kn2z, ws, LSE ? nullptr : idx_out,
+                                     LSE ? nullptr : logp_out, lse_out);
         }
       } else {
         const int zc0 = split * range_chunks;
@@ -275,8 +282,11 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   f32x16 acc[2];
   acc[0] = tile_chain<DKU, SP, F16>(a, bq[0], splat16(0.f));
 
-  auto stage_body = [&](int stage, auto full_tag) {
+  // TRK: track the maxima.  Always, except in an LSE kernel whose wave holds only queries the Cauchy-Schwarz bound keeps
+  // inside the direct sum's range (the loop exists twice there; which copy runs is wave-uniform).
+  auto stage_body = [&](int stage, auto full_tag, auto trk_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
+    constexpr bool TRK = !LSE || decltype(trk_tag)::value;
     const int buf = stage & 1;
     const bool has_next = stage + 1 < nstage;
     if constexpr (!DMA) { if (has_next) gload(stage + 1); }
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
 #pragma unroll
             for (int j = 0; j < SP; ++j) c = mfma16<F16>(a[RF::PA[ph] * SP + j], bq[qbn][RF::PB[ph] * SP + j], c);
             if (RF::RD[ph] >= 0) reads(RF::RD[ph]);
-            if (ph == 0) {
+            if (ph == 0 && TRK) {
               const float t = tile_max(cur);
               st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);   // second largest of {m, m2, t} (m2 <= m)
               st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;                     // strict: the first tile to reach m keeps it
@@ -358,10 +368,12 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         asm volatile("" :: "v"(cur[0]), "v"(cur[15]));
         st[qb].m = 0.f;
 #else
-        const float t = tile_max(cur);
-        st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);   // second largest of {m, m2, t} (m2 <= m)
-        st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;                     // strict: the first tile to reach m keeps it
-        st[qb].m = fmaxf(st[qb].m, t);
+        if constexpr (TRK) {
+          const float t = tile_max(cur);
+          st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);   // second largest of {m, m2, t} (m2 <= m)
+          st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;                     // strict: the first tile to reach m keeps it
+          st[qb].m = fmaxf(st[qb].m, t);
+        }
 #endif
         float l = st[qb].l;
 #ifdef ISR_ABL_DNOEXP
@@ -378,7 +390,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
         // ties the item's results to a fixed point of the instruction stream: a stage is one basic
         // block, and without it instruction selection sinks all eight epilogues below all eight MFMA
         // chains (eight tiles live, 243 VGPRs, nothing overlapped).
-        constexpr int G = ((NAT ? 60 : 44) + NMF - 1) / NMF;
+        constexpr int G = ((NAT ? 60 : 44) - (TRK ? 0 : 12) + NMF - 1) / NMF;
 #pragma unroll
         for (int s = 0; s < NMF; ++s) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -396,25 +408,52 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   bool over[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) over[qb] = false;
-  int stage = 0;
-  for (int c = c0; stage < nstage; ++c) {
-    const int send = min(nstage, stage + CSTAGES);
-    const int sfull = min(nfull, send);
-    for (; stage < sfull; ++stage) stage_body(stage, std::true_type{});
-    if (stage < send) { stage_body(stage, std::false_type{}); ++stage; }   // only a range's last stage is partial
+  auto run_chunks = [&](auto trk_tag) {
+    int stage = 0;
+    for (int c = c0; stage < nstage; ++c) {
+      const int send = min(nstage, stage + CSTAGES);
+      const int sfull = min(nfull, send);
+      for (; stage < sfull; ++stage) stage_body(stage, std::true_type{}, trk_tag);
+      if (stage < send) { stage_body(stage, std::false_type{}, trk_tag); ++stage; }   // only a range's last stage is partial
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      const float lc = st[qb].l + __shfl_xor(st[qb].l, 32, 64);
-      over[qb] |= !(lc <= 3.0e38f);     // the same on both lanes of the query
-      const int q = q0 + qb * 32 + r;
-      if (whole) st[qb].L += (double)lc;                    // the first chunk: 0 + l_0 = l_0, as in the finalize merge
-      else if (h == 0 && q < P) ws.plc[(size_t)c * P + q] = lc;
-      st[qb].l = 0.f;
+      for (int qb = 0; qb < QB; ++qb) {
+        const float lc = st[qb].l + __shfl_xor(st[qb].l, 32, 64);
+        over[qb] |= !(lc <= 3.0e38f);     // the same on both lanes of the query
+        const int q = q0 + qb * 32 + r;
+        if (whole) st[qb].L += (double)lc;                    // the first chunk: 0 + l_0 = l_0, as in the finalize merge
+        else if (h == 0 && q < P) ws.plc[(size_t)c * P + q] = lc;
+        st[qb].l = 0.f;
+      }
     }
+  };
+  // LSE: does any query of this wave need its maximum to decide whether the direct sum applies?  (|s'| <= |q||k|_max < 99
+  // log2 units keeps every term a normal f32 and the maximum above kLow: the full kernel calls such a query good too.)
+  bool trk = true;
+  if constexpr (LSE) {
+    const float kn2l = kn2_max(ws);
+    bool unsure = false;
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) unsure |= !((NAT ? kLog2e * kLog2e : 1.f) * qn2[qb] * kn2l < kLseBound2);
+    trk = __any(unsure) != 0;
   }
+  if (trk) run_chunks(std::true_type{});
+  else run_chunks(std::false_type{});
 
   // ---- row recovery: one MFMA chain per distinct winning tile of the wave's queries
   bool any_bad_lane = false;
+  if constexpr (LSE) {
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      // the full kernel's rule — overflow, or a maximum below kLow — on the maximum where the wave tracked it; where it did
+      // not, the bound has shown that neither can happen
+      const float M = fmaxf(st[qb].m, __shfl_xor(st[qb].m, 32, 64));
+      const bool bad_q = over[qb] || (trk && !((NAT ? M * kLog2e : M) >= kLow));   // the same on both lanes of the query
+      const int q = q0 + qb * 32 + r;
+      if (whole) over[qb] = bad_q;
+      else if (h == 0 && q < P) ws.pbad[(size_t)split * P + q] = bad_q ? 1 : 0;
+      any_bad_lane |= bad_q && q < P;
+    }
+  } else
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     // the two lanes (h = 0, 1) of a query agree on (M, T): the maximum and the lowest tile reaching it
@@ -512,7 +551,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       if (over[qb]) ws.qn2[q] = qn2[qb];
     }
     if (!over[qb])
-      corr_finish<NAT ? 2 : 1>(q, st[qb].m, st[qb].m2, st[qb].tb, false, st[qb].L, 0.0, DEFF, EABS, qn2[qb], kn2,
-                               ws, idx_out, logp_out, lse_out);
+      corr_finish<NAT ? 2 : 1>(q, LSE ? 0.f : st[qb].m, LSE ? 0.f : st[qb].m2, LSE ? 0 : st[qb].tb, false, st[qb].L, 0.0, DEFF, EABS,
+                               qn2[qb], kn2, ws, LSE ? nullptr : idx_out, LSE ? nullptr : logp_out, lse_out);
   }
 }

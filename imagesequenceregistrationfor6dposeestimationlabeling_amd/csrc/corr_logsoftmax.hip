@@ -222,7 +222,8 @@ int row_lse(const float* Q, const float* K, int P, int N, int D, int ldq, int ld
   void* k1 = w.take<char>(0);
   const size_t used = (size_t)(static_cast<char*>(k1) - static_cast<char*>(ws));
   *lse_out = lse;
-  return isr_corr_argmax(Q, K, P, N, D, ldq, ldk, ISR_DTYPE_F32, idx, nullptr, lse, k1, ws_bytes - used, stream);
+  (void)idx;   // an lse-only call of K1 (idx == nullptr): no maxima tracked, nothing rechecked
+  return isr_corr_argmax(Q, K, P, N, D, ldq, ldk, ISR_DTYPE_F32, nullptr, nullptr, lse, k1, ws_bytes - used, stream);
 }
 
 }  // namespace

@@ -1480,7 +1480,8 @@ extern "C" int isr_estimate_pose(const float* mask_lgts, const float* query_img,
   // descriptor grid: pooled queries (win 1) or the crop's own pixels (win = scale)
   const float* qgrid = avg_queries ? L.queries : query_img;
   const int rows = avg_queries ? n : r * r, pitch = avg_queries ? res : r, win = avg_queries ? 1 : scale;
-  rc = isr_corr_argmax(qgrid, obj_keys, rows, m, e, e, e, ISR_DTYPE_F32, L.k1_idx, nullptr, L.lse, L.ws_k1, L.b_k1, stream_);
+  // the rows' log-sum-exps: an lse-only call of K1 (idx == nullptr)
+  rc = isr_corr_argmax(qgrid, obj_keys, rows, m, e, e, e, ISR_DTYPE_F32, nullptr, nullptr, L.lse, L.ws_k1, L.b_k1, stream_);
   if (rc != ISR_OK) return rc;
   rc = isr_ep_sample_direct(qgrid, L.lse, pitch, e, win, res, L.mprob, obj_keys, m, alpha, max_poses, seed, L.corr_idx, L.ws_sample,
                             L.b_sample, stream_);

@@ -241,6 +241,41 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     return (idx, logp, lse) if want_lse else (idx, logp)
 
 
+def corr_lse(queries: torch.Tensor, keys: torch.Tensor, log2_prescaled: bool = False) -> torch.Tensor:
+    """The row log-sum-exps of queries @ keys.T alone — pose_refine.py:56's denominator image, estimate_pose's row sums
+    (poseEstSurf.py:68-71) — as an lse-only call of isr_corr_argmax (idx = logp = NULL): no maxima are tracked, no index is
+    certified, and the values are the bits corr_argmax(..., want_lse=True) returns."""
+    dev = require_cuda(queries, keys)
+    if queries.ndim != 2 or keys.ndim != 2 or queries.shape[1] != keys.shape[1]:
+        raise ValueError(f"queries {tuple(queries.shape)} / keys {tuple(keys.shape)} must be (P,D),(N,D)")
+    P, D = queries.shape
+    N = keys.shape[0]
+    if P == 0 or N == 0:
+        raise ValueError("empty queries or keys")
+    if queries.dtype == torch.bfloat16 and keys.dtype == torch.bfloat16:
+        dtype = _capi.DTYPE_BF16_LOG2 if log2_prescaled else _capi.DTYPE_BF16
+        Dp = next((d for d in (16, 32, 64, 128) if d >= D), None)
+        if Dp is None:
+            raise ValueError(f"bf16 path supports D <= 128, got {D}")
+    else:
+        if log2_prescaled:
+            raise ValueError("log2_prescaled needs bf16 queries and keys")
+        dtype = _capi.DTYPE_F32
+        queries, keys = queries.to(torch.float32), keys.to(torch.float32)
+        Dp = D
+        if D > 128:
+            raise ValueError(f"f32 path supports D <= 128, got {D}")
+    q, k = _pad_cols(queries, Dp), _pad_cols(keys, Dp)
+    lse = torch.empty(P, dtype=torch.float32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_corr_argmax_workspace_bytes(P, N, Dp, dtype), "corr")
+    with torch.cuda.device(dev), _timed("corr_lse", 2.0 * P * N * Dp):
+        rc = L.isr_corr_argmax(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, None, None, ptr(lse), ptr(ws), ws.numel(),
+                               current_stream(dev))
+    check(rc, "isr_corr_argmax (lse only)")
+    return lse
+
+
 _last_corr = None
 
 

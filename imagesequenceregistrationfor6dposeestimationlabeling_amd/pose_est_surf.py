@@ -137,7 +137,7 @@ class DescriptorGrid:
 
     @staticmethod
     def row_lse(q_rows: torch.Tensor, keys: torch.Tensor) -> torch.Tensor:
-        return ops.corr_argmax(q_rows, keys, want_lse=True)[2]
+        return ops.corr_lse(q_rows, keys)      # K1, lse only (the bits of corr_argmax(..., want_lse=True)[2])
 
     @classmethod
     def pooled(cls, queries: torch.Tensor, keys: torch.Tensor, res: int, lse: torch.Tensor = None):

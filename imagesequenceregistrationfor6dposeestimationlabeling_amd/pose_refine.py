@@ -108,10 +108,9 @@ def rodrigues(rvec):
 
 
 def denominator_image(query_img: torch.Tensor, keys_sampled: torch.Tensor) -> torch.Tensor:
-    """pose_refine.py:56: logsumexp(query_img @ keys_sampled.T, -1) -> (H, W, 1), via K1's lse output."""
+    """pose_refine.py:56: logsumexp(query_img @ keys_sampled.T, -1) -> (H, W, 1): an lse-only call of K1."""
     H, W, e = query_img.shape
-    _, _, lse = ops.corr_argmax(query_img.reshape(H * W, e).to(torch.float32), keys_sampled.to(torch.float32),
-                                want_lse=True)
+    lse = ops.corr_lse(query_img.reshape(H * W, e).to(torch.float32), keys_sampled.to(torch.float32))
     return lse.reshape(H, W, 1)
 
 

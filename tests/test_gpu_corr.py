@@ -565,6 +565,39 @@ def test_corr_f32_plane_routes_repeat_bit_for_bit(cuda0, D, chain):
     assert float((first[1] - ref[1]).abs().max()) < 2e-5 and float((first[2] - ref[2]).abs().max()) < 2e-4
 
 
+@pytest.mark.parametrize("kind,P,N,D,chain", [("f32", 50176, 80000, 12, 0), ("f32", 5476, 80000, 12, 0), ("f32", 3000, 10960, 12, 0),
+                                              ("f32", 4000, 9000, 40, 0), ("f32", 4000, 9000, 12, 2), ("f32", 4000, 9000, 12, 1),
+                                              ("f32", 4000, 9000, 12, 4), ("bf16_log2", 6000, 20000, 64, 0), ("bf16", 3000, 5000, 32, 0),
+                                              ("f32", 300, 31, 12, 0)])
+def test_corr_lse_only_call_returns_the_full_call_s_lse(cuda0, kind, P, N, D, chain):
+    """isr_corr_argmax with idx = logp = NULL (ops.corr_lse: pose_refine.py:56's denominator image, estimate_pose's row sums):
+    the LSE instantiations track no maxima, recover no rows and recheck nothing, queries whose Cauchy-Schwarz bound
+    |q||k|_max leaves the direct sum's range are redone with a per-query reference as bad ones are — and the values are
+    torch.equal to the lse output of the full call, on every route (routes without an LSE instantiation run the full kernels
+    with the index writes off), with zero rows, out-of-range rows, one key range and several."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    g = torch.Generator(device=cuda0).manual_seed(P + N + D)
+    K = torch.randn(N, D, device=cuda0, generator=g)
+    K = 5.0 * K / K.norm(dim=1, keepdim=True)
+    Q = 1.2 * K[torch.randint(N, (P,), device=cuda0, generator=g)] + 0.3 * (12.0 / max(D, 12)) ** 0.5 * torch.randn(P, D, device=cuda0, generator=g)
+    Q[::9] = 0.0
+    Q[5] *= 30.0                                   # far outside the direct sum's range: the per-query fallback
+    Q[7] *= 12.0                                   # fails the bound (|q||k| > 99 log2 units) while its logits would have fitted
+    Q[11] = -8.0 * K[11]                           # every logit far below zero except none: maximum below kLow
+    if P >= 3000:
+        Q[1024:1280] = 0.0
+    log2 = kind == "bf16_log2"
+    if kind != "f32":
+        Q, K = (ops.prescale_queries_log2(Q) if log2 else Q.bfloat16()), K.bfloat16()
+    for ns in ((0, 1, 2, 3) if P >= 3000 else (0,)):
+        with ops.tuning(k1_f32_chain=chain, k1_split=ns):
+            full = ops.corr_argmax(Q, K, want_lse=True, log2_prescaled=log2)[2]
+            only = ops.corr_lse(Q, K, log2_prescaled=log2)
+        assert torch.equal(only, full), (ns, int((only != full).sum()))
+    ref = torch.logsumexp((Q.double() / (ops.LOG2E if log2 else 1.0)) @ K.double().T, dim=-1)
+    assert float((only.double() - ref).abs().max()) < (2e-5 if kind == "f32" else 2e-2) * (1.0 + float(ref.abs().max()) / 50.0)
+
+
 @pytest.mark.parametrize("where", ["query", "key"])
 def test_corr_f32_f16_planes_fall_through_when_a_descriptor_does_not_fit_f16(cuda0, oracle_lib, where):
     """The default f32 route keeps f16 planes; an |x| >= 65 000 anywhere raises the gate word in its split kernel (finite
