@@ -361,7 +361,10 @@ def estimate_pose(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diam
     materialize=False (default): the (n, m) correspondence matrices of :70-107 are never formed — the sampler and the
     scorer compute the elements they need from the descriptors (DescriptorGrid); True: the round-2/3 route through the
     arrays (corr_matrices / patch_corr + pool_corr).  Both return the same bits."""
-    if not materialize and poses is None and not returnPoints and not visualize:
+    # isr_estimate_pose scores every surviving pose in ONE scorer launch (pose = blockIdx.y: at most 65 535); a larger
+    # max_pose_evaluations (or do_prune=False with a large max_poses) takes the staged route below, which scores in
+    # pose_batch_size batches as the reference does (poseEstSurf.py:225-237)
+    if not materialize and poses is None and not returnPoints and not visualize and int(max_pose_evaluations) <= 65535:
         return _estimate_pose_one_call(mask_lgts, query_img, obj_pts, obj_normals, obj_keys, obj_diameter, K, max_poses,
                                        max_pose_evaluations, down_sample_scale, alpha, dist_2d_min, max_pool, avg_queries,
                                        do_prune, debug, seed)

@@ -166,6 +166,8 @@ def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tenso
         for s in pool:
             cur.wait_stream(s)
         _publish(out, cur)
+        for n_dev in counts:              # allocated on k1_stream, read by the cat below on the caller's stream
+            n_dev.record_stream(cur)
     n_all = torch.cat(counts)
     return out, n_all
 

@@ -85,6 +85,12 @@ int isr_tuning_get(int knob);
  *             margin is inside the f32 accumulation error bound are re-decided in exact arithmetic)
  *   logp[p] = max_n logit - logsumexp_n logit   (= the top-1 value of log_softmax)
  *   lse[p]  = logsumexp_n logit      (nullable)
+ * idx = logp = NULL with lse given: an lse-only call (pose_refine.py:56, poseEstSurf.py:68-71) — no maxima tracked, no index
+ * certified; lse carries the bits of a full call's.
+ * f32, D <= 64 (round 4): the rows run on the 16-bit matrix cores as f16 planes (x1 | x2s | x1s, three plane pairs per
+ * 16-wide block) with a margin test and a recheck by the k-ordered f32 fmaf chain of the ORIGINAL rows — idx is the chain's
+ * arg-max bit for bit, logp / lse are accurate to f32 (2^-21 |q||k|); descriptors must be finite, and a call holding an
+ * |element| >= 65 000 runs the f32-MFMA chain kernels instead (decided on the device).  ISR_TUNE_K1_F32_CHAIN selects the others.
  * The (P x N) matrix is never materialised.
  */
 size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype);
@@ -372,7 +378,9 @@ int isr_zbuf_score_direct(const float* obj_pts, int m, const float* Rt, int B, c
  * pose / mask / coord scores (max_pose_evaluations), and per SAMPLE (max_poses each) dist_2d f32, size_mask, normals_mask,
  * solved u8 (the reference's returned arrays are the entries with solved = 1, in order).  *n_poses_host = how many poses were
  * scored (rows of Rt32 / scores that are valid), *n_keep_host (nullable) = how many samples survived the pruning.  The stream
- * is synchronised once (the survivor count sizes the scoring launch).  Same bits as the stage entry points in sequence. */
+ * is synchronised once INSIDE the call (hipStreamSynchronize: the survivor count sizes the scoring launch), so the entry cannot
+ * be used under stream capture; max_pose_evaluations <= 65 535 (one scorer launch, pose = blockIdx.y — larger values: the stage
+ * entry points, scoring in slices, as pose_est_surf.estimate_pose does).  Same bits as the stage entry points in sequence. */
 size_t isr_estimate_pose_workspace_bytes(int r, int e, int m, int scale, int max_poses, int max_pose_evaluations,
                                          int avg_queries);
 int isr_estimate_pose(const float* mask_lgts, const float* query_img, int r, int e, const float* obj_pts,
