@@ -276,6 +276,35 @@ def corr_lse(queries: torch.Tensor, keys: torch.Tensor, log2_prescaled: bool = F
     return lse
 
 
+def corr_topk(queries: torch.Tensor, keys: torch.Tensor, k: int):
+    """getCors with leaves = k > 1 (inference.py:145-149): per query the k largest entries of log_softmax(queries @ keys.T)
+    and their keys — isr_corr_topk behind an lse-only K1 call; the (P, N) matrix is never formed.  Any float dtype (bf16 /
+    f16 rows are widened exactly); 1 <= k <= 8.  Returns idx (P, k) int32, vals (P, k) f32 on the device, descending,
+    equal values by ascending key."""
+    dev = require_cuda(queries, keys)
+    if queries.ndim != 2 or keys.ndim != 2 or queries.shape[1] != keys.shape[1]:
+        raise ValueError(f"queries {tuple(queries.shape)} / keys {tuple(keys.shape)} must be (P,D),(N,D)")
+    if not 1 <= int(k) <= 8:
+        raise ValueError(f"leaves = {k}: 1 .. 8 are supported without materialising the matrix")
+    q, kk = _f32c(queries), _f32c(keys)
+    P, D = q.shape
+    N = kk.shape[0]
+    if P == 0 or N == 0:
+        raise ValueError("empty queries or keys")
+    if D > 128:
+        raise ValueError(f"D <= 128, got {D}")
+    lse = corr_lse(q, kk)
+    idx = torch.empty((P, int(k)), dtype=torch.int32, device=dev)
+    vals = torch.empty((P, int(k)), dtype=torch.float32, device=dev)
+    L = lib()
+    ws = workspace(dev, L.isr_corr_topk_workspace_bytes(P, N), "corr_topk")
+    with torch.cuda.device(dev):
+        rc = L.isr_corr_topk(ptr(q), ptr(kk), P, N, D, D, D, int(k), ptr(lse), ptr(idx), ptr(vals), ptr(ws), ws.numel(),
+                             current_stream(dev))
+    check(rc, "isr_corr_topk")
+    return idx, vals
+
+
 _last_corr = None
 
 

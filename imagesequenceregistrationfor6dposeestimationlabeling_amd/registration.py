@@ -50,14 +50,18 @@ def getCors(queries, feats, leaves=1):
     cMat = log_softmax(queries @ feats.T, -1); vals, idx = topk(cMat, leaves)
     returns (idx[...,0].cpu(), vals) for leaves == 1 — idx a CPU LongTensor (P,), vals (P,1) on
     the device — else (idx.cpu() (P,leaves), vals (P,leaves)).
-    bf16 inputs run the bf16 MFMA kernel, anything else the exact-f32 MFMA kernel; the (P,N)
-    matrix is never materialised for leaves == 1."""
+    bf16 inputs run the bf16 MFMA kernel, anything else the exact-f32 route (f16 planes on the matrix cores, indices of
+    the f32 fmaf chain); the (P,N) matrix is never materialised for leaves <= 8."""
     q, f = _dev(queries), _dev(feats)
     if leaves == 1:
         idx, logp = ops.corr_argmax(q, f)
         return idx.to(torch.int64).cpu(), logp[:, None]
-    # leaves > 1 (never used by the reference's call sites): materialise the log-softmax matrix with
-    # the HIP kernel, then torch.topk picks the k largest per row as the reference does
+    # leaves > 1 (no call site of the reference passes one).  Up to 8: isr_corr_topk keeps each query's list in registers
+    # while the keys stream by (round 3 materialised the (P, N) log-softmax matrix and ran torch.topk on it: 1.8 GB at the
+    # reference's 5 625 x 80 000); more than 8 leaves still take that route.
+    if leaves <= 8:
+        idx, vals = ops.corr_topk(q, f, leaves)
+        return idx.to(torch.int64).cpu(), vals
     cMat = ops.corr_logsoftmax(q, f)
     vals, idx = torch.topk(cMat, k=leaves, dim=-1)
     return idx.cpu(), vals

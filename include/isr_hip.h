@@ -119,6 +119,15 @@ size_t isr_corr_logsoftmax_workspace_bytes(int P, int N, int D, int dtype);
 int isr_corr_logsoftmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
                         int dtype, float* out, int64_t ldo, void* ws, size_t ws_bytes, isr_stream_t stream);
 
+/* K1 with leaves > 1: getCors(queries, feats, leaves) = topk(log_softmax(queries @ feats.T), leaves) (inference.py:145-149)
+ * without the (P x N) matrix.  f32 rows, D <= 128, 1 <= k <= 8; lse (P) = the rows' log-sum-exps from an lse-only
+ * isr_corr_argmax call on the same rows.  Per query the k largest k-ordered-fmaf-chain logits (the values
+ * isr_corr_logsoftmax writes), descending, equal values by ascending key: idx (P, k) int32 (-1 where N < k), vals (P, k) =
+ * logit - lse. */
+size_t isr_corr_topk_workspace_bytes(int P, int N);
+int isr_corr_topk(const float* Q, const float* K, int P, int N, int D, int ldq, int ldk, int k, const float* lse,
+                  int32_t* idx, float* vals, void* ws, size_t ws_bytes, isr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * hand-off from the descriptor network to K1
  * replaces  imfeats[:, ::3, ::3]; inputMask[::3, ::3]; maskIds = torch.where(inputMask);

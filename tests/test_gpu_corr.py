@@ -598,6 +598,45 @@ def test_corr_lse_only_call_returns_the_full_call_s_lse(cuda0, kind, P, N, D, ch
     assert float((only.double() - ref).abs().max()) < (2e-5 if kind == "f32" else 2e-2) * (1.0 + float(ref.abs().max()) / 50.0)
 
 
+@pytest.mark.parametrize("P,N,D,k", [(5625, 80000, 12, 3), (300, 31, 12, 8), (1000, 4097, 40, 5), (257, 9000, 100, 2), (64, 5, 12, 8),
+                                     (2000, 20000, 64, 1)])
+def test_corr_topk_without_the_matrix(cuda0, P, N, D, k):
+    """getCors(leaves = k) through isr_corr_topk (the (P, N) matrix never exists) against torch.topk on the materialised
+    log-softmax matrix of isr_corr_logsoftmax — the round-3 route, whose elements are the same k-ordered fmaf chains minus
+    the same lse: indices equal wherever the matrix's k + 1 largest entries of a row are distinct, values to 2e-6; duplicate
+    keys (equal values: the lower key first), zero rows (every value equal: keys 0 .. k - 1), N < k (-1 beyond the keys)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, registration
+    g = torch.Generator(device=cuda0).manual_seed(P + N + D + k)
+    K = torch.randn(N, D, device=cuda0, generator=g)
+    K = 5.0 * K / K.norm(dim=1, keepdim=True)
+    if N > 20:
+        K[N // 2] = K[0]
+        K[N - 1] = K[0]
+    Q = 1.2 * K[torch.randint(N, (P,), device=cuda0, generator=g)] + 0.3 * (12.0 / max(D, 12)) ** 0.5 * torch.randn(P, D, device=cuda0, generator=g)
+    Q[::11] = 0.0
+    Q[3] = 1.5 * K[0]                                   # three equal winners: keys 0, N // 2, N - 1 in that order
+    idx, vals = ops.corr_topk(Q, K, k)
+    kk = min(k, N)
+    cMat = ops.corr_logsoftmax(Q, K)
+    rv, ri = torch.topk(cMat, k=min(kk + 1, N), dim=-1)
+    # rows whose k + 1 best matrix entries are pairwise distinct have one right answer
+    distinct = (rv[:, :-1] != rv[:, 1:]).all(dim=1) if rv.shape[1] > 1 else torch.ones(P, dtype=torch.bool, device=cuda0)
+    assert int(distinct.sum()) > 0.7 * P - 30
+    assert torch.equal(idx[distinct][:, :kk].long(), ri[distinct][:, :kk])
+    assert float((vals[:, :kk] - rv[:, :kk]).abs().max()) < 2e-6 * (1.0 + float(rv[:, :kk].abs().max()))
+    if N < k:
+        assert bool((idx[:, N:] == -1).all())
+    # ties: by ascending key
+    assert idx[0, :kk].tolist() == list(range(kk))                                  # a zero row
+    if N > 20 and k >= 3:
+        assert idx[3, :3].tolist() == [0, N // 2, N - 1]
+    # the reference's call shape
+    ci, cv = registration.getCors(Q, K, leaves=k)
+    assert ci.dtype == torch.int64 and not ci.is_cuda and cv.is_cuda
+    if k > 1:
+        assert tuple(ci.shape) == (P, k) and torch.equal(ci, idx.long().cpu()) and torch.equal(cv, vals)
+
+
 @pytest.mark.parametrize("where", ["query", "key"])
 def test_corr_f32_f16_planes_fall_through_when_a_descriptor_does_not_fit_f16(cuda0, oracle_lib, where):
     """The default f32 route keeps f16 planes; an |x| >= 65 000 anywhere raises the gate word in its split kernel (finite
