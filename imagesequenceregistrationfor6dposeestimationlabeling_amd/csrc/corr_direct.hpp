@@ -201,7 +201,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   // 16-byte units of the stage image, so the swizzle sits on the SOURCE side — unit u of the image takes the chunk that
   // belongs there, key_slot being its own inverse inside a plane): 24 staging registers and the ds_write pass less in a
   // kernel whose 24 + 12 operand fragments leave none to spare.
-  constexpr bool DMA = SP != 0;
+#ifndef ISR_DIRECT_DMA
+#define ISR_DIRECT_DMA 1      // plain rows (power-of-two chunk counts) through the same DMA staging: -1.5 % at D = 64 (profiles/r04_k1_dma_ab.txt); 0: registers + ds_write
+#endif
+  constexpr bool DMA = SP != 0 || (ISR_DIRECT_DMA != 0 && POW2);
   int koff[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -242,13 +245,22 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   bf16x8 a[NFR];
   // split rows: block j of every plane sits at the lane's rb[j] plus a compile-time offset (the XOR term of key_slot depends
   // on r alone: 32 rows are a multiple of its period) — one address register per block, the rest in the ds_read's immediate
-  int rb[SP ? SP : 1];
-  if constexpr (SP != 0) {
+  // plain rows of up to four blocks: the same, one register per block (the swizzle term of `slot` depends on r alone there too)
+  constexpr bool RB = SP != 0 || NFR <= 4;
+  int rb[RB ? (SP ? SP : NFR) : 1];
+  if constexpr (RB) {
 #pragma unroll
-    for (int j = 0; j < SP; ++j) rb[j] = r * NCH + slot(r, 2 * j + h);
+    for (int j = 0; j < (SP ? SP : NFR); ++j) rb[j] = r * NCH + slot(r, 2 * j + h);
   }
   auto load_a = [&](int buf, int sub) {
-    if constexpr (SP != 0) {
+    if constexpr (SP == 0 && RB) {
+      const uint4* lp = &lds[0][0] + buf * CHUNKS;
+#pragma unroll
+      for (int s = 0; s < NFR; ++s) {
+        const uint4 v = lp[rb[s] + sub * 32 * NCH];
+        a[s] = *reinterpret_cast<const bf16x8*>(&v);
+      }
+    } else if constexpr (SP != 0) {
       const uint4* lp = &lds[0][0] + buf * CHUNKS;
 #pragma unroll
       for (int i = 0; i < NFR; ++i) {
