@@ -1,0 +1,63 @@
+"""CPU: host-side helpers added in round 4 — the MIN-table rehearsal of shard.py and the P3P disagreement classifier."""
+import numpy as np
+import pytest
+import torch
+
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import shard
+
+
+def test_min_table_image_and_merge_equal_an_allreduce_min():
+    """Eight ranks' contributions built by min_table_image and merged by merge_min_tables = the table an
+    all_reduce(MIN) over the int64 images leaves: owned entries pass through bit for bit, unowned stay +inf, a NaN entry
+    (a failed image's pose) cannot win, the merge order does not matter, an empty contribution may sit past the end."""
+    rng = np.random.default_rng(3)
+    n, size = 511, 8
+    full = rng.uniform(0.0, 50.0, n)
+    full[100] = np.nextafter(full[7], 0.0)              # less than one ulp below another rank's value
+    full[400] = np.nan
+    parts = []
+    for r in range(size):
+        lo, hi = shard.owned_pairs(n + 1, r, size)
+        parts.append(shard.min_table_image(torch.from_numpy(full[lo:hi].copy()), lo, n))
+    parts.append(shard.min_table_image(torch.empty(0, dtype=torch.float64), n + 5, n))      # a rank that owns nothing
+    merged = shard.merge_min_tables(parts)
+    back = shard.merge_min_tables(parts[::-1])
+    assert torch.equal(merged.view(torch.int64), back.view(torch.int64))
+    got = merged.numpy()
+    ok = ~np.isnan(full)
+    assert np.array_equal(got[ok].view(np.int64), full[ok].view(np.int64))
+    assert np.isinf(got[400]) or np.isnan(got[400])
+    i, v = shard.first_min(merged)
+    assert i == int(np.nanargmin(full)) and v == np.nanmin(full)
+    with pytest.raises(ValueError):
+        shard.min_table_image(torch.ones(4, dtype=torch.float64), n - 2, n)
+
+
+def _rot(axis, ang):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_rotvec(np.asarray(axis, float) / np.linalg.norm(axis) * ang).as_matrix()
+
+
+def test_p3p_classifier_on_constructed_root_sets():
+    from tests import p3p_classify as pc
+    K = np.array([[100.0, 0, 16], [0, 100.0, 16], [0, 0, 1]])
+    X = np.array([[10.0, 0, 0], [0, 12.0, 0], [-8.0, -5.0, 3.0]])
+    R0, t0 = _rot([1, 2, 3], 0.4), np.array([1.0, -2.0, 300.0])
+    Xc = X @ R0.T + t0
+    uv = (Xc @ K.T)[:, :2] / Xc[:, 2:3]
+    root = (R0, t0)
+    # the same sets: nothing to explain
+    m = pc.measures(X, uv, K, [root], [root])
+    assert pc.explain(m) == "" and m["sliver_img"] > 0.1 and m["sliver_obj"] > 0.1
+    # a twin of the root within DOUBLE radians that one solver lacks: a merging pair (a hand-made twin does not reproject
+    # the points exactly, and the classifier reports that first)
+    twin = (_rot([0, 0, 1], 1e-3) @ R0, t0)
+    m2 = pc.measures(X, uv, K, [root, twin], [root])
+    assert len(m2["unmatched"]) == 1 and m2["unmatched"][0]["twin"] < pc.DOUBLE and pc.explain(m2) in ("double", "invalid")
+    # an extra root that does not reproject its points and has no twin: invalid
+    far = (_rot([1, 0, 0], 1.0) @ R0, t0 + np.array([30.0, 0, 0]))
+    assert pc.explain(pc.measures(X, uv, K, [root, far], [root])) == "invalid"
+    # collinear pixels: whatever the root sets, the problem is a sliver
+    uvc = np.array([[1.0, 1.0], [2.0, 2.0], [3.0, 3.0]])
+    assert pc.explain(pc.measures(X, uvc, K, [root], [])) == "sliver"
+    assert pc.sliverness(uvc) == 0.0 and pc.sliverness(np.array([[0.0, 0], [1, 0], [0, 1]])) == pytest.approx(0.5)
