@@ -330,7 +330,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
           if (!FULL && kb + 32 > k1) mask_tail(acc[w & 1], kb + 4 * h, k1);
           const f32x16& cur = acc[w & 1];
           f32x16& nxt = acc[(w + 1) & 1];
-          const bool reload = qb == 0 && (w != NW - 2 || has_next);
+          // the reads are unconditional in the items that own them: past the range's last stage they fetch stale LDS
+          // into fragments nobody multiplies (a branch here would cut the phase into basic blocks the scheduler cannot
+          // interleave across)
+          const bool reload = qb == 0;                 // folds once the item loop is unrolled
           const int rbuf = (w == NW - 2) ? (buf ^ 1) : buf, rsub = (w == NW - 2) ? 0 : sub + 1;
           auto reads = [&](int pl) {
             if (reload) {
@@ -344,12 +347,12 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
           };
           float l = st[qb].l;
           f32x16 c = splat16(0.f);
-#pragma unroll
-          for (int ph = 0; ph < RF::NPH; ++ph) {
+          auto phase = [&](auto ph_tag) {
+            constexpr int ph = decltype(ph_tag)::value;
 #pragma unroll
             for (int j = 0; j < SP; ++j) c = mfma16<F16>(a[RF::PA[ph] * SP + j], bq[qbn][RF::PB[ph] * SP + j], c);
-            if (RF::RD[ph] >= 0) reads(RF::RD[ph]);
-            if (ph == 0 && TRK) {
+            if constexpr (RF::RD[ph] >= 0) reads(RF::RD[ph]);
+            if constexpr (ph == 0 && TRK) {
               const float t = tile_max(cur);
               st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);   // second largest of {m, m2, t} (m2 <= m)
               st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;                     // strict: the first tile to reach m keeps it
@@ -357,10 +360,28 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
             }
 #pragma unroll
             for (int i = RF::E0[ph]; i < RF::E0[ph + 1]; ++i) l += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
-            if (ph + 1 < RF::NPH) {
+            // issue order inside the phase: each matrix instruction followed by its share of the phase's VALU work (and, in
+            // the items that reload fragments, one of the freed plane's ds_reads)
+            constexpr int nv = ((ph == 0 && TRK) ? 12 : 0) + (NAT ? 3 : 2) * (RF::E0[ph + 1] - RF::E0[ph]);
+            constexpr int gv = (nv + SP - 1) / SP;
+#pragma unroll
+            for (int j = 0; j < SP; ++j) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (reload && RF::RD[ph] >= 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if constexpr (gv > 0) __builtin_amdgcn_sched_group_barrier(0x002, gv, 0);
+            }
+            if constexpr (ph + 1 < RF::NPH) {
               asm volatile("" : "+v"(c), "+v"(l), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
               __builtin_amdgcn_sched_barrier(0);
             }
+          };
+          phase(std::integral_constant<int, 0>{});
+          phase(std::integral_constant<int, 1>{});
+          phase(std::integral_constant<int, 2>{});
+          if constexpr (RF::NPH == 6) {
+            phase(std::integral_constant<int, 3>{});
+            phase(std::integral_constant<int, 4>{});
+            phase(std::integral_constant<int, 5>{});
           }
           st[qb].l = l;
           nxt = c;
