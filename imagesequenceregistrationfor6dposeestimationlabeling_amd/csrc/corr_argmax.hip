@@ -1195,8 +1195,11 @@ extern "C" int isr_corr_argmax_recheck_count_f32(const void* ws_, size_t ws_byte
   if (route.kind == 1) carve_split(w, P, N, &q2, &k2, &ws);
   else carve_planes(w, P, N, route.sp, route.kind == 3, &q2, &k2, &gate, &ws, nullptr);
   hipStream_t stream = isr::as_stream(stream_);
+  int32_t gated = 0;
+  if (route.kind == 3) ISR_CHECK_HIP(hipMemcpyAsync(&gated, gate, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.rcount, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
   ISR_CHECK_HIP(hipStreamSynchronize(stream));
+  if (gated) *count_host = -1;           // the call fell through to the f32-MFMA chain kernels (a descriptor beyond f16's range)
   return ISR_OK;
 }
 
