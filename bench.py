@@ -393,6 +393,13 @@ def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower,
     o = cbind.corr_argmax_bf16(bits(q), bits(keys), logit_scale=float(np.log(2.0)) if model.log2_queries else 1.0)
     out["k1_rows_checked"] = int(rows)
     out["k1_idx_equal_rows"] = int((idx_dev.cpu().numpy() == o["idx"]).sum())
+    if last.get("_k1_first") is not None:
+        # what the LAST TIMED STEP's K1 launch (32 images per launch, beside the chains and the verification) left for this
+        # rank's first image, against the same rows through a launch of their own with the GPU idle: a result is a function
+        # of (query, keys) only, so both must be the same bits
+        idx_step, logp_step = last["_k1_first"]
+        idx_alone, logp_alone = ops.corr_argmax(Q_rows, keys, log2_prescaled=model.log2_queries)
+        out["k1_in_step_equals_alone"] = bool(torch.equal(idx_step, idx_alone) and torch.equal(logp_step, logp_alone))
     poses = np.asarray(last["poses_all"], np.float64).reshape(-1, 3, 4)
     n = poses.shape[0]
     pc = pts.cpu().numpy().astype(np.float64)
@@ -550,7 +557,7 @@ def main():
             n_eval = torch.cat([r.n_eval for r in res])
             ev = torch.cuda.Event()
             ev.record(reg_streams[s & 1])
-        return poses, status, n_eval, ev
+        return poses, status, n_eval, ev, (res[0].idx, res[0].logp)
 
     reg_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     tail_stream = torch.cuda.Stream(device=dev, priority=-1)
@@ -558,7 +565,7 @@ def main():
     def owner_of(image: int) -> int:
         return next(r for r in range(world) if shard.block_range(n_total, r, world)[0] <= image < shard.block_range(n_total, r, world)[1])
 
-    def verify(poses, status, n_eval, ev):
+    def verify(poses, status, n_eval, ev, k1_first):
         """Every rank: pose all-gather + its share of the verification — `--verify pick`: the consecutive pairs it
         owns, then ONE all-reduce(MIN) over the f64 table (verfication.py:61-108); `--verify vote`: its rows of the
         n x n ADD-S vote, then the row-sum all-gather (choosePose.py:121-151 -> icp.py:37-39).  The rank that OWNS the
@@ -568,7 +575,7 @@ def main():
         torch.cuda.set_device(dev)
         if args.ablate == "noverify":
             ev.synchronize()
-            return {"ablate": "noverify", "registered_this_rank": int(status.sum().item())}
+            return {"ablate": "noverify", "registered_this_rank": int(status.sum().item()), "_k1_first": k1_first}
         with torch.cuda.stream(tail_stream):
             tail_stream.wait_event(ev)
             poses_all = shard.allgather_rows(poses, n_total)
@@ -581,7 +588,7 @@ def main():
                 best, ch, table = sequence.pick_by_chamfer_table(pts, poses_all, R_gt, t_gt, n_total)
                 out.update(picked_pair=best, picked_image=best, pair_chamfer=ch, chamfer_table=table)
             st = status.cpu()
-            out.update(_poses_local=poses, _status_local=status)
+            out.update(_poses_local=poses, _status_local=status, _k1_first=k1_first)
             out.update(registered_this_rank=int(st.sum().item()), images_this_rank=int(st.numel()),
                        hypotheses_scored_mean=float(n_eval.float().mean().item()), icp_rank=owner_of(best),
                        poses_all=poses_all.cpu().numpy())
