@@ -319,6 +319,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       // DMA: every wave is past the barrier above, so nobody reads this stage's buffer any more: the stage after the next
       // goes into it now, a whole stage ahead of the barrier that publishes it (the compiler drains the DMA counter in front
       // of the next ds_read, an item away)
+      // (the pieces of a stage issued in two halves an item apart: 3 % slower at D = 64 with f16 planes, profiles/README.md)
       if constexpr (DMA) { if (w == NW - 1 && stage + 2 < nstage) gload(stage + 2); }
       const int kb = k0 + stage * TKS + sub * 32;
       if constexpr (SP != 0) {
