@@ -224,7 +224,7 @@ constexpr int split_deff(int SP) { return (103 * (96 * SP + 2) + 51 * (16 * SP +
 // D_eff + 2 >= 1.002 (48 SP + 2) + 0.501 (13 + 16 SP).  And absolutely, for subnormal x1s elements, 2^-25 (|k|_1 + |q|_1)
 // <= split_eabs(SP) (|k| + |q|) with split_eabs = 1.01 x 2^-25 sqrt(16 SP).
 constexpr int split_deff_f16(int SP) { return (1002 * (48 * SP + 2) + 501 * (13 + 16 * SP)) / 1000 + 1; }
-constexpr float split_eabs(int SP) { return (SP == 1 ? 4.04f : SP == 2 ? 5.72f : 8.08f) * 2.98023223876953125e-08f; }
+constexpr float split_eabs(int SP) { return (SP == 1 ? 4.04f : SP == 2 ? 5.72f : SP == 4 ? 8.08f : 11.43f) * 2.98023223876953125e-08f; }
 
 // ------------------------------------------------------------------------- key staging (LDS)
 // Key stages through a swizzled LDS image: coalesced 16-byte global loads, conflict-free ds_read_b128 in MFMA
@@ -1037,13 +1037,14 @@ int slots_for(int dtype, int D) {
 }
 
 int slots_planes(int sp, bool f16) {
-  static int cache[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+  static int cache[2][9] = {{0, 0, 0, 0, 0, 0, 0, 0, 0}, {0, 0, 0, 0, 0, 0, 0, 0, 0}};
   int& c = cache[f16 ? 1 : 0][sp];
   if (c == 0) {
     if (f16)
       c = sp == 1 ? resident_slots(corr_bf16_direct_kernel<3, kQB, false, 3, 1, true>)
         : sp == 2 ? resident_slots(corr_bf16_direct_kernel<6, kQB, false, 6, 2, true>)
-                  : resident_slots(corr_bf16_direct_kernel<12, kQB, false, 12, 4, true>);
+        : sp == 4 ? resident_slots(corr_bf16_direct_kernel<12, kQB, false, 12, 4, true>)
+                  : 256;      // SP = 8: one workgroup per CU (96 KB of LDS, 512 registers per wave)
     else
       c = sp == 1 ? resident_slots(corr_bf16_direct_kernel<3, kQB, false, 3, 1>)
         : sp == 2 ? resident_slots(corr_bf16_direct_kernel<6, kQB, false, 6, 2>)
@@ -1088,7 +1089,8 @@ size_t carve_split(isr::Workspace& w, int P, int N, uint16_t** q2, uint16_t** k2
 }
 
 constexpr int kSplitMaxD = 16;    // round-3 form of the split route (96-wide rows on the generic direct kernel)
-constexpr int kSplit3MaxD = 64;   // plane forms: SP = 1, 2, 4 blocks per plane
+constexpr int kSplit3MaxD = 64;   // plane forms with two waves per SIMD: SP = 1, 2, 4 blocks per plane
+constexpr int kSplitF16MaxD = 128;  // f16 planes also at SP = 8 (one wave per SIMD, dynamic LDS)
 
 // How an f32 call runs.  kind: 0 the f32-MFMA chain kernel; 1 round 3's 96-wide split (D <= 16); 2 three bf16 planes;
 // 3 f16 planes (gated: falls through to the chain kernel when a descriptor does not fit f16).  ISR_TUNE_K1_F32_CHAIN:
@@ -1097,10 +1099,10 @@ constexpr int kSplit3MaxD = 64;   // plane forms: SP = 1, 2, 4 blocks per plane
 struct F32Route { int kind, sp; };
 F32Route f32_route(int D) {
   const int t = isr::tuning(ISR_TUNE_K1_F32_CHAIN);
-  if (t == 1 || D > kSplit3MaxD) return {0, 0};
-  const int sp = D <= 16 ? 1 : D <= 32 ? 2 : 4;
+  if (t == 1 || D > kSplitF16MaxD) return {0, 0};
+  const int sp = D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : 8;
   if (t == 4 && D <= kSplitMaxD) return {1, 0};
-  if (t == 2 || t == 4) return {2, sp};
+  if (t == 2 || t == 4) return D <= kSplit3MaxD ? F32Route{2, sp} : F32Route{0, 0};      // bf16 planes stop at D = 64
   return {3, sp};
 }
 
@@ -1132,11 +1134,11 @@ extern "C" size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype
     const size_t split = carve_split(w2, P, N, &q2, &k2, &o) + 256;
     if (split > bytes) bytes = split;
   }
-  if (dtype == ISR_DTYPE_F32 && D <= kSplit3MaxD) {                // the plane routes (any knob setting: the size is a function of the shape)
+  if (dtype == ISR_DTYPE_F32 && D <= kSplitF16MaxD) {              // the plane routes (any knob setting: the size is a function of the shape)
     isr::Workspace w3(nullptr, 0);
     uint16_t *q3, *k3;
     int32_t* gate;
-    const size_t split = carve_planes(w3, P, N, D <= 0 ? 4 : D <= 16 ? 1 : D <= 32 ? 2 : 4, true, &q3, &k3, &gate, &o, nullptr) + 256;
+    const size_t split = carve_planes(w3, P, N, D <= 0 ? 8 : D <= 16 ? 1 : D <= 32 ? 2 : D <= 64 ? 4 : 8, true, &q3, &k3, &gate, &o, nullptr) + 256;
     if (split > bytes) bytes = split;
   }
   return bytes;
@@ -1273,7 +1275,22 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
       case 4: ISR_LAUNCH_PLANES(2, false); break;
       case 5: ISR_LAUNCH_PLANES(2, true); break;
       case 8: ISR_LAUNCH_PLANES(4, false); break;
-      default: ISR_LAUNCH_PLANES(4, true); break;
+      case 9: ISR_LAUNCH_PLANES(4, true); break;
+      default: {     // SP = 8, f16 planes: two 48 KB stage buffers as dynamic LDS
+        constexpr int kDynLds = 2 * 64 * 48 * 16;
+        static bool attr_set = false;
+        if (!attr_set) {
+          ISR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&corr_bf16_direct_kernel<24, kQB, false, 24, 8, true, false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, kDynLds));
+          attr_set = true;
+        }
+        corr_bf16_direct_kernel<24, kQB, false, 24, 8, true, false><<<grid, kThreads, kDynLds, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks,
+                                                                                                       ws, idx, logp, lse);
+        corr_bf16_kernel<24, true, 8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
+        corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
+        if (!lse_only) corr_recheck_kernel<24, 8, true><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
+        break;
+      }
     }
   } else
 #undef ISR_LAUNCH_PLANES
@@ -1358,7 +1375,11 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     switch (sp) {
       case 1: ISR_SPLIT_PLANES(1); break;
       case 2: ISR_SPLIT_PLANES(2); break;
-      default: ISR_SPLIT_PLANES(4); break;
+      case 4: ISR_SPLIT_PLANES(4); break;
+      default:      // SP = 8 exists with f16 planes only (f32_route)
+        corr_split2h_f32_kernel<8><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3, gate);
+        corr_split2h_f32_kernel<8><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3, gate);
+        break;
     }
 #undef ISR_SPLIT_PLANES
     if (f16) ws.skip = gate;

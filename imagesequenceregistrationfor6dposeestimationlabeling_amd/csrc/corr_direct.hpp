@@ -58,8 +58,11 @@ __device__ __forceinline__ float tile_max(const f32x16& acc) {
 // Cauchy-Schwarz bound instead: |s'| <= |q||k|_max < kLseBound puts every term inside [2^-99, 2^99] and the maximum above kLow;
 // a query that fails the bound goes to the fallback as a bad one does.  The sums, and with them lse, are the full kernel's bits.
 constexpr float kLseBound2 = 99.f * 99.f;
+// SP = 8 (f16 planes of 128-wide rows): 24 + 24 + 24 fragments of a wave's two query blocks and of a key sub-tile need more
+// than 256 registers — one wave per SIMD with the whole 512-register file, and two 48 KB stage buffers as dynamic LDS.
+extern __shared__ uint4 corr_direct_dyn_lds[];
 template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0, bool F16 = false, bool LSE = false>
-__global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_kernel(
+__global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
     float* __restrict__ lse_out) {
@@ -83,8 +86,11 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   constexpr int NLD = CHUNKS / kThreads;
   static_assert(CHUNKS % kThreads == 0, "every thread stages the same number of chunks");
   static_assert(SP != 0 || POW2 || NCH == 12, "LDS chunk placement is written for a power of two or 12 chunks per row");
-  static_assert(NCH <= 24, "wider rows need a shorter stage");
-  __shared__ uint4 lds[2][CHUNKS];
+  static_assert(NCH <= 48, "wider rows need a shorter stage");
+  // two stage buffers: static up to 64 KB, dynamic beyond (the launch passes 2 * CHUNKS * 16 bytes)
+  constexpr bool DYN = 2 * CHUNKS * sizeof(uint4) > 64 * 1024;
+  __shared__ uint4 lds_static[DYN ? 1 : 2 * CHUNKS];
+  uint4* const lds = DYN ? corr_direct_dyn_lds : lds_static;
   // where chunk c of key row `row` lives inside the row's NCH slots: an XOR swizzle for power-of-two rows; for 12-chunk rows a
   // rotation by (row / 4) % 4 — a row starts 12 row (mod 16) sixteen-byte banks in, which only depends on row % 4, and the
   // rotation separates the four rows of every such class: the 16 lanes of a ds_read_b128 phase hit 16 distinct banks.
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass of this template rejects the LDS address-space cast (and then drops the kernel's stub)
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)&lds[stage & 1][i * kThreads + wave * 64],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)&lds[(stage & 1) * CHUNKS + i * kThreads + wave * 64],
                                                  16, koff[i] + so, 0, 0, 0);
 #endif
     } else {
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       for (int i = 0; i < NLD; ++i) {
         const int ci = tid + i * kThreads;
         const int row = ci / NCH, c = ci % NCH;
-        lds[buf][row * NCH + slot(row, c)] = stg[i];
+        lds[buf * CHUNKS + row * NCH + slot(row, c)] = stg[i];
       }
     }
   };
@@ -254,14 +260,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
   }
   auto load_a = [&](int buf, int sub) {
     if constexpr (SP == 0 && RB) {
-      const uint4* lp = &lds[0][0] + buf * CHUNKS;
+      const uint4* lp = lds + buf * CHUNKS;
 #pragma unroll
       for (int s = 0; s < NFR; ++s) {
         const uint4 v = lp[rb[s] + sub * 32 * NCH];
         a[s] = *reinterpret_cast<const bf16x8*>(&v);
       }
     } else if constexpr (SP != 0) {
-      const uint4* lp = &lds[0][0] + buf * CHUNKS;
+      const uint4* lp = lds + buf * CHUNKS;
 #pragma unroll
       for (int i = 0; i < NFR; ++i) {
         const int pl = 2 - i / SP, j = i % SP;        // in the order tile_chain lets go of the planes: k3, then k2, then k1
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
       const int row = sub * 32 + r;
 #pragma unroll
       for (int s = 0; s < NFR; ++s) {
-        const uint4 v = lds[buf][row * NCH + slot(row, 2 * s + h)];
+        const uint4 v = lds[buf * CHUNKS + row * NCH + slot(row, 2 * s + h)];
         a[s] = *reinterpret_cast<const bf16x8*>(&v);
       }
     }
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : 2) void corr_bf16_direct_ke
           const int rbuf = (w == NW - 2) ? (buf ^ 1) : buf, rsub = (w == NW - 2) ? 0 : sub + 1;
           auto reads = [&](int pl) {
             if (reload) {
-              const uint4* lp = &lds[0][0] + rbuf * CHUNKS;
+              const uint4* lp = lds + rbuf * CHUNKS;
 #pragma unroll
               for (int j = 0; j < SP; ++j) {
                 const uint4 v = lp[rb[j] + rsub * 32 * NCH + pl * 2 * SP];

@@ -65,7 +65,7 @@ int isr_device_count(void);
 #define ISR_TUNE_NN_TILE_SQ 6    /* 0 default | query cell scale x 1000 */
 #define ISR_TUNE_NN_TILE_TB 7    /* 0 default | 64 | 128 | 256 threads per workgroup */
 #define ISR_TUNE_EP_WSUM_VALU 8  /* 0 (default) the sampler's chunk sums form their logits on the f32 MFMA | 1 on VALU fma chains (same bits) */
-#define ISR_TUNE_K1_F32_CHAIN 9  /* f32 queries, D <= 64: 0 / 3 (default) f16 planes on the matrix cores, exact f32-chain recheck, falls through to the chain kernel when a descriptor does not fit f16 | 1 the f32-MFMA chain kernel | 2 three bf16 planes | 4 round 3 96-wide rows (D <= 16) */
+#define ISR_TUNE_K1_F32_CHAIN 9  /* f32 queries: 0 / 3 (default) f16 planes on the matrix cores, exact f32-chain recheck, falls through to the chain kernel when a descriptor does not fit f16 | 1 the f32-MFMA chain kernel | 2 three bf16 planes (D <= 64; chain kernel above) | 4 round 3 96-wide rows (D <= 16) */
 #define ISR_TUNE_K1_SPLIT 10     /* 0 (default) K1 picks its number of key ranges | n > 0 forced (capped); results do not depend on it */
 #define ISR_TUNE_COUNT 11
 int isr_tuning_set(int knob, int value);
@@ -87,7 +87,7 @@ int isr_tuning_get(int knob);
  *   lse[p]  = logsumexp_n logit      (nullable)
  * idx = logp = NULL with lse given: an lse-only call (pose_refine.py:56, poseEstSurf.py:68-71) — no maxima tracked, no index
  * certified; lse carries the bits of a full call's.
- * f32, D <= 64 (round 4): the rows run on the 16-bit matrix cores as f16 planes (x1 | x2s | x1s, three plane pairs per
+ * f32 (round 4): the rows run on the 16-bit matrix cores as f16 planes (x1 | x2s | x1s, three plane pairs per
  * 16-wide block) with a margin test and a recheck by the k-ordered f32 fmaf chain of the ORIGINAL rows — idx is the chain's
  * arg-max bit for bit, logp / lse are accurate to f32 (2^-21 |q||k|); descriptors must be finite, and a call holding an
  * |element| >= 65 000 runs the f32-MFMA chain kernels instead (decided on the device).  ISR_TUNE_K1_F32_CHAIN selects the others.

@@ -458,10 +458,12 @@ def test_corr_f32_split_route_equals_chain_route(cuda0, oracle_lib, P, N, D):
                                          (513, 4096, 40, 0), (6000, 33000, 64, 0), (2000, 9000, 32, 0), (64, 128, 48, 0),
                                          (1000, 4097, 12, 0), (5000, 20000, 16, 0), (777, 12289, 5, 0),
                                          (1000, 4097, 24, 2), (5000, 20000, 64, 2), (777, 12289, 33, 2), (2000, 9000, 32, 2),
-                                         (1000, 4097, 12, 2), (5000, 20000, 16, 2), (777, 12289, 5, 4)])
+                                         (1000, 4097, 12, 2), (5000, 20000, 16, 2), (777, 12289, 5, 4),
+                                         (1000, 4097, 65, 0), (5000, 20000, 128, 0), (777, 12289, 100, 0), (300, 31, 96, 0)])
 def test_corr_f32_three_plane_route_equals_chain_route(cuda0, oracle_lib, P, N, D, chain):
-    """f32 descriptors with D <= 64 on the 16-bit matrix cores (round 4), both plane forms (RowFrags in corr_argmax.hip):
-    chain = 0, the default — f16 planes x1 | x2s | x1s, three plane pairs per 16-wide block; chain = 2 — bf16 planes
+    """f32 descriptors on the 16-bit matrix cores (round 4), both plane forms (RowFrags in corr_argmax.hip):
+    chain = 0, the default — f16 planes x1 | x2s | x1s, three plane pairs per 16-wide block, D <= 128 (above 64: one wave per
+    SIMD with the whole register file, dynamic LDS); chain = 2 — bf16 planes (D <= 64)
     x1 | x2 | x3, six plane pairs; chain = 4 — round 3's 96-wide rows (D <= 16).  Each with its margin test and the recheck
     by the f32 fmaf chain of the original rows.  Indices = the f32-MFMA chain kernel's (ISR_TUNE_K1_F32_CHAIN = 1) = the
     oracle's, with duplicate keys (one pair across a canonical chunk boundary), an exact tie, zero rows (a whole workgroup
@@ -542,7 +544,7 @@ def test_corr_f32_chain_kernel_all_zero_workgroups(cuda0, oracle_lib, D):
     assert np.array_equal(idx[rows].cpu().numpy(), o["idx"])
 
 
-@pytest.mark.parametrize("D,chain", [(64, 0), (64, 2), (32, 0), (12, 0), (12, 2)])
+@pytest.mark.parametrize("D,chain", [(64, 0), (64, 2), (32, 0), (12, 0), (12, 2), (128, 0)])
 def test_corr_f32_plane_routes_repeat_bit_for_bit(cuda0, D, chain):
     """Six calls on a chip-filling shape (the keys reach the LDS by buffer_load ... lds, stage s + 2 in flight under stage
     s + 1: a missing wait between a DMA piece landing and the barrier that publishes it shows as outputs that change from
