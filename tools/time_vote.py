@@ -1,0 +1,29 @@
+"""The n x n ADD-S vote (choosePose.py:121-151) alone: python tools/time_vote.py [n] [V] [N]
+Items = n^2 searches of V CAD vertices against N surface points; predictions a few degrees / millimetres off the truth (what a
+working registration leaves) and, for contrast, unrelated predictions (every item's clouds far apart)."""
+import sys, time
+from pathlib import Path
+import numpy as np, torch
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops, sequence, synth
+n, V, N = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (256, 5000, 20000)
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(1)
+S = synth.tless_like(rng, N); Vv = synth.tless_like(rng, V); diam = synth.diameter(S)
+Rg, tg = synth.random_poses(rng, n)
+for label, deg, tr in (("registered (0.2-3 deg, 0.5-3 mm off)", (0.2, 3.0), (0.5, 3.0)), ("half of them failed (random poses)", None, None)):
+    if deg is not None:
+        P = [synth.perturb_pose(rng, Rg[i], tg[i], rng.uniform(*deg), rng.uniform(*tr)) for i in range(n)]
+    else:
+        P = [synth.perturb_pose(rng, Rg[i], tg[i], 1.0, 1.0) if i % 2 else (synth.random_poses(rng, 1)[0][0], tg[i]) for i in range(n)]
+    Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
+    for path in (-1, 0):
+        with ops.tuning(nn_path=path):
+            sequence.vote_rows(Vv, S, Rg[:8], tg[:8], Rp[:8], tp[:8], diam, 0, 8)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            e_d, sums = sequence.vote_rows(Vv, S, Rg, tg, Rp, tp, diam, 0, n)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            err, img = e_d.float().cpu().numpy(), int(sums[:, 0].argmax())
+        print(f"{label}: nn_path={path:2d}  n={n} ({n * n} items of {V} x {N}): {dt * 1e3:8.1f} ms = {dt / (n * n) * 1e6:6.2f} us per item, "
+              f"{n * n * V * N / dt * 1e-12:6.1f} T brute-force-equivalent pairs/s; accepted {err.mean():.3f}, chosen {img}", flush=True)
