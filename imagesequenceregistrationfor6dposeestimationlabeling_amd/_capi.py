@@ -18,7 +18,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ISR_HIP_LIB"]) if os.environ.get("ISR_HIP_LIB") else _PKG / "libisr_hip.so"
 
 ISR_OK = 0
-ABI_VERSION = 3
+ABI_VERSION = 4
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
 DTYPE_BF16_LOG2 = 2

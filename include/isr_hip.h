@@ -27,7 +27,9 @@
 extern "C" {
 #endif
 
-#define ISR_ABI_VERSION 3
+/* v4 (round 4): isr_corr_argmax accepts idx = logp = NULL (lse-only call), f32 rows run as f16 planes by default
+ * (ISR_TUNE_K1_F32_CHAIN values 0-4), new isr_corr_topk / isr_corr_topk_workspace_bytes. */
+#define ISR_ABI_VERSION 4
 
 #define ISR_OK 0
 #define ISR_ERR_ARG (-1)         /* bad shape / null pointer / unsupported value */
