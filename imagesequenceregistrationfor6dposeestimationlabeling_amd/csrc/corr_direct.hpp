@@ -100,7 +100,8 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
     else return POW2 ? (c ^ ((row / RPB) & (NCH - 1))) : (c + ((row >> 2) & 3)) % NCH;
   };
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // the wave index as a scalar: the LDS-DMA destination of a wave (M0) is then formed without vector instructions
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int r = lane & 31, h = lane >> 5;
   const int split = blockIdx.y;
   const int q0 = (blockIdx.x * kWaves + wave) * (QB * 32);
@@ -218,13 +219,14 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
     koff[i] = DMA ? ((ci / NCH) * ldk + 8 * slot(ci / NCH, ci % NCH)) * 2 : ((ci / NCH) * ldk + 8 * (ci % NCH)) * 2;
   }
   uint4 stg[DMA ? 1 : NLD];
-  auto gload = [&](int stage) {
+  auto gload = [&](int stage, int dbuf = -1) {       // dbuf: the destination buffer when the caller knows it at compile time
     const int so = stage * TKS * ldk * 2;
+    if (dbuf < 0) dbuf = stage & 1;
     if constexpr (DMA) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass of this template rejects the LDS address-space cast (and then drops the kernel's stub)
 #pragma unroll
       for (int i = 0; i < NLD; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)&lds[(stage & 1) * CHUNKS + i * kThreads + wave * 64],
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)&lds[dbuf * CHUNKS + i * kThreads + wave * 64],
                                                  16, koff[i] + so, 0, 0, 0);
 #endif
     } else {
@@ -302,10 +304,13 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
 
   // TRK: track the maxima.  Always, except in an LSE kernel whose wave holds only queries the Cauchy-Schwarz bound keeps
   // inside the direct sum's range (the loop exists twice there; which copy runs is wave-uniform).
-  auto stage_body = [&](int stage, auto full_tag, auto trk_tag) {
+  // buf_tag: the stage's LDS buffer (stage & 1) as a compile-time constant — full stages run in even / odd pairs — so that
+  // every LDS address of the loop is a lane register plus an immediate; -1: taken from the stage index at run time.
+  auto stage_body = [&](int stage, auto full_tag, auto trk_tag, auto buf_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     constexpr bool TRK = !LSE || decltype(trk_tag)::value;
-    const int buf = stage & 1;
+    constexpr int BUF = decltype(buf_tag)::value;
+    const int buf = BUF >= 0 ? BUF : (stage & 1);
     const bool has_next = stage + 1 < nstage;
     if constexpr (!DMA) { if (has_next) gload(stage + 1); }
 #pragma unroll
@@ -326,7 +331,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
       // goes into it now, a whole stage ahead of the barrier that publishes it (the compiler drains the DMA counter in front
       // of the next ds_read, an item away)
       // (the pieces of a stage issued in two halves an item apart: 3 % slower at D = 64 with f16 planes, profiles/README.md)
-      if constexpr (DMA) { if (w == NW - 1 && stage + 2 < nstage) gload(stage + 2); }
+      if constexpr (DMA) { if (w == NW - 1 && stage + 2 < nstage) gload(stage + 2, buf); }
       const int kb = k0 + stage * TKS + sub * 32;
       if constexpr (SP != 0) {
         // Split rows: an item is its plane pairs as phases (RowFrags: six with bf16 planes, three with f16 planes), SP matrix
@@ -453,8 +458,13 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
     for (int c = c0; stage < nstage; ++c) {
       const int send = min(nstage, stage + CSTAGES);
       const int sfull = min(nfull, send);
-      for (; stage < sfull; ++stage) stage_body(stage, std::true_type{}, trk_tag);
-      if (stage < send) { stage_body(stage, std::false_type{}, trk_tag); ++stage; }   // only a range's last stage is partial
+      // a chunk starts at an even stage (kChunk / TKS stages per chunk, ranges of whole chunks)
+      for (; stage + 1 < sfull; stage += 2) {
+        stage_body(stage, std::true_type{}, trk_tag, std::integral_constant<int, 0>{});
+        stage_body(stage + 1, std::true_type{}, trk_tag, std::integral_constant<int, 1>{});
+      }
+      for (; stage < sfull; ++stage) stage_body(stage, std::true_type{}, trk_tag, std::integral_constant<int, -1>{});
+      if (stage < send) { stage_body(stage, std::false_type{}, trk_tag, std::integral_constant<int, -1>{}); ++stage; }   // only a range's last stage is partial
 #pragma unroll
       for (int qb = 0; qb < QB; ++qb) {
         const float lc = st[qb].l + __shfl_xor(st[qb].l, 32, 64);
