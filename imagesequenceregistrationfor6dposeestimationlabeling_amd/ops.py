@@ -4,6 +4,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import numpy as np
+
 import torch
 
 from . import _capi
@@ -164,6 +166,61 @@ def nn_batched(qry: torch.Tensor, tgt: torch.Tensor, Tq: torch.Tensor | None = N
                               ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_nn_batched")
     return NNResult(sum_d, sum_d2, n_in, nn_idx, nn_d, cov)
+
+
+@dataclass
+class DistField:
+    """Distances from the cell centres of a uniform grid to a (static) cloud: what isr_adds_bounds reads."""
+    field: torch.Tensor       # (nz, ny, nx) f32 device
+    grid_min: np.ndarray      # (3,) f64 host: the corner of cell (0, 0, 0)
+    h: float                  # cell edge
+    dims: tuple               # (nx, ny, nz)
+    bbox: np.ndarray          # (6,) f32 host: the cloud's bounding box, lo xyz then hi xyz
+    n_points: int
+
+
+def dist_field(cloud: torch.Tensor, cells: int = 128, margin: float | None = None) -> DistField:
+    """Exact distances from the centres of a cells^3-ish grid around `cloud` (N,3) to the cloud, through isr_nn_batched.
+    margin: how far beyond the cloud's bounding box the grid reaches (default: a quarter of its longest extent)."""
+    dev = require_cuda(cloud)
+    c = _f32c(cloud)
+    lo, hi = c.min(dim=0).values.double().cpu().numpy(), c.max(dim=0).values.double().cpu().numpy()
+    ext = hi - lo
+    m = float(0.25 * ext.max()) if margin is None else float(margin)
+    h = float((ext.max() + 2.0 * m) / cells)
+    gmin = lo - m
+    dims = tuple(int(np.ceil((ext[a] + 2.0 * m) / h)) for a in range(3))
+    ax = [gmin[a] + h * (torch.arange(dims[a], device=dev, dtype=torch.float64) + 0.5) for a in range(3)]
+    zz, yy, xx = torch.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+    centres = torch.stack([xx, yy, zz], dim=-1).reshape(-1, 3).to(torch.float32).contiguous()
+    # the centres as f32 are what the field is exact for: their rounding (<= 4e-6 mm at object scale) sits inside the slack
+    # every user of the bounds keeps around the threshold
+    parts = [nn_batched(centres[s0:s0 + (1 << 20)], c, want_dist=True).nn_d[0] for s0 in range(0, centres.shape[0], 1 << 20)]
+    field = torch.cat(parts).to(torch.float32).reshape(dims[2], dims[1], dims[0]).contiguous()
+    return DistField(field, np.asarray(gmin, np.float64), h, dims, np.concatenate([lo, hi]).astype(np.float32), int(c.shape[0]))
+
+
+def adds_bounds(verts: torch.Tensor, Tq: torch.Tensor, Tt: torch.Tensor | None, fld: DistField):
+    """isr_adds_bounds: per batch item b bounds of sum_v dist(Tt[b]^-1 Tq[b] v, cloud) — isr_nn_batched's sum_d for queries
+    `verts` against the field's cloud — as (lb_sum, ub_sum) f64 device tensors (wider, still finite, for vertices off the grid)."""
+    import ctypes
+    dev = require_cuda(verts, Tq, Tt, fld.field)
+    v, Tq, Tt = _f32c(verts), _f64c(Tq), _f64c(Tt)
+    if v.ndim != 2 or v.shape[1] != 3 or Tq.numel() % 12 or (Tt is not None and Tt.numel() != Tq.numel()):
+        raise ValueError(f"adds_bounds: verts {tuple(v.shape)}, Tq {tuple(Tq.shape)}, Tt {None if Tt is None else tuple(Tt.shape)}")
+    B = Tq.numel() // 12
+    lb = torch.empty(B, dtype=torch.float64, device=dev)
+    ub = torch.empty(B, dtype=torch.float64, device=dev)
+    if B == 0:
+        return lb, ub
+    gmin = (ctypes.c_double * 3)(*[float(x) for x in fld.grid_min])
+    bbox = (ctypes.c_float * 6)(*[float(x) for x in fld.bbox])
+    with torch.cuda.device(dev), _timed("adds_bounds", float(B) * v.shape[0]):
+        rc = lib().isr_adds_bounds(ptr(v), v.shape[0], ptr(Tq), ptr(Tt), B, ptr(fld.field), ctypes.cast(gmin, ctypes.c_void_p),
+                                   float(fld.h), fld.dims[0], fld.dims[1], fld.dims[2], ctypes.cast(bbox, ctypes.c_void_p),
+                                   ptr(lb), ptr(ub), current_stream(dev))
+    check(rc, "isr_adds_bounds")
+    return lb, ub
 
 
 def rel_pose_table(R: torch.Tensor, t: torch.Tensor, mode: int, i0: int = 0,

@@ -401,10 +401,35 @@ def pick_by_chamfer_table(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: 
     return idx, val, table
 
 
-def vote_rows(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, lo: int, hi: int, chunk: int = 4096):
+_field_cache: dict = {}
+
+
+def surface_field(surface_pts: torch.Tensor, cells: int = 128) -> "ops.DistField":
+    """The distance field of a surface cloud for vote_rows' bounds, built once per cloud."""
+    # keyed by CONTENT (two checksums, one small read-back): an address can be handed to another cloud of the same shape
+    w = torch.arange(1, surface_pts.shape[0] + 1, device=surface_pts.device, dtype=torch.float64)
+    sums = torch.stack([surface_pts.double().sum(), (surface_pts.double() * w[:, None]).sum()]).cpu().numpy()
+    key = (float(sums[0]), float(sums[1]), tuple(surface_pts.shape), surface_pts.device.index, cells)
+    fld = _field_cache.get(key)
+    if fld is None:
+        if len(_field_cache) > 4:
+            _field_cache.clear()
+        fld = _field_cache[key] = ops.dist_field(surface_pts, cells=cells)
+    return fld
+
+
+VOTE_SLACK_MM = 1e-3      # an item within this of the threshold is always evaluated exactly (f32 coordinates, field rounding)
+
+
+def vote_rows(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, lo: int, hi: int, chunk: int = 4096,
+              bounds: bool | None = None, stats: dict | None = None):
     """The device part of the row-sharded vote (choosePose.py:98-107, 121-138): rows [lo, hi) of
         error[i][j] = ADDS(modelVerts, gt_rel[i][j], pred_rel[i][j]) < 0.1 * diameter
-    Returns (error rows (hi - lo, n) bool device tensor, their int32 row sums (hi - lo, 1))."""
+    Returns (error rows (hi - lo, n) bool device tensor, their int32 row sums (hi - lo, 1)).
+    The vote needs the DECISION, not the ADD-S value.  bounds (default: on from 1 024 items): every item first gets a
+    rigorous lower and upper bound of its ADD-S from a distance field of the surface cloud (ops.adds_bounds: one gather per
+    vertex); only items whose bounds straddle 0.1 * diameter (+- VOTE_SLACK_MM) go through the nearest-neighbour search —
+    the booleans are those of evaluating every item (tested).  stats (optional dict) receives the counts."""
     n = len(R_gt)
     v = registration._dev(model_verts, torch.float32)
     sp = registration._dev(surface_pts, torch.float32)
@@ -412,10 +437,32 @@ def vote_rows(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, lo
     Rp, tp = registration._dev(R_pred, torch.float64), registration._dev(t_pred, torch.float64)
     gt_rel = ops.rel_pose_table(Rg, tg, 0, lo, hi).reshape(-1, 12)        # (rows * n, 12) f64, [R_i^T R_j | t_j - t_i]
     pr_rel = ops.rel_pose_table(Rp, tp, 0, lo, hi).reshape(-1, 12)
-    parts = [ops.nn_batched(v, sp, gt_rel[s0:s0 + chunk], pr_rel[s0:s0 + chunk]).sum_d
-             for s0 in range(0, (hi - lo) * n, chunk)]
-    adds = torch.cat(parts).reshape(hi - lo, n) / v.shape[0]
-    err_d = adds < 0.1 * float(diameter)
+    items = (hi - lo) * n
+    thr = 0.1 * float(diameter)
+    V = v.shape[0]
+
+    def exact(sel_g, sel_p):
+        parts = [ops.nn_batched(v, sp, sel_g[s0:s0 + chunk], sel_p[s0:s0 + chunk]).sum_d for s0 in range(0, sel_g.shape[0], chunk)]
+        return torch.cat(parts) / V
+
+    use_bounds = items >= 1024 if bounds is None else bool(bounds)
+    if not use_bounds:
+        err_d = (exact(gt_rel, pr_rel) < thr).reshape(hi - lo, n)
+        if stats is not None:
+            stats.update(items=items, by_bounds=0, exact=items)
+        return err_d, err_d.sum(dim=1, dtype=torch.int32)[:, None]
+    fld = surface_field(sp)
+    lb, ub = ops.adds_bounds(v, gt_rel, pr_rel, fld)
+    accept = ub / V < thr - VOTE_SLACK_MM
+    reject = lb / V > thr + VOTE_SLACK_MM
+    open_idx = torch.nonzero(~(accept | reject))[:, 0]                    # the one host round trip: how many need the search
+    err_flat = accept.clone()
+    if open_idx.numel():
+        err_flat[open_idx] = exact(gt_rel[open_idx], pr_rel[open_idx]) < thr
+    if stats is not None:
+        stats.update(items=items, by_bounds=items - int(open_idx.numel()), exact=int(open_idx.numel()),
+                     accepted_by_bound=int(accept.sum().item()), rejected_by_bound=int(reject.sum().item()))
+    err_d = err_flat.reshape(hi - lo, n)
     return err_d, err_d.sum(dim=1, dtype=torch.int32)[:, None]
 
 

@@ -292,6 +292,19 @@ int isr_nn_batched(const float* qry, int Nq, const float* tgt, int Nt, const dou
                    int32_t* n_in, int32_t* nn_idx, double* nn_d, double* cov, void* ws,
                    size_t ws_bytes, isr_stream_t stream);
 
+/* a11 (the n x n vote, choosePose.py:121-145) needs only the decision ADDS(...) < 0.1 * diameter.  Bounds of
+ *   sum_v dist(Tt[b]^-1 Tq[b] v, S)   (= V x ADD-S of item b: isr_nn_batched's sum_d with queries verts, targets S)
+ * from a distance field of the surface cloud S: field (nz, ny, nx) f32 = the exact distance from each cell CENTRE of a uniform
+ * grid (origin grid_min, edge h; the caller builds it once per cloud, e.g. through isr_nn_batched on the centres) — dist(., S)
+ * is 1-Lipschitz, so a vertex x lies within |x - centre(c)| of field[c] for the cell c that holds it (or, outside the grid, the
+ * nearest cell of the grid; its distance to surface_bbox (lo xyz, hi xyz) is then a second lower bound): both sums are
+ * finite for every pose.  verts (V,3) f32, Tq / Tt (B,12) f64 rigid
+ * [R|t] (Tt nullable = identity), field on the device; grid_min (3 doubles) and surface_bbox (6 floats) on the HOST.
+ * lb_sum, ub_sum (B) f64 on the device.  An item whose bounds straddle the threshold is evaluated exactly by the caller. */
+int isr_adds_bounds(const float* verts, int V, const double* Tq, const double* Tt, int B, const float* field,
+                    const double* grid_min, double h, int nx, int ny, int nz, const float* surface_bbox,
+                    double* lb_sum, double* ub_sum, isr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * a6 / a7  estimate_pose(): the SurfEmb-style sample-and-score estimator, poseEstSurf.py:11-261
  * (stages; the host driver pose_est_surf.estimate_pose keeps the reference's signature).

@@ -92,6 +92,13 @@ def test_vote_n512_as_eight_row_blocks(cuda0):
 
     img, top, err = sequence.vote_choose_image(V, S, Rg, tg, Rp, tp, diam)       # unsharded: all 262 144 items
     assert err.shape == (n, n) and 0.1 < err.mean() < 0.95
+    # the bounds route (the default at this size) decides most items without a search and returns the booleans of the
+    # search on every item: rows 100 .. 131 both ways
+    st = {}
+    e_b, _ = sequence.vote_rows(V, S, Rg, tg, Rp, tp, diam, 100, 132, bounds=True, stats=st)
+    e_x, _ = sequence.vote_rows(V, S, Rg, tg, Rp, tp, diam, 100, 132, bounds=False)
+    assert torch.equal(e_b, e_x) and np.array_equal(e_b.cpu().numpy().astype(np.float64), err[100:132])
+    assert st["items"] == 32 * n and st["by_bounds"] > 0.5 * st["items"], st
     sums_blocks, rows_blocks = [], []
     for r in range(RANKS):
         lo, hi = shard.block_range(n, r, RANKS)

@@ -12,18 +12,31 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(1)
 S = synth.tless_like(rng, N); Vv = synth.tless_like(rng, V); diam = synth.diameter(S)
 Rg, tg = synth.random_poses(rng, n)
-for label, deg, tr in (("registered (0.2-3 deg, 0.5-3 mm off)", (0.2, 3.0), (0.5, 3.0)), ("half of them failed (random poses)", None, None)):
-    if deg is not None:
+diam_thr = 0.1 * diam
+for label, deg, tr in (("registered (0.2-3 deg, 0.5-3 mm off)", (0.2, 3.0), (0.5, 3.0)), ("half of them failed (random poses)", None, None),
+                       ("a quarter near the threshold (translations 0.6-1.4 x 0.1 diameter off)", "mixed", None)):
+    if deg == "mixed":
+        P = [synth.perturb_pose(rng, Rg[i], tg[i], 2.0, 1.0) for i in range(n)]
+        for i in range(0, n, 4):
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            P[i] = (P[i][0], tg[i] + u * diam_thr * rng.uniform(0.6, 1.4))
+    elif deg is not None:
         P = [synth.perturb_pose(rng, Rg[i], tg[i], rng.uniform(*deg), rng.uniform(*tr)) for i in range(n)]
     else:
         P = [synth.perturb_pose(rng, Rg[i], tg[i], 1.0, 1.0) if i % 2 else (synth.random_poses(rng, 1)[0][0], tg[i]) for i in range(n)]
     Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
-    for path in (-1, 0):
+    ref = None
+    for path, bounds in ((-1, True), (-1, False), (0, False)):
         with ops.tuning(nn_path=path):
-            sequence.vote_rows(Vv, S, Rg[:8], tg[:8], Rp[:8], tp[:8], diam, 0, 8)
+            st = {}
+            sequence.vote_rows(Vv, S, Rg[:8], tg[:8], Rp[:8], tp[:8], diam, 0, 8, bounds=bounds)      # warm: field, workspaces
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            e_d, sums = sequence.vote_rows(Vv, S, Rg, tg, Rp, tp, diam, 0, n)
+            e_d, sums = sequence.vote_rows(Vv, S, Rg, tg, Rp, tp, diam, 0, n, bounds=bounds, stats=st)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             err, img = e_d.float().cpu().numpy(), int(sums[:, 0].argmax())
-        print(f"{label}: nn_path={path:2d}  n={n} ({n * n} items of {V} x {N}): {dt * 1e3:8.1f} ms = {dt / (n * n) * 1e6:6.2f} us per item, "
-              f"{n * n * V * N / dt * 1e-12:6.1f} T brute-force-equivalent pairs/s; accepted {err.mean():.3f}, chosen {img}", flush=True)
+        ref = err if ref is None else ref
+        print(f"{label}: nn_path={path:2d} bounds={int(bounds)}  n={n} ({n * n} items of {V} x {N}): {dt * 1e3:8.1f} ms = "
+              f"{dt / (n * n) * 1e6:6.2f} us per item, {n * n * V * N / dt * 1e-12:6.1f} T brute-force-equivalent pairs/s; "
+              f"accepted {err.mean():.3f}, chosen {img}, searched {st['exact']} of {st['items']}, same matrix {bool((err == ref).all())}", flush=True)
+t0 = time.perf_counter(); sequence._field_cache.clear(); f = sequence.surface_field(torch.from_numpy(S).to(dev)); torch.cuda.synchronize()
+print(f"distance field {f.dims} of {N} points (h = {f.h:.3f} mm): {(time.perf_counter() - t0) * 1e3:.1f} ms, once per object", flush=True)
