@@ -582,8 +582,10 @@ def main():
             out = {}
             if args.verify == "vote":
                 Pa = poses_all.reshape(-1, 3, 4)
-                best, top, err = sequence.vote_choose_image(cad_d, pts, R_gt, t_gt, Pa[:, :, :3], Pa[:, :, 3], diameter)
-                out.update(picked_image=best, vote_top5=[int(v) for v in top[:5]], vote_row_sum=float(err.sum(1).max()) if len(err) else None)
+                vst = {}
+                best, top, err = sequence.vote_choose_image(cad_d, pts, R_gt, t_gt, Pa[:, :, :3], Pa[:, :, 3], diameter, stats=vst)
+                out.update(picked_image=best, vote_top5=[int(v) for v in top[:5]], vote_row_sum=float(err.sum(1).max()) if len(err) else None,
+                           vote_items_searched=vst.get("exact"), vote_items=vst.get("items"))
             else:
                 best, ch, table = sequence.pick_by_chamfer_table(pts, poses_all, R_gt, t_gt, n_total)
                 out.update(picked_pair=best, picked_image=best, pair_chamfer=ch, chamfer_table=table)

@@ -466,7 +466,8 @@ def vote_rows(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, lo
     return err_d, err_d.sum(dim=1, dtype=torch.int32)[:, None]
 
 
-def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, top: int = 50, chunk: int = 4096):
+def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, top: int = 50, chunk: int = 4096,
+                      bounds: bool | None = None, stats: dict | None = None):
     """choosePose.py:79-151 sharded by rows: every rank holds all n predicted and GT
     poses, builds rows block_range(n, rank, world) of the two relative-pose tables on the device
     (compute_rel_poses, choosePose.py:43-51), evaluates its rows of
@@ -474,13 +475,13 @@ def vote_choose_image(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diam
     with the batched NN kernel, and all-gathers the int32 row sums; argmax / top-50 are then computed
     identically on every rank (ties -> lower index).  The tables, the ADD-S values and the comparison stay on
     the device: one copy brings back this rank's error rows (the reference writes them to error.npy), one the
-    row sums.  Returns (image_id, top indices, local error rows (rows, n) f64 of 0/1)."""
+    row sums.  bounds / stats: see vote_rows (items decided from the distance field, the search only where needed).  Returns (image_id, top indices, local error rows (rows, n) f64 of 0/1)."""
     rank, size = shard.world()
     n = len(R_gt)
     lo, hi = shard.block_range(n, rank, size)
     dev = registration.device()
     if hi > lo:
-        err_d, sums_local = vote_rows(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, lo, hi, chunk)
+        err_d, sums_local = vote_rows(model_verts, surface_pts, R_gt, t_gt, R_pred, t_pred, diameter, lo, hi, chunk, bounds, stats)
         err = err_d.to(torch.float64).cpu().numpy()
     else:
         err = np.zeros((0, n))
