@@ -152,6 +152,11 @@ def test_vote_vs_reference_statements(cuda0):
     image_id, top, rows = sequence.vote_choose_image(g["verts"], g["surface"], g["R_gt"], g["t_gt"], g["R_pred"], g["t_pred"],
                                                      float(g["diameter"]))
     assert image_id == int(g["image_id"]) and np.array_equal(rows, g["error"])
+    # the same with every item first bracketed from the surface cloud's distance field (the default from 1 024 items)
+    st = {}
+    image_b, _, rows_b = sequence.vote_choose_image(g["verts"], g["surface"], g["R_gt"], g["t_gt"], g["R_pred"], g["t_pred"],
+                                                    float(g["diameter"]), bounds=True, stats=st)
+    assert image_b == image_id and np.array_equal(rows_b, g["error"]) and st["by_bounds"] + st["exact"] == rows_b.size
     sums = g["error"].sum(1)
     assert np.array_equal(sums[np.asarray(top)], sums[g["top_indices"]])
 
