@@ -34,6 +34,7 @@ struct DirectState {
   float m2;  // second largest tile maximum (with multiplicity)
   float l;   // sum 2^(s') over the current chunk
   int tb;    // first key of the first 32-key tile whose maximum reached m
+  float thr; // screen (ISR_K1_SCREEN): 2^(query's maximum so far - dlt) — a tile whose sum of exponentials stays below it holds nothing near the maximum
   double L;  // the canonical f64 sum of the chunk sums so far (what corr_finalize_kernel forms from memory)
 };
 
@@ -58,6 +59,20 @@ __device__ __forceinline__ float tile_max(const f32x16& acc) {
 // Cauchy-Schwarz bound instead: |s'| <= |q||k|_max < kLseBound puts every term inside [2^-99, 2^99] and the maximum above kLow;
 // a query that fails the bound goes to the fallback as a bad one does.  The sums, and with them lse, are the full kernel's bits.
 constexpr float kLseBound2 = 99.f * 99.f;
+// ISR_K1_SCREEN (plain rows): the tile's 16 exponentials are summed on their own (ts) before they join the chunk sum, and
+// ts >= max_i 2^(s_i) (1 - 16 u) SCREENS the tile for the maxima: with thr = 2^(M - dlt), M the largest logit the query's two
+// lanes have seen and dlt > 2 eps + the roundings of exp2 / the sum / M - dlt (eps: corr_finish's margin bound), ts < thr
+// proves that every logit of the tile lies more than 2 eps below M, hence below the final maximum: it is neither the
+// arg-max nor a runner-up the margin test could care about (a logit within 2 eps of the winner always sits in a tile that
+// took the slow path, where m / m2 / tb are kept exactly as before).  The 12 max-type instructions of a tile (of 44) then
+// run only when SOME lane of the wave fails the screen (wave-uniform branch); the slow path also refreshes thr from the
+// maximum of the query's two lanes (v_permlane32_swap).  The first tiles always take it (thr starts at 0).
+#ifndef ISR_K1_SCREEN
+#define ISR_K1_SCREEN 1
+#endif
+#ifndef ISR_K1_SCREEN_PLANES          // bit SP: plane rows of SP blocks per plane use the screen
+#define ISR_K1_SCREEN_PLANES 0x106    // SP = 1, 2, 8
+#endif
 // SP = 8 (f16 planes of 128-wide rows): 24 + 24 + 24 fragments of a wave's two query blocks and of a key sub-tile need more
 // than 256 registers — one wave per SIMD with the whole 512-register file, and two 48 KB stage buffers as dynamic LDS.
 extern __shared__ uint4 corr_direct_dyn_lds[];
@@ -75,6 +90,10 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
   // the margin test's bound: plain rows (D + 2) 2^-23 |q||k|; split rows split_deff / split_deff_f16 (+ the absolute term)
   constexpr int DEFF = SP ? (F16 ? split_deff_f16(SP) : split_deff(SP)) : 16 * DK;
   constexpr float EABS = (SP && F16) ? split_eabs(SP ? SP : 1) : 0.f;
+  // the sum screen of the maxima: plain rows always; plane rows where it pays — SP = 1, 2 and 8 (D = 12: 3.30 -> 3.05 ms on the
+  // crop batch, D = 32: 1.56 -> 1.50, D = 128: 6.7 -> 5.8 ms per image); at SP = 4 the 12 (24) matrix instructions of a tile
+  // already hide the maxima and the branch behind the item costs more than they did (2.56 -> 2.77 ms, profiles/r04_k1_screen.txt)
+  constexpr bool SCR = ISR_K1_SCREEN != 0 && (SP == 0 || ((ISR_K1_SCREEN_PLANES >> SP) & 1) != 0);
   if (gated_off(ws)) return;
   static_assert(SP == 0 || DK == 3 * SP, "split rows: DK counts the 3 SP blocks of a row");
   constexpr int NCH = 2 * NFR;
@@ -192,6 +211,21 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     st[qb].m = -__builtin_inff(); st[qb].m2 = -__builtin_inff(); st[qb].l = 0.f; st[qb].tb = 0; st[qb].L = 0.0;
+#if defined(ISR_ABL_SCREEN) && ISR_ABL_SCREEN == 1
+    st[qb].thr = __builtin_inff();
+#else
+    st[qb].thr = 0.f;
+#endif
+  }
+  // the screen's distance below the maximum, in raw logit units: 2 eps of corr_finish (same |q|^2, same max |k|^2) inflated by
+  // 1 %, plus 1e-4 for v_exp_f32 (1 ulp), the 15 additions of ts and the rounding of M - dlt (|M| < 128: 8e-6)
+  float dlt[QB];
+  {
+    const float kn2s = kn2_max(ws);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+      dlt[qb] = 2.02f * ((float)(DEFF + 2) * 1.1920929e-7f * 1.0001f * __builtin_sqrtf(qn2[qb] * kn2s) +
+                         EABS * (__builtin_sqrtf(qn2[qb]) + __builtin_sqrtf(kn2s))) + 1e-4f;
   }
 
   const int c0 = split * range_chunks;                 // first canonical chunk of this key range
@@ -357,6 +391,59 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
               }
             }
           };
+          if constexpr (SCR) {
+          // the screen (see ISR_K1_SCREEN above): the tile's own sum ts grows through the phases, joins the chunk sum in the last
+          // one, and decides behind the item whether the maxima look at the tile at all
+          float ts = 0.f;
+          f32x16 c = splat16(0.f);
+          auto phase = [&](auto ph_tag) {
+            constexpr int ph = decltype(ph_tag)::value;
+#pragma unroll
+            for (int j = 0; j < SP; ++j) c = mfma16<F16>(a[RF::PA[ph] * SP + j], bq[qbn][RF::PB[ph] * SP + j], c);
+            if constexpr (RF::RD[ph] >= 0) reads(RF::RD[ph]);
+#pragma unroll
+            for (int i = RF::E0[ph]; i < RF::E0[ph + 1]; ++i) {
+              const float e = __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
+              ts = i == 0 ? e : ts + e;
+            }
+            if constexpr (ph + 1 == RF::NPH) st[qb].l += ts;
+            constexpr int ne = RF::E0[ph + 1] - RF::E0[ph];
+            constexpr int nv = (NAT ? 3 : 2) * ne - (RF::E0[ph] == 0 && ne > 0 ? 1 : 0) + (ph + 1 == RF::NPH ? 1 : 0);
+            constexpr int gv = (nv + SP - 1) / SP;
+#pragma unroll
+            for (int j = 0; j < SP; ++j) {
+              __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+              if (reload && RF::RD[ph] >= 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+              if constexpr (gv > 0) __builtin_amdgcn_sched_group_barrier(0x002, gv, 0);
+            }
+            if constexpr (ph + 1 < RF::NPH) {
+              asm volatile("" : "+v"(c), "+v"(ts));
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
+          phase(std::integral_constant<int, 0>{});
+          phase(std::integral_constant<int, 1>{});
+          phase(std::integral_constant<int, 2>{});
+          if constexpr (RF::NPH == 6) {
+            phase(std::integral_constant<int, 3>{});
+            phase(std::integral_constant<int, 4>{});
+            phase(std::integral_constant<int, 5>{});
+          }
+          nxt = c;
+          asm volatile("" : "+v"(nxt), "+v"(st[qb].l), "+v"(ts));
+          if constexpr (TRK) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(ts >= st[qb].thr) != 0ull, 0)) {   // wave-uniform
+              const float t = tile_max(cur);
+              st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);   // second largest of {m, m2, t} (m2 <= m)
+              st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;                     // strict: the first tile to reach m keeps it
+              st[qb].m = fmaxf(st[qb].m, t);
+              const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[qb].m), __float_as_uint(st[qb].m), false, false);
+              const float mq = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+              const float ax = mq - dlt[qb];
+              st[qb].thr = __builtin_amdgcn_exp2f(NAT ? ax * kLog2e : ax);
+            }
+          }
+          } else {
           float l = st[qb].l;
           f32x16 c = splat16(0.f);
           auto phase = [&](auto ph_tag) {
@@ -398,6 +485,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
           st[qb].l = l;
           nxt = c;
           asm volatile("" : "+v"(nxt), "+v"(st[qb].l));
+          }
         }
       } else
       if (FULL || kb < k1) {  // block-uniform
@@ -409,6 +497,42 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
           if (w == NW - 2) { if (has_next) load_a(buf ^ 1, 0); }
           else load_a(buf, sub + 1);
         }
+#if ISR_K1_SCREEN
+        // the tile's own sum first (the canonical order of a chunk sum: tile sums in register order, added tile after tile)
+        float ts = __builtin_amdgcn_exp2f(NAT ? cur[0] * kLog2e : cur[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) ts += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
+        st[qb].l += ts;
+        // issue order: the item's 33 VALU instructions (16 exp2, 15 + 1 add, the screen's compare; NAT: 16 mul more) spread
+        // evenly behind the DK MFMAs of the next item; the empty asm ties the item's results to a fixed point of the
+        // instruction stream (without it instruction selection sinks all eight epilogues below all eight MFMA chains)
+        constexpr int G = ((NAT ? 49 : 33) + NMF - 1) / NMF;
+#pragma unroll
+        for (int s = 0; s < NMF; ++s) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (qb == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // this fragment's next ds_read
+          __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
+        }
+        asm volatile("" : "+v"(nxt), "+v"(st[qb].l), "+v"(ts));
+#ifndef ISR_ABL_DNOMAX   // timing-only ablation (tools/ablate_direct.sh): no maxima at all
+        if constexpr (TRK) {
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(ts >= st[qb].thr) != 0ull, 0)) {   // wave-uniform
+            const float t = tile_max(cur);
+            st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);   // second largest of {m, m2, t} (m2 <= m)
+            st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;                     // strict: the first tile to reach m keeps it
+            st[qb].m = fmaxf(st[qb].m, t);
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(st[qb].m), __float_as_uint(st[qb].m), false, false);
+            const float mq = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));   // [0]: the h = 0 lane's value on both lanes, [1]: the h = 1 lane's
+            const float a = mq - dlt[qb];
+#if !defined(ISR_ABL_SCREEN)   // timing-only ablations: 1 = thr stays +inf (no tile takes the slow path), 2 = thr stays 0 (every tile does)
+            st[qb].thr = __builtin_amdgcn_exp2f(NAT ? a * kLog2e : a);
+#else
+            asm volatile("" :: "v"(a));
+#endif
+          }
+        }
+#endif
+#else
 #ifdef ISR_ABL_DNOMAX   // timing-only ablations (tools/ablate_direct.sh): keep the accumulator live
         asm volatile("" :: "v"(cur[0]), "v"(cur[15]));
         st[qb].m = 0.f;
@@ -444,6 +568,7 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
           __builtin_amdgcn_sched_group_barrier(0x002, G, 0);
         }
         asm volatile("" : "+v"(nxt), "+v"(st[qb].l), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }

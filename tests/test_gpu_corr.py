@@ -686,3 +686,56 @@ def test_corr_result_is_independent_of_the_number_of_key_ranges(cuda0, kind):
             got = call()
         for a, b in zip(got, auto):
             assert torch.equal(a, b), ns
+
+
+@pytest.mark.parametrize("log2", [True, False])
+@pytest.mark.parametrize("D", [16, 64, 128])
+def test_corr_screened_maxima_near_ties_in_skipped_looking_tiles(cuda0, oracle_lib, log2, D):
+    """The sum screen of the direct kernel (corr_direct.hpp, ISR_K1_SCREEN): a tile enters the maxima only when the sum of
+    its exponentials reaches 2^(maximum so far - dlt).  Adversarial layout: a dominant key early in the stream (every later
+    tile of plain keys is skipped), and far behind it — alone among near-zero keys — keys whose EXACT logit differs from
+    the dominant one's by one bf16 ulp of one coordinate, by nothing (a duplicate), or by less than the MFMA's accumulation
+    error, above and below.  The exact arg-max (lowest key on ties) must come out, through the recheck where the f32
+    logits cannot tell."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(100 + D + (1 if log2 else 0))
+    P, N = 384, 12000
+    K = rng.normal(0, 0.02, (N, D)).astype(np.float32)                  # near-zero keys: logits ~ 0, tile sums ~ 16
+    Q = rng.normal(0, 1.0, (P, D)).astype(np.float32)
+    Q *= 6.0 / np.linalg.norm(Q, axis=1, keepdims=True)
+    qb = torch.from_numpy(Q).bfloat16()
+    Qr = qb.float().numpy()
+    dom = Qr[:96] * (5.0 / 6.0)                                          # 96 dominant keys, parallel to queries 0..95 (logit ~ 30); the other queries see them at random angles
+    pos_dom = 40 + 37 * np.arange(96)                                    # early keys, scattered over tiles
+    K[pos_dom] = dom
+    kb = torch.from_numpy(K).bfloat16()
+    Kr = kb.float().numpy()
+    # rivals far behind: copies of the rounded dominant key with a one-ulp nudge of one coordinate (up, down, none)
+    pos_riv = 6000 + 61 * np.arange(96)
+    riv = Kr[pos_dom].copy()
+    kind = np.arange(96) % 3
+    for j in range(96):
+        c = int(rng.integers(D))
+        v = torch.tensor(riv[j, c]).bfloat16()
+        bits = v.view(torch.int16).item()
+        if kind[j] == 1: bits += 1 if bits >= 0 else -1                 # one ulp away from zero
+        if kind[j] == 2: bits -= 1 if bits > 0 else -1                  # one ulp towards zero
+        riv[j, c] = torch.tensor(bits, dtype=torch.int16).view(torch.bfloat16).float().item()
+    Kr[pos_riv] = riv
+    Kr[3] = Kr[pos_dom[5]]                                               # and an exact duplicate IN FRONT of a dominant key
+    kb = torch.from_numpy(Kr).bfloat16()
+    if log2:
+        ql = ops.prescale_queries_log2(torch.from_numpy(Qr).to(cuda0))
+        idx, logp = ops.corr_argmax(ql, kb.to(cuda0), log2_prescaled=True)
+        o = oracle_lib.corr_argmax_bf16(_bits(ql.cpu()), _bits(kb), logit_scale=np.log(2.0))
+    else:
+        idx, logp = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0))
+        o = oracle_lib.corr_argmax_bf16(_bits(qb), _bits(kb))
+    torch.cuda.synchronize()
+    got = idx.cpu().numpy()
+    assert np.array_equal(got, o["idx"])
+    # the layout does what it says: winners are dominant keys, their rivals or the duplicate in front
+    assert np.isin(got, np.concatenate([pos_dom, pos_riv, [3]])).all()
+    assert (np.isin(got, pos_riv)).sum() > 0 and (np.isin(got, pos_dom)).sum() > 0
+    assert ops.corr_recheck_count() > 0
+    np.testing.assert_allclose(logp.cpu().numpy(), o["maxlogit"] - o["lse"], atol=3e-5)
