@@ -499,9 +499,24 @@ __global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void cor
         }
 #if ISR_K1_SCREEN
         // the tile's own sum first (the canonical order of a chunk sum: tile sums in register order, added tile after tile)
-        float ts = __builtin_amdgcn_exp2f(NAT ? cur[0] * kLog2e : cur[0]);
+        // DK = 1 (one matrix instruction per tile: the item is all VALU): four interleaved partial sums (registers i, i + 4,
+        // i + 8, i + 12), then (c0 + c1) + (c2 + c3) — the same 15 additions as one chain, a quarter of its dependent length:
+        // 17.98 -> 17.22 ms per 32-image launch at D = 16; at D = 64 / 128 and on the plane routes one chain is as fast or
+        // 1 % faster (profiles/r04_k1_screen.txt, section 8)
+        float ts;
+        if constexpr (DK == 1) {
+          float tc[4];
 #pragma unroll
-        for (int i = 1; i < 16; ++i) ts += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
+          for (int i = 0; i < 16; ++i) {
+            const float e = __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
+            tc[i & 3] = i < 4 ? e : tc[i & 3] + e;
+          }
+          ts = (tc[0] + tc[1]) + (tc[2] + tc[3]);
+        } else {
+          ts = __builtin_amdgcn_exp2f(NAT ? cur[0] * kLog2e : cur[0]);
+#pragma unroll
+          for (int i = 1; i < 16; ++i) ts += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
+        }
         st[qb].l += ts;
         // issue order: the item's 33 VALU instructions (16 exp2, 15 + 1 add, the screen's compare; NAT: 16 mul more) spread
         // evenly behind the DK MFMAs of the next item; the empty asm ties the item's results to a fixed point of the
