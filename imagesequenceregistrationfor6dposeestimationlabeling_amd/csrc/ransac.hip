@@ -412,6 +412,9 @@ __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __r
 }
 
 // ---------------------------------------------------------------------------------- refit
+#ifndef ISR_GN_SPLIT_SOLVE
+#define ISR_GN_SPLIT_SOLVE 1      // 0: the solve in gn_accumulate_kernel's last workgroup (round 3 .. first half of round 4)
+#endif
 constexpr int kRefThreads = 256;
 constexpr int kRefBlocks = 64;
 constexpr int kNAcc = 29;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2) + 1 (number of correspondences used)
@@ -420,7 +423,7 @@ constexpr int kNAcc = 29;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2) + 1 (nu
 // the 6x6 normal equations by Cholesky and retracts:  R <- Q(w) R,  t <- Q(w) t + dt  with Q(w) the
 // rotation of the unit quaternion (1, w/2)/|.| (sqrt only: no sin/cos, so the step is plain IEEE
 // arithmetic).  state[0] = 1 once the step is below 1e-12: later launches return at once.
-// (Runs in the LAST workgroup of gn_accumulate_kernel to deliver its partial sums: one launch per iteration.)
+// (gn_solve_kernel, a launch of its own behind gn_accumulate_kernel: see there.)
 __device__ void gn_solve(const double* __restrict__ partial, int nblocks, double* __restrict__ Rt, int32_t* __restrict__ state) {
   __shared__ double s[kNAcc];
   if (threadIdx.x < kNAcc) {
@@ -555,6 +558,24 @@ __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
   if (threadIdx.x < kNAcc)
     partial[(size_t)blockIdx.x * kNAcc + threadIdx.x] =
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+#if ISR_GN_SPLIT_SOLVE
+  (void)last;
+}
+
+// The solve of one Gauss-Newton step, one workgroup per image, in a launch of its own behind gn_accumulate_kernel.  Until
+// the second half of round 4 the LAST workgroup of gn_accumulate_kernel solved (a ticket behind __threadfence()): on gfx950
+// an agent-scope fence is `buffer_wbl2 sc1` + `buffer_inv sc1` — a write-back and an invalidation of the XCD's L2 — in
+// every wave of every one of the 2 048 workgroups of every launch, beside a K1 whose keys live in that L2.  The kernel
+// boundary orders the partial sums for free.
+__global__ __launch_bounds__(64) void gn_solve_kernel(const double* __restrict__ partial, int nblocks, double* __restrict__ Rt,
+                                                       const int32_t* __restrict__ status_dev, int32_t* __restrict__ state) {
+  const int img = blockIdx.x;
+  state += 4 * img;
+  if (state[0]) return;                                  // converged
+  if (status_dev && status_dev[img] == 0) return;        // no pose: nothing was accumulated
+  gn_solve(partial + (size_t)img * kRefBlocks * kNAcc, nblocks, Rt + (size_t)img * 12, state);
+}
+#else
   // the last workgroup to deliver its sums (agent-scope fences order them before the ticket) solves
   __threadfence();
   __syncthreads();
@@ -565,6 +586,7 @@ __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
   if (threadIdx.x == 0) state[1] = 0;
   gn_solve(partial, (int)gridDim.x, const_cast<double*>(Rt), state);
 }
+#endif
 
 // ------------------------------------------------------------------- refit, small correspondence sets
 // The whole refit of an image — Gauss-Newton over the RANSAC inliers, the local-optimisation round (inliers of the
@@ -905,6 +927,9 @@ static int refine_impl(const float* p3d, const float* p2d, const int32_t* M_dev,
   for (int it = 0; it < iters; ++it) {
     gn_accumulate_kernel<<<dim3(nblocks, 1, B), kRefThreads, 0, stream>>>(p3d, p2d, M_dev, M_cap, mask, mask_words_of(M_cap),
                                                                              ib, Rt_io, status_dev, state, partial);
+#if ISR_GN_SPLIT_SOLVE
+    gn_solve_kernel<<<B, 64, 0, stream>>>(partial, nblocks, Rt_io, status_dev, state);
+#endif
   }
   ISR_CHECK_LAUNCH("pnp refine kernels");
   return ISR_OK;
