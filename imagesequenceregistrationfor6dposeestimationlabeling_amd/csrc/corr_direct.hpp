@@ -76,8 +76,11 @@ constexpr float kLseBound2 = 99.f * 99.f;
 // SP = 8 (f16 planes of 128-wide rows): 24 + 24 + 24 fragments of a wave's two query blocks and of a key sub-tile need more
 // than 256 registers — one wave per SIMD with the whole 512-register file, and two 48 KB stage buffers as dynamic LDS.
 extern __shared__ uint4 corr_direct_dyn_lds[];
+#ifndef ISR_K1_PLAIN_WAVES
+#define ISR_K1_PLAIN_WAVES 3      // waves per SIMD the plain-row kernels (D <= 64) are compiled for
+#endif
 template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0, bool F16 = false, bool LSE = false>
-__global__ __launch_bounds__(kThreads, DK <= 4 ? 3 : (SP >= 8 ? 1 : 2)) void corr_bf16_direct_kernel(
+__global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES : (DK <= 4 ? 3 : (SP >= 8 ? 1 : 2))) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
     float* __restrict__ lse_out) {
