@@ -739,3 +739,36 @@ def test_corr_screened_maxima_near_ties_in_skipped_looking_tiles(cuda0, oracle_l
     assert (np.isin(got, pos_riv)).sum() > 0 and (np.isin(got, pos_dom)).sum() > 0
     assert ops.corr_recheck_count() > 0
     np.testing.assert_allclose(logp.cpu().numpy(), o["maxlogit"] - o["lse"], atol=3e-5)
+
+
+@pytest.mark.parametrize("D,chain", [(12, 0), (12, 2), (32, 0), (32, 2), (64, 0), (100, 0), (128, 0)])
+def test_corr_f32_screened_maxima_near_ties_in_skipped_looking_tiles(cuda0, oracle_lib, D, chain):
+    """The same adversarial layout on the f32 plane routes (the screen is compiled in at SP = 1, 2, 8: D <= 32 and D > 64):
+    rivals one f32 ulp away from a dominant key, far behind it among near-zero keys; the f32 fmaf-chain arg-max of the oracle
+    (lowest key on ties) must come out."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(300 + D + chain)
+    P, N = 384, 12000
+    K = rng.normal(0, 0.02, (N, D)).astype(np.float32)
+    Q = rng.normal(0, 1.0, (P, D)).astype(np.float32)
+    Q *= (6.0 / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float32)
+    pos_dom = 40 + 37 * np.arange(96)
+    pos_riv = 6000 + 61 * np.arange(96)
+    K[pos_dom] = Q[:96] * np.float32(5.0 / 6.0)
+    riv = K[pos_dom].copy()
+    kind = np.arange(96) % 3
+    for j in range(96):
+        c = int(rng.integers(D))
+        if kind[j] == 1: riv[j, c] = np.nextafter(riv[j, c], np.float32(np.inf) * np.sign(riv[j, c]))
+        if kind[j] == 2: riv[j, c] = np.nextafter(riv[j, c], np.float32(0))
+    K[pos_riv] = riv
+    K[3] = K[pos_dom[5]]
+    with ops.tuning(k1_f32_chain=chain):
+        idx, logp = ops.corr_argmax(torch.from_numpy(Q).to(cuda0), torch.from_numpy(K).to(cuda0))
+        torch.cuda.synchronize()
+    o = oracle_lib.corr_argmax_f32(Q, K)
+    got = idx.cpu().numpy()
+    assert np.array_equal(got, o["idx"])
+    assert np.isin(got, np.concatenate([pos_dom, pos_riv, [3]])).all()
+    assert (np.isin(got, pos_riv)).sum() > 0 and (np.isin(got, pos_dom)).sum() > 0
+    np.testing.assert_allclose(logp.cpu().numpy(), o["maxlogit"].astype(np.float64) - o["lse"], atol=3e-5)
