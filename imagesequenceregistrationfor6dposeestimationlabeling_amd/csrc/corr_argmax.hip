@@ -810,10 +810,19 @@ __device__ __attribute__((noinline)) double exact_logit(const uint16_t* __restri
 // list length.  (With 4 ranges fixed the pass took 0.43 ms of a 1.6 ms estimate_pose call at P = 5 476, N = 80 000.)
 // The outcome does not depend on the partition: ranges merge in ascending order, ties keep the lower key.
 constexpr int kRSplitGrid = 64;
+// A LONG list needs no key ranges at all: every (group of 256 listed queries, range) unit gathers the group's query rows again and
+// pays its own prologue, so ranges are halved while half as many still leave kRUnits units for the launch's slots (configs[3]'s
+// keys send 6.8 % of 9.8 M queries here: 2 608 groups x 64 ranges of 7 stages each took 8.9 ms per launch; see the header of
+// profiles/r04_k1_recheck_ranges.txt).
+#ifndef ISR_K1_RECHECK_UNITS
+#define ISR_K1_RECHECK_UNITS 2048
+#endif
+constexpr long kRUnits = ISR_K1_RECHECK_UNITS;
 __device__ __forceinline__ int recheck_ranges(int cnt, int P, int rsplit, int nstage_all) {
   const long cap = (long)rsplit * P;
+  const long groups = ((long)cnt + kWaves * kQB * 32 - 1) / (kWaves * kQB * 32);
   int rs = kRSplitGrid;
-  while (rs > 1 && ((long)rs * cnt > cap || rs > nstage_all)) rs >>= 1;
+  while (rs > 1 && ((long)rs * cnt > cap || rs > nstage_all || groups * (rs >> 1) >= kRUnits)) rs >>= 1;
   return rs;
 }
 
@@ -891,8 +900,12 @@ __global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
                 for (int i = 0; i < 16; ++i) {            // ascending key inside the lane: strict > keeps the lowest
                   if (acc[i] >= thr[qb]) {
                     const int n = kb + 4 * h + (i & 3) + 8 * (i >> 2);
+#ifdef ISR_ABL_RECHECK_NOEXACT   // timing-only ablation: what the in-line exact evaluations cost the pass (results are the f32 arg-max)
+                    const double v = (double)acc[i];
+#else
                     const double v = f32.q ? chain_logit_f32(f32.q + (size_t)qrow[qb] * f32.ldq, f32.k + (size_t)n * f32.ldk, f32.D)
                                            : exact_logit(Q + (size_t)qrow[qb] * ldq, K + (size_t)n * ldk, 16 * DK, scale);
+#endif
                     if (v > best[qb] || (v == best[qb] && n < bidx[qb])) { best[qb] = v; bidx[qb] = n; }
                   }
                 }
