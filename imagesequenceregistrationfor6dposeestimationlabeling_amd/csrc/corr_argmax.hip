@@ -836,8 +836,11 @@ __device__ __attribute__((noinline)) double chain_logit_f32(const float* __restr
   return (double)acc;
 }
 
+#ifndef ISR_K1_RECHECK_WAVES
+#define ISR_K1_RECHECK_WAVES 1      // waves per SIMD corr_recheck_kernel is compiled for on plain rows of D <= 64
+#endif
 template <int DK, int SP = 0, bool F16 = false>
-__global__ __launch_bounds__(kThreads, 1) void corr_recheck_kernel(
+__global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_RECHECK_WAVES : 1) void corr_recheck_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int rsplit, double scale, F32Rows f32, CorrWs ws) {
   using KS = KeyStage<DK, SP>;

@@ -1,10 +1,10 @@
 #!/bin/bash
 # round 4, session 2: what bounds corr_recheck_kernel on a long list — kernel table of tools/time_corr_ties.py, tree against the timing-only
-# ablation without the in-line exact evaluations (ab_tmp/rr_noexact.so)
+# build for three waves per SIMD (ab_tmp/rrw3.so)
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2
-for lib in tree rr_noexact; do
+for lib in tree rrw3; do
   [ $lib = tree ] && unset ISR_HIP_LIB || export ISR_HIP_LIB=$GRAFT_REPO_ROOT/ab_tmp/$lib.so
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/s2/prof_$lib -- python3 tools/time_corr_ties.py > gpurun_out/s2/ties_$lib.txt 2>&1 || { tail -5 gpurun_out/s2/ties_$lib.txt; exit 1; }
   echo "== $lib"; grep -E "^revolution" gpurun_out/s2/ties_$lib.txt
