@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, session 2: Gauss-Newton solve in a launch of its own (tree) against the last-workgroup solve behind __threadfence (ab_tmp/gnfused.so)
+# alt library: bash tools/build_ab_lib.sh gnfused ransac.hip -DISR_GN_SPLIT_SOLVE=0
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2

@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, session 2: key ranges of the exact recheck by list length (tree) against always as many as the scratch holds (ab_tmp/rr_old.so)
+# alt library: bash tools/build_ab_lib.sh rr_old corr_argmax.hip -DISR_K1_RECHECK_UNITS=4000000000000
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4, session 2: what bounds corr_recheck_kernel on a long list — kernel table of tools/time_corr_ties.py, tree against the timing-only
 # build for three waves per SIMD (ab_tmp/rrw3.so)
+# alt library: bash tools/build_ab_lib.sh rrw3 corr_argmax.hip -DISR_K1_RECHECK_WAVES=3   (rr_noexact: -DISR_ABL_RECHECK_NOEXACT, timing only)
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2

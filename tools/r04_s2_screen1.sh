@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, session 2: the sum screen of K1's maxima — corr tests, then tree (screen) against ab_tmp/noscreen.so, alternated
+# alt library: bash tools/build_ab_lib.sh noscreen corr_argmax.hip -DISR_K1_SCREEN=0   (after the tree's build, on the build host)
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2

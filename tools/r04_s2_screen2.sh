@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, session 2: screen ablations (timing only) and the SQ counters of the screened kernel
+# alt libraries: bash tools/build_ab_lib.sh noscreen corr_argmax.hip -DISR_K1_SCREEN=0; abl_never: -DISR_ABL_SCREEN=1; abl_always: -DISR_ABL_SCREEN=2; abl_nomax: -DISR_ABL_DNOMAX
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2

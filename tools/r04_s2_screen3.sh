@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4, session 2: the screened K1 (plain and plane routes): corr tests, every route alone (tree against ab_tmp/noscreen.so,
 # alternated), the step with either library
+# alt library: bash tools/build_ab_lib.sh noscreen corr_argmax.hip -DISR_K1_SCREEN=0
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2

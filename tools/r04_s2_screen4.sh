@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 4, session 2: plane-route screen by plane count (tree: SP = 1, 8; ab_tmp/planes2.so: SP = 2 as well), the stress tools,
 # then the whole GPU suite on the tree's library
+# alt libraries: bash tools/build_ab_lib.sh planes2 corr_argmax.hip -DISR_K1_SCREEN_PLANES=0x106 (the shipped value since; the tree then had 0x102); noscreen: -DISR_K1_SCREEN=0
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2

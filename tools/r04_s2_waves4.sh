@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, session 2: plain-row K1 compiled for two waves per SIMD (ab_tmp/waves2.so) against three (tree)
+# alt library: bash tools/build_ab_lib.sh waves2 corr_argmax.hip -DISR_K1_PLAIN_WAVES=2   (waves4: =4)
 set -eo pipefail
 : "${GRAFT_REPO_ROOT:?run on the GPU box through gpurun (GRAFT_REPO_ROOT = the snapshot root)}"
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/s2
