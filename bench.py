@@ -111,6 +111,10 @@ def make_model(dev, N, D, tau=5.0, obj="tless"):
         keys_f32 = tau * k / k.norm(dim=1, keepdim=True)
     cloud = solid(rng, 4 * N)
     upper, lower = synth.split_halves(rng, cloud, N)
+    # the two halves are kept in Morton order (rows that are neighbours in space): a rigid motion keeps that locality, so the
+    # ICP's per-wave tile cull works on them as stored and the calls below pass spatial_order=False (no sort per step)
+    upper = upper[registration.morton_order(torch.from_numpy(upper)).numpy()]
+    lower = lower[registration.morton_order(torch.from_numpy(lower)).numpy()]
     cad = solid(rng, 5000)
     return keys_f32, torch.from_numpy(pts).to(dev), upper, lower, cad
 
@@ -423,7 +427,7 @@ def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower,
     pose = poses[best]
     src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)
     init = np.linalg.inv(np.vstack([pose, [0, 0, 0, 1]]))
-    T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init)
+    T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init, spatial_order=False)
     fc = registration.final_chamfer(src, lower, T, cad)
     Tr, rfit, rrmse, traj = ro.icp_point_to_point(src, lower, 20, init, search="f64")
     out["icp_rot_rad"] = synth.rot_angle(T[:3, :3], Tr[:3, :3])
@@ -598,7 +602,7 @@ def main():
                 pose = out["poses_all"][best].reshape(3, 4)
                 src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)   # icp.py:68
                 init = np.linalg.inv(np.vstack([pose, [0, 0, 0, 1]]))                               # icp.py:88-92
-                T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init)
+                T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init, spatial_order=False)
                 out.update(final_chamfer=registration.final_chamfer(src, lower, T, cad), icp_fitness=fit,
                            icp_rmse=rmse, rot_err_rad=synth.rot_angle(pose[:, :3], R_gt[best]),
                            trans_err_mm=float(np.linalg.norm(pose[:, 3] - t_gt[best])))

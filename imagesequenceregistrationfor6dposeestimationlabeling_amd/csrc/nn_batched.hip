@@ -46,6 +46,43 @@ __device__ __forceinline__ void xform64(const double* __restrict__ T, float x, f
 
 constexpr int kUnresolved = -2;   // part_idx of a query the grid search handed to the brute-force pass
 
+// Query r of a lane: a WAVE owns RQ x 64 consecutive queries (wave w of workgroup x: x RQ 256 + w RQ 64 .. + RQ 64), a lane's RQ
+// queries sit 64 apart.  Consecutive rows of a spatially ordered cloud (registration.icp_point_to_point sorts along a Morton
+// curve) are a compact patch, which is what the per-wave tile cull below lives on; loads stay coalesced (lane = fastest index).
+template <int RQ>
+__device__ __forceinline__ int query_of(int r) {
+  return (int)blockIdx.x * RQ * kThreads + ((int)threadIdx.x >> 6) * (RQ * 64) + r * 64 + ((int)threadIdx.x & 63);
+}
+
+// Axis-aligned boxes of the target cloud's 256-point tiles (untransformed frame), one workgroup per tile: {lo xyz, hi xyz}.
+__global__ __launch_bounds__(256) void tile_box_kernel(const float* __restrict__ tgt, int Nt, float* __restrict__ box) {
+  __shared__ float red[6][4];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  float v[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+  if (j < Nt) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) v[a] = v[3 + a] = tgt[3 * (size_t)j + a];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      v[a] = fminf(v[a], __shfl_xor(v[a], o, 64));
+      v[3 + a] = fmaxf(v[3 + a], __shfl_xor(v[3 + a], o, 64));
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) red[a][threadIdx.x >> 6] = v[a];
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int a = threadIdx.x;
+    const float r0 = red[a][0], r1 = red[a][1], r2 = red[a][2], r3 = red[a][3];
+    box[6 * (size_t)blockIdx.x + a] = a < 3 ? fminf(fminf(r0, r1), fminf(r2, r3)) : fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+  }
+}
+
 // FILTER = false: the plain loop — per pair the difference form d2 = fmaf(dz,dz,fmaf(dy,dy,dx*dx)) (6 VALU ops), a min3
 // tree per group of 8 targets, the (value, index) update in a wave-uniform slow path.
 // FILTER = true: the search runs on the 3-FMA form  s = |t|^2 - 2 q.t  (= d2 - |q|^2 up to rounding: half the VALU work of the
@@ -82,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     float* __restrict__ part_d2, int32_t* __restrict__ part_idx, const int32_t* __restrict__ skip,
     const int32_t* __restrict__ unresolved, unsigned long long* __restrict__ packed = nullptr,
     const int32_t* __restrict__ warm = nullptr, int32_t* __restrict__ amb = nullptr,
-    const float* __restrict__ t2_bound = nullptr) {
+    const float* __restrict__ t2_bound = nullptr, const float* __restrict__ tile_box = nullptr, float cull_r2 = 0.f) {
   __shared__ __attribute__((aligned(16))) float lds[2][FILTER ? 4 : 3][kTile];   // FILTER: -2x, -2y, -2z, |t|^2; else x, y, z
   __shared__ float tile_t2[2][kThreads / 64];                       // largest |t|^2 of a tile, per staging wave
   if (skip && *skip) return;  // device-side ICP loop: converged, later iterations are no-ops
@@ -95,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     int mine = 0;
 #pragma unroll
     for (int r = 0; r < RQ; ++r) {
-      const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+      const int qi = query_of<RQ>(r);
       if (qi < Nq) mine |= part_idx[((size_t)b * nsplit + split) * Nq + qi] == kUnresolved;
     }
     if (!__syncthreads_or(mine)) return;
@@ -116,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
   };
 #pragma unroll
   for (int r = 0; r < RQ; ++r) {
-    int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+    int qi = query_of<RQ>(r);
     qi = qi < Nq ? qi : Nq - 1;  // clamp: out-of-range lanes compute a valid query, never store
     double x, y, z;
     xform64(tq, qry[3 * (size_t)qi], qry[3 * (size_t)qi + 1], qry[3 * (size_t)qi + 2], x, y, z);
@@ -144,6 +181,57 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
   const int t1 = min(Nt, t0 + split_len);
   const int ntiles = (t1 - t0 + kTile - 1) / kTile;
   constexpr float kU = 5.9604645e-8f;    // 2^-24
+
+  // Per-wave tile cull (tile_box != nullptr: the ICP loop; targets untransformed).  A lane needs a target only if its f32
+  // squared distance can reach the lane's bound — the warm neighbour's distance under the new transform (widened for near
+  // ties when EXACT), capped by the radius beyond which nothing is a correspondence (cull_r2 > 0): a target farther than
+  // that changes no output of the loop (a point whose neighbour lies beyond the radius contributes nothing, found or not).
+  // The wave's bound is the largest of its lanes'; a tile whose box lies farther from the wave's query box than that, with
+  // 1e-4 relative + 1e-4 absolute to spare (f32 roundings of the boxes, of the distance, of the bound: < 1e-5), holds
+  // nothing any lane needs, and the wave skips its compute; a workgroup whose one tile every wave skips leaves at once.
+  float wlo[3], whi[3], wb = __builtin_inff();
+  if (tile_box) {
+    float b = 0.f;
+    wlo[0] = wlo[1] = wlo[2] = 3.0e38f; whi[0] = whi[1] = whi[2] = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) {
+      float br = EXACT ? thx[r] : best[r];
+      if (cull_r2 > 0.f) br = fminf(br, cull_r2);
+      b = fmaxf(b, br);
+      wlo[0] = fminf(wlo[0], qx[r]); wlo[1] = fminf(wlo[1], qy[r]); wlo[2] = fminf(wlo[2], qz[r]);
+      whi[0] = fmaxf(whi[0], qx[r]); whi[1] = fmaxf(whi[1], qy[r]); whi[2] = fmaxf(whi[2], qz[r]);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      b = fmaxf(b, __shfl_xor(b, o, 64));
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        wlo[a] = fminf(wlo[a], __shfl_xor(wlo[a], o, 64));
+        whi[a] = fmaxf(whi[a], __shfl_xor(whi[a], o, 64));
+      }
+    }
+    // wave-wide values: parked in scalar registers (seven SGPRs instead of seven VGPRs through the loop)
+    wb = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(__builtin_fmaf(b, 1.0001f, 1.0e-4f))));
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      wlo[a] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(wlo[a])));
+      whi[a] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(whi[a])));
+    }
+  }
+  auto tile_culled = [&](int tile) {   // wave-uniform
+    if (!tile_box) return false;
+    const float* bx = tile_box + 6 * (size_t)(t0 / kTile + tile);
+    float d2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float g = fmaxf(0.f, fmaxf(wlo[a] - bx[3 + a], bx[a] - whi[a]));
+      d2 = __builtin_fmaf(g, g, d2);
+    }
+    return d2 > wb;
+  };
+  if (tile_box && ntiles == 1) {
+    if (!__syncthreads_or(tile_culled(0) ? 0 : 1)) return;   // block-uniform: nobody posts (no lane's neighbour can sit in this tile)
+  }
 
   auto stage = [&](int tile, int buf) {
     const int j = t0 + tile * kTile + tid;
@@ -185,6 +273,12 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     const int buf = tile & 1;
     if (tile + 1 < ntiles) stage(tile + 1, buf ^ 1);
     const int jbase = t0 + tile * kTile;
+    // (scalar by construction — every input is a wave reduction — and told so, lest the branch be laid out with the barrier
+    // on both of its sides under an execution mask)
+    if (__builtin_amdgcn_readfirstlane(tile_culled(tile) ? 1 : 0) != 0) {   // the wave still takes part in the staging and its barrier
+      __syncthreads();
+      continue;
+    }
     if (!FILTER) {
 #pragma unroll 2
       for (int g = 0; g < kTile; g += kGroup) {
@@ -304,7 +398,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     bool posted[RQ];
 #pragma unroll
     for (int r = 0; r < RQ; ++r) {
-      const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+      const int qi = query_of<RQ>(r);
       const bool own = widx[r] < 0 || bidx[r] != widx[r] || (widx[r] >= t0 && widx[r] < t1);
       posted[r] = qi < Nq && bidx[r] >= 0 && own;
       old[r] = ~0ull;
@@ -317,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     if (EXACT) {
 #pragma unroll
       for (int r = 0; r < RQ; ++r) {
-        const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+        const int qi = query_of<RQ>(r);
         // the value this one displaced, or failed to displace, is another target split's winner: a near tie between
         // the two is a near tie of the query (every pair of posting splits meets here through the slot's history)
         const float od = __uint_as_float((unsigned int)(old[r] >> 32));
@@ -330,7 +424,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
   }
 #pragma unroll
   for (int r = 0; r < RQ; ++r) {
-    const int qi = (blockIdx.x * RQ + r) * kThreads + tid;
+    const int qi = query_of<RQ>(r);
     if (qi < Nq) {
       const size_t o = ((size_t)b * nsplit + split) * Nq + qi;
       if (unresolved && part_idx[o] != kUnresolved) continue;
@@ -805,7 +899,7 @@ constexpr int kFilterMinTiles = 4;
 void launch_search(const NNPlan& p, const dim3& grid, hipStream_t stream, const float* qry, int Nq, const float* tgt, int Nt,
                    const double* tq, const double* tt, float* part_d2, int32_t* part_idx, const int32_t* skip,
                    const int32_t* unresolved, unsigned long long* packed, const int32_t* warm, int32_t* amb = nullptr,
-                   const float* t2_bound = nullptr) {
+                   const float* t2_bound = nullptr, const float* tile_box = nullptr, float cull_r2 = 0.f) {
   bool filter = warm != nullptr || p.split_len >= kFilterMinTiles * kTile;
   // tuning hook (experiments only) for cold searches; a warm start always takes the filter loop (its tie rule —
   // equal distance, lower index — is what makes a warm-started lane return the cold winner)
@@ -815,7 +909,7 @@ void launch_search(const NNPlan& p, const dim3& grid, hipStream_t stream, const 
                                                            skip, unresolved, packed, warm)
 #define ISR_SEARCH_X(RQv, Fv)                                                                                            \
   nn_search_kernel<RQv, Fv, true><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len, p.nsplit, part_d2, \
-                                                                 part_idx, skip, unresolved, packed, warm, amb, t2_bound)
+                                                                 part_idx, skip, unresolved, packed, warm, amb, t2_bound, tile_box, cull_r2)
   if (amb) {       // the ICP loop: near ties are flagged for the exact decision (packed slots, no target transform)
     if (p.rq == 4) { if (filter) ISR_SEARCH_X(4, true); else ISR_SEARCH_X(4, false); }
     else { if (filter) ISR_SEARCH_X(1, true); else ISR_SEARCH_X(1, false); }
@@ -926,7 +1020,7 @@ extern "C" size_t isr_icp_workspace_bytes(int Ns, int Nt) {
   if (Ns <= 0 || Nt <= 0) return 0;
   const NNPlan p = make_plan(Ns, Nt, 1, true);
   return isr::align_up((size_t)p.fblocks * kNV * sizeof(double), 256) + isr::align_up((size_t)Ns * 8, 256) +
-         2 * isr::align_up((size_t)Ns * 4, 256) + 2048;
+         2 * isr::align_up((size_t)Ns * 4, 256) + isr::align_up((size_t)((Nt + kTile - 1) / kTile) * 6 * sizeof(float), 256) + 2048;
 }
 
 extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt, int Nt, double threshold,
@@ -950,9 +1044,19 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
   int32_t* prev_idx = w.take<int32_t>(Ns);
   int32_t* amb = w.take<int32_t>(Ns);
   float* t2_bound = w.take<float>(1);
+  float* tile_box = w.take<float>((size_t)((Nt + kTile - 1) / kTile) * 6);
   const bool warm = isr::tuning(ISR_TUNE_ICP_WARM) != 0;          // tuning knob: 0 keeps every pass on the cold kernel
   icp_init_kernel<<<(Ns + kThreads - 1) / kThreads, kThreads, 0, stream>>>(st, T_io, packed, amb, Ns);
   cloud_r2max_kernel<<<1, kThreads, 0, stream>>>(tgt, Nt, t2_bound);
+  // per-wave tile cull of the searches (nn_search_kernel): boxes of the target's 256-point tiles, once per call; the radius
+  // caps every lane's bound (f32, rounded up: the finalize's f64 test s2 <= threshold^2 decides what counts).  Pays when the
+  // clouds' rows are spatially ordered (registration.icp_point_to_point sorts them); otherwise every box is the whole cloud
+  // and nothing is skipped.
+#ifndef ISR_ICP_CULL
+#define ISR_ICP_CULL 1
+#endif
+  const float cull_r2 = (float)(threshold * threshold * 1.0001 + 1e-6);
+  if (ISR_ICP_CULL) tile_box_kernel<<<(Nt + kTile - 1) / kTile, 256, 0, stream>>>(tgt, Nt, tile_box);
   const dim3 grid(p.qblocks, p.nsplit, 1);
   for (int it = 0; it <= max_iter; ++it) {
     // two launches per pass: search with one packed atomic min per (point, target split), then the
@@ -960,7 +1064,7 @@ extern "C" int isr_icp_point_to_point(const float* src, int Ns, const float* tgt
     // (from the second pass on: the warm-started filter search, bounded by the previous pass's neighbour)
     const int32_t* w_idx = (it > 0 && warm) ? prev_idx : nullptr;
     launch_search(p, grid, stream, src, Ns, tgt, Nt, T_io, nullptr, nullptr, nullptr, &st->done, nullptr, packed, w_idx, amb,
-                  t2_bound);
+                  t2_bound, ISR_ICP_CULL ? tile_box : nullptr, cull_r2);
     icp_finalize_update_kernel<<<p.fblocks, kThreads, 0, stream>>>(src, Ns, tgt, Nt, threshold, packed, prev_idx, amb, part_sums,
                                                                    max_iter, rel_fitness, rel_rmse, T_io, st, result);
   }
