@@ -147,3 +147,34 @@ def test_icp_and_final_chamfer(reg, ro):
     # ICP lowered its own objective (the inlier rmse); with half-overlapping clouds and the
     # reference's threshold of 20 it need not lower the Chamfer distance to the CAD model.
     assert rmse <= r + 1e-9
+
+
+@pytest.mark.parametrize("N,threshold", [(20000, 20.0), (20000, 3.0), (3000, 8.0), (700, 1.5)])
+def test_icp_tile_cull_and_row_order(reg, ro, N, threshold):
+    """The ICP searches skip, wave by wave, the target tiles beyond the wave's bound and beyond the radius (nn_search_kernel),
+    which works on rows kept in Morton order (registration.morton_order, the default of icp_point_to_point).  The result does
+    not depend on the order of the rows beyond the last bits of the f64 sums, whatever the radius leaves without a
+    correspondence (small thresholds: most points have none, their waves are bounded by the radius alone), and equals the
+    oracle's exact-neighbour loop."""
+    rng = np.random.default_rng(N + int(10 * threshold))
+    cloud = synth.tless_like(rng, 4 * N)
+    upper, lower = synth.split_halves(rng, cloud, N)
+    Rg, tg = synth.random_poses(rng, 1)
+    Rp, tp = synth.perturb_pose(rng, Rg[0], tg[0], 0.02, 0.1)
+    src = (upper.astype(np.float64) @ Rg[0].T + tg[0]).astype(np.float32)
+    init = np.linalg.inv(np.vstack([np.hstack([Rp, tp[:, None]]), [0, 0, 0, 1]]))
+    T, fit, rmse = reg.icp_point_to_point(src, lower, threshold, init)                          # Morton-ordered rows
+    Tu, fu, ru = reg.icp_point_to_point(src, lower, threshold, init, spatial_order=False)       # rows as given
+    perm = rng.permutation(N)
+    Tp, fp, rp = reg.icp_point_to_point(src[perm], lower[rng.permutation(N)], threshold, init, spatial_order=False)
+    for (Ta, fa, ra) in ((Tu, fu, ru), (Tp, fp, rp)):
+        assert fa == fit                                     # the same correspondences counted
+        assert np.abs(Ta - T).max() < 1e-10 and abs(ra - rmse) < 1e-10
+    Tr, rfit, rrmse, _ = ro.icp_point_to_point(src, lower, threshold, init, search="f64")
+    assert synth.rot_angle(T[:3, :3], Tr[:3, :3]) < 1e-9 and np.linalg.norm(T[:3, 3] - Tr[:3, 3]) < 1e-6
+    assert abs(fit - rfit) < 1e-12 and abs(rmse - rrmse) < 1e-9
+    # the permutation really is one, and it is a locality-preserving one
+    o = reg.morton_order(torch.from_numpy(lower)).numpy()
+    assert np.array_equal(np.sort(o), np.arange(N))
+    step = lambda p: np.linalg.norm(np.diff(p, axis=0), axis=1).mean()
+    assert step(lower[o]) < 0.5 * step(lower)
