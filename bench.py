@@ -80,6 +80,7 @@ def parse_args():
                     help="RANSAC confidence (cv2.solvePnPRansac's parameter; its default 0.99 is what the reference's "
                          "call uses); 1 scores every hypothesis")
     ap.add_argument("--ablate", default="", help="debug only (not a valid bench line): 'noverify' skips a13-a15")
+    ap.add_argument("--tune", default="", help="debug only (not a valid bench line): library knobs, e.g. 'nn_plan_rq=1,icp_warm=0' (ops.set_tuning)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg")
     ap.add_argument("--verify", choices=("pick", "vote"), default="pick",
                     help="verification stage: 'pick' = consecutive-pair Chamfer pick (verfication.py:61-108, the headline); "
@@ -526,6 +527,8 @@ def main():
 
     P, N, D = args.width * args.height, args.keys, args.dim
     n_local, n_total = args.images, args.images * world
+    if args.tune:
+        ops.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
     Kcam = synth.camera(args.width, args.height)
     keys_f32, pts, upper, lower, cad = make_model(dev, N, D, args.tau, args.object)
     keys = keys_f32.bfloat16().contiguous()

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void tile_box_kernel(const float* __restrict__
 // winner that displaces a near-tied predecessor raises the flag too, and so does the packed atomicMin when the value
 // it displaces (or fails to displace) — another target split's winner — is a near tie.  Cost in the fast path: none
 // (the comparisons are against thx instead of best).  On 20 000-point clouds one or two queries per pass are flagged.
-template <int RQ, bool FILTER, bool EXACT = false>
+template <int RQ, bool FILTER, bool EXACT = false, bool CULL = false>
 __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     const float* __restrict__ qry, int Nq, const float* __restrict__ tgt, int Nt,
     const double* __restrict__ Tq, const double* __restrict__ Tt, int split_len, int nsplit,
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
   // 1e-4 relative + 1e-4 absolute to spare (f32 roundings of the boxes, of the distance, of the bound: < 1e-5), holds
   // nothing any lane needs, and the wave skips its compute; a workgroup whose one tile every wave skips leaves at once.
   float wlo[3], whi[3], wb = __builtin_inff();
-  if (tile_box) {
+  if (CULL && tile_box) {
     float b = 0.f;
     wlo[0] = wlo[1] = wlo[2] = 3.0e38f; whi[0] = whi[1] = whi[2] = -3.0e38f;
 #pragma unroll
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     }
   }
   auto tile_culled = [&](int tile) {   // wave-uniform
-    if (!tile_box) return false;
+    if (!CULL || !tile_box) return false;
     const float* bx = tile_box + 6 * (size_t)(t0 / kTile + tile);
     float d2 = 0.f;
 #pragma unroll
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(kThreads) void nn_search_kernel(
     }
     return d2 > wb;
   };
-  if (tile_box && ntiles == 1) {
+  if (CULL && tile_box && ntiles == 1) {
     if (!__syncthreads_or(tile_culled(0) ? 0 : 1)) return;   // block-uniform: nobody posts (no lane's neighbour can sit in this tile)
   }
 
@@ -907,9 +907,12 @@ void launch_search(const NNPlan& p, const dim3& grid, hipStream_t stream, const 
 #define ISR_SEARCH(RQv, Fv)                                                                                              \
   nn_search_kernel<RQv, Fv><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len, p.nsplit, part_d2, part_idx, \
                                                            skip, unresolved, packed, warm)
+  // (the tile cull is compiled into the warm-started filter kernel only: in the cold plain loop its state took the kernel from
+  // 167 to 191 registers — and beside K1, whose three waves per SIMD hold 504 of the 512, a wave that needs more than one K1
+  // wave's 168 waits for two of them to leave: the ICP's first pass went from 0.8 to 6.7 ms inside the step)
 #define ISR_SEARCH_X(RQv, Fv)                                                                                            \
-  nn_search_kernel<RQv, Fv, true><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len, p.nsplit, part_d2, \
-                                                                 part_idx, skip, unresolved, packed, warm, amb, t2_bound, tile_box, cull_r2)
+  nn_search_kernel<RQv, Fv, true, Fv><<<grid, kThreads, 0, stream>>>(qry, Nq, tgt, Nt, tq, tt, p.split_len, p.nsplit, part_d2, \
+                                                                     part_idx, skip, unresolved, packed, warm, amb, t2_bound, tile_box, cull_r2)
   if (amb) {       // the ICP loop: near ties are flagged for the exact decision (packed slots, no target transform)
     if (p.rq == 4) { if (filter) ISR_SEARCH_X(4, true); else ISR_SEARCH_X(4, false); }
     else { if (filter) ISR_SEARCH_X(1, true); else ISR_SEARCH_X(1, false); }
