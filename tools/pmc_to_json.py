@@ -26,7 +26,7 @@ def hbm(c, frag):
             "tcc_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
 
 
-src = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, separate passes (tools/pmc_all.sh), round 3 kernels"
+src = "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum, separate passes (tools/pmc_all.sh), round 4 kernels (second half)"
 k1 = {"kernel": "corr_bf16_direct_kernel<4,2,false> (K1, ISR_DTYPE_BF16_LOG2) + its finalize / recheck passes, N=20000 D=64 bf16",
       "correction": "gfx950: read bytes = 2 x FETCH_SIZE (128-B requests tallied at 64 B), WRITE_SIZE exact, both in KiB",
       "per_launch": {}}
