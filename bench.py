@@ -338,6 +338,12 @@ def measure_k1_f32(Q_img, keys_f32, dev, log2_domain):
             "logp_max_abs_diff_vs_chain": float((out[1] - out_chain[1]).abs().max())}
 
 
+def rank_command(n: int, port: int, argv: list) -> list:
+    """The child command of a plain `python bench.py --gpus N`: the driver's own launch line (one rank per GPU of one node)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+
+
 def spawn_ranks(n: int) -> int:
     """`python bench.py --gpus N` started plainly: run the N ranks as CHILD processes under
     torch.distributed.run (one per GPU) and relay their output.  Nothing in this process has touched the
@@ -347,8 +353,7 @@ def spawn_ranks(n: int) -> int:
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    cmd = rank_command(n, port, sys.argv[1:])
     print("bench.py: launching " + " ".join(cmd), file=sys.stderr, flush=True)
     return subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")).returncode
 

@@ -24,7 +24,7 @@ DTYPE_F32 = 1
 DTYPE_BF16_LOG2 = 2
 # ISR_TUNE_* knobs of include/isr_hip.h
 TUNE = {"nn_path": 0, "nn_filter": 1, "icp_warm": 2, "nn_plan_rq": 3, "nn_plan_blocks": 4,
-        "nn_tile_st": 5, "nn_tile_sq": 6, "nn_tile_tb": 7, "ep_wsum_valu": 8, "k1_f32_chain": 9, "k1_split": 10}
+        "nn_tile_st": 5, "nn_tile_sq": 6, "nn_tile_tb": 7, "ep_wsum_valu": 8, "k1_f32_chain": 9, "k1_split": 10, "k1_skip": 11}
 
 
 class IsrError(RuntimeError):

@@ -12,6 +12,11 @@
 // isr_nn_batched, everything else is decided here — the same booleans as evaluating every item (tests compare the error
 // matrices), at ~40 VALU operations and one 4-byte gather per vertex instead of a nearest-neighbour search.
 //
+// Tt need not be exactly orthonormal (the reference loads f32-born poses from pred_R.npy): with A its 3 x 3 part and
+// eta >= ||A^T A - I||_2,  | |A^T w - s| - |w - A s| | <= eta (|s| + |w - A s|)  for every surface point s, so each vertex's
+// bracket is widened by eta (max|s| + its upper bound) — 1e-5 mm at eta = 1e-7 and object scale, nothing for f64 rotations;
+// a Tt that is far from rigid only makes the brackets useless (everything is searched), never wrong.
+//
 // The field is built once per surface cloud by the caller (cell centres through isr_nn_batched: exact distances).
 #include "isr_common.hpp"
 
@@ -25,14 +30,21 @@ __global__ __launch_bounds__(kBThreads) void adds_bounds_kernel(const float* __r
                                                                 int nz, float b0, float b1, float b2, float b3, float b4, float b5,
                                                                 double* __restrict__ lb_sum, double* __restrict__ ub_sum) {
   __shared__ float E[12];
+  __shared__ double eta_s;
   __shared__ double red[2][kBThreads / 64];
   const int b = blockIdx.x;
   if (threadIdx.x == 0) {
     // E = Tt^-1 Tq in f64 (Tt rigid: R^T, -R^T t), handed to the lanes as f32: the vertices live at object scale
     const double* q = Tq + 12 * (size_t)b;
     double R[9], t[3];
+    eta_s = 0.0;
     if (Tt) {
       const double* p = Tt + 12 * (size_t)b;
+      double g = 0.0;                                   // max |(A^T A - I)_ij|; ||.||_2 <= ||.||_F <= 3 max
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+          g = fmax(g, fabs(p[i] * p[j] + p[4 + i] * p[4 + j] + p[8 + i] * p[8 + j] - (i == j ? 1.0 : 0.0)));
+      eta_s = 3.0 * g;
       for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) R[3 * i + j] = p[i] * q[j] + p[4 + i] * q[4 + j] + p[8 + i] * q[8 + j];
         t[i] = p[i] * (q[3] - p[3]) + p[4 + i] * (q[7] - p[7]) + p[8 + i] * (q[11] - p[11]);
@@ -69,8 +81,12 @@ __global__ __launch_bounds__(kBThreads) void adds_bounds_kernel(const float* __r
   if (threadIdx.x == 0) {
     double l = 0.0, u = 0.0;
     for (int w = 0; w < kBThreads / 64; ++w) { l += red[0][w]; u += red[1][w]; }
-    lb_sum[b] = l;
-    ub_sum[b] = u;
+    // a Tt that is not exactly orthonormal: widen by eta (V max|s| + sum of the upper bounds); max|s| from the surface's box
+    const double sx = fmax(fabs((double)b0), fabs((double)b3)), sy = fmax(fabs((double)b1), fabs((double)b4)),
+                 sz = fmax(fabs((double)b2), fabs((double)b5));
+    const double widen = eta_s * ((double)V * sqrt(sx * sx + sy * sy + sz * sz) + u) * 1.01;
+    lb_sum[b] = l - widen;
+    ub_sum[b] = u + widen;
   }
 }
 

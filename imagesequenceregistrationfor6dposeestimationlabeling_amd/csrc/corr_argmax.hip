@@ -73,6 +73,10 @@ struct CorrWs {
   // its split kernel), in which case the f32-MFMA chain kernels behind it run instead (`only`): no host round trip decides.
   const int32_t* skip;   // leave at once when *skip != 0
   const int32_t* only;   // leave at once when *only == 0
+  // tile skip (SKIP instantiations of the direct kernel): per query a LOWER bound of its maximum logit (raw units), or null
+  const float* lower;
+  float* lowbuf;         // (P) where the call's own pre-pass leaves those bounds
+  float skip_default;    // the threshold when `lower` is null (experiments: +inf skips every tile, -inf none)
 };
 
 __device__ __forceinline__ bool gated_off(const CorrWs& ws) {
@@ -953,6 +957,18 @@ __global__ __launch_bounds__(256) void corr_recheck_merge_kernel(int P, int N, i
   }
 }
 
+// EXPERIMENT: lower[q] = <q, k[hint[q]]> (f32 fma chain over the bf16 rows) - a little: a lower bound of the query's maximum
+__global__ __launch_bounds__(256) void corr_lower_from_hint_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int D,
+                                                                   int ldq, int ldk, const int32_t* __restrict__ hint, float* __restrict__ lower) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= P) return;
+  const uint16_t* qr = Q + (size_t)q * ldq;
+  const uint16_t* kr = K + (size_t)hint[q] * ldk;
+  float acc = 0.f;
+  for (int d = 0; d < D; ++d) acc = __builtin_fmaf(__uint_as_float((uint32_t)qr[d] << 16), __uint_as_float((uint32_t)kr[d] << 16), acc);
+  lower[q] = acc - 1e-3f * fabsf(acc);
+}
+
 // ------------------------------------------------------------------------------------ plan
 constexpr int kMaxSplit = 64;     // upper bound on key ranges per launch
 constexpr int kSlotCap = 2048;    // device-independent cap on the resident-workgroup estimate
@@ -1092,8 +1108,11 @@ size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   o->rlist = bf16 ? w.take<int32_t>(P) : nullptr;
   o->rval = bf16 ? w.take<double>((size_t)rs * P) : nullptr;
   o->ridx = bf16 ? w.take<int32_t>((size_t)rs * P) : nullptr;
+  o->lowbuf = bf16 ? w.take<float>(P) : nullptr;
   o->skip = nullptr;
   o->only = nullptr;
+  o->lower = nullptr;
+  o->skip_default = -__builtin_inff();
   return w.off;
 }
 
@@ -1315,6 +1334,22 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     corr_bf16_kernel<8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
     corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
     if (!lse_only) corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
+  } else
+  if (D == 64 && log2 && !lse_only && isr::tuning(ISR_TUNE_K1_SKIP) != 0) {     // EXPERIMENT: the tile-skip kernel
+    const int mode = isr::tuning(ISR_TUNE_K1_SKIP);
+    CorrWs w2 = ws;
+    if (mode == 1) w2.skip_default = __builtin_inff();
+    if (mode == 3) {         // bounds from the shipped kernel's own winners (timing experiment)
+      ISR_LAUNCH_BF16(4);
+      corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, N, p.rsplit, ws, idx);
+      corr_lower_from_hint_kernel<<<(P + 255) / 256, 256, 0, stream>>>(q, k, P, D, ldq, ldk, idx, ws.lowbuf);
+      corr_keynorm_kernel<false><<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, kn_inflate, ws);     // (zeroes the counters again)
+      w2.lower = ws.lowbuf;
+    }
+    corr_bf16_direct_kernel<4, kQB, false, 4, 0, false, false, 1><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, w2, idx, logp, lse);
+    corr_bf16_kernel<4, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, w2);
+    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, w2, idx, logp, lse);
+    corr_recheck_kernel<4><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, w2);
   } else
   switch (D) {
     case 16: ISR_LAUNCH_BF16(1); break;

@@ -28,6 +28,12 @@
 // The runner-up bounds the top-2 margin; corr_finalize_kernel sends queries whose margin is inside
 // the f32 accumulation error bound to corr_recheck_kernel, which decides them in exact arithmetic.
 constexpr float kLow = -100.f;     // log2 units: a maximum below this sends the query to the fallback
+// The range tests below are written `!(x >= kLow)` / `!(lc <= 3.0e38f)`.  This file is compiled with -fno-honor-nans
+// (build.py), under which the compiler may read them as `x < kLow` / `lc > 3.0e38f`: that is all they have to catch — a
+// maximum of -inf (no key), an overflowed sum (+inf).  A NaN cannot arise from FINITE descriptors (no inf - inf, no 0 x inf:
+// products of finite bf16 / f16 values are finite in f32 and the sums' only non-finite value is +inf); finite descriptors
+// are a stated precondition of K1, and nothing here relies on a NaN taking either branch.
+constexpr float kSkipT = 42.f;     // log2 units: a tile whose maximum lies this far below a lower bound of the query's maximum adds nothing to an f32 sum
 
 struct DirectState {
   float m;   // largest tile maximum so far (raw logit)
@@ -79,7 +85,7 @@ extern __shared__ uint4 corr_direct_dyn_lds[];
 #ifndef ISR_K1_PLAIN_WAVES
 #define ISR_K1_PLAIN_WAVES 3      // waves per SIMD the plain-row kernels (D <= 64) are compiled for
 #endif
-template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0, bool F16 = false, bool LSE = false>
+template <int DK, int QB, bool NAT, int DKU = DK, int SP = 0, bool F16 = false, bool LSE = false, int SKIP = 0>
 __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES : (DK <= 4 ? 3 : (SP >= 8 ? 1 : 2))) void corr_bf16_direct_kernel(
     const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int N, int ldq, int ldk,
     int range_chunks, CorrWs ws, int32_t* __restrict__ idx_out, float* __restrict__ logp_out,
@@ -219,6 +225,11 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
 #else
     st[qb].thr = 0.f;
 #endif
+    if constexpr (SKIP != 0) {
+      // the tile-skip threshold: (a lower bound of the query's maximum) - kSkipT, raw logit units
+      const int q = min(q0 + qb * 32 + r, P - 1);
+      st[qb].thr = ws.lower ? ws.lower[q] - kSkipT * (NAT ? 0.6931471805599453f : 1.f) : ws.skip_default;
+    }
   }
   // the screen's distance below the maximum, in raw logit units: 2 eps of corr_finish (same |q|^2, same max |k|^2) inflated by
   // 1 %, plus 1e-4 for v_exp_f32 (1 ulp), the 15 additions of ts and the rounding of M - dlt (|M| < 128: 8e-6)
@@ -500,6 +511,28 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
           if (w == NW - 2) { if (has_next) load_a(buf ^ 1, 0); }
           else load_a(buf, sub + 1);
         }
+        if constexpr (SKIP != 0) {
+          // EXPERIMENT (tile skip): the tile's maximum first; its 16 exponentials only when some lane's maximum reaches its
+          // query's threshold (wave-uniform branch), each lane adding its own tile sum only when ITS maximum does
+          float t = tile_max(cur);
+          constexpr int GS = (9 + NMF - 1) / NMF;
+#pragma unroll
+          for (int s = 0; s < NMF; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (qb == 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, GS, 0);
+          }
+          asm volatile("" : "+v"(nxt), "+v"(t));
+          if (__builtin_expect(__builtin_amdgcn_ballot_w64(t >= st[qb].thr) != 0ull, 0)) {   // wave-uniform
+            float ts = __builtin_amdgcn_exp2f(NAT ? cur[0] * kLog2e : cur[0]);
+#pragma unroll
+            for (int i = 1; i < 16; ++i) ts += __builtin_amdgcn_exp2f(NAT ? cur[i] * kLog2e : cur[i]);
+            st[qb].l += (t >= st[qb].thr) ? ts : 0.f;
+            st[qb].m2 = __builtin_amdgcn_fmed3f(st[qb].m, st[qb].m2, t);
+            st[qb].tb = (t > st[qb].m) ? kb : st[qb].tb;
+            st[qb].m = fmaxf(st[qb].m, t);
+          }
+        } else {
 #if ISR_K1_SCREEN
         // the tile's own sum first (the canonical order of a chunk sum: tile sums in register order, added tile after tile)
         // DK = 1 (one matrix instruction per tile: the item is all VALU): four interleaved partial sums (registers i, i + 4,
@@ -587,6 +620,7 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
         }
         asm volatile("" : "+v"(nxt), "+v"(st[qb].l), "+v"(st[qb].m), "+v"(st[qb].m2), "+v"(st[qb].tb));
 #endif
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }

@@ -132,11 +132,24 @@ int ranges_for(int P, int N) {
   return nr < 1 ? 1 : nr;
 }
 
+// the key ranges a call uses: `per` keys each (whole tiles), `nru` of them hold a key — the one place the workspace size and
+// the launch take it from (round 4 reserved kTopMaxRanges lists per query whatever the shape: 1.26 GB at 640 x 480 queries,
+// of which one range's 20 MB was used)
+struct TopRanges { int per, nru; };
+TopRanges top_ranges(int P, int N) {
+  const int nr = ranges_for(P, N);
+  const int tiles = (N + kTopTile - 1) / kTopTile;
+  TopRanges t;
+  t.per = (tiles + nr - 1) / nr * kTopTile;
+  t.nru = (N + t.per - 1) / t.per;
+  return t;
+}
+
 }  // namespace
 
 extern "C" size_t isr_corr_topk_workspace_bytes(int P, int N) {
   if (P <= 0 || N <= 0) return 0;
-  return (size_t)kTopMaxRanges * P * kTopK * (sizeof(float) + sizeof(int32_t)) + 1024;
+  return (size_t)top_ranges(P, N).nru * P * kTopK * (sizeof(float) + sizeof(int32_t)) + 1024;
 }
 
 extern "C" int isr_corr_topk(const float* Q, const float* K, int P, int N, int D, int ldq, int ldk, int k, const float* lse,
@@ -151,12 +164,10 @@ extern "C" int isr_corr_topk(const float* Q, const float* K, int P, int N, int D
   }
   hipStream_t stream = isr::as_stream(stream_);
   isr::Workspace w(ws_, ws_bytes);
-  float* pv = w.take<float>((size_t)kTopMaxRanges * P * kTopK);
-  int32_t* pi = w.take<int32_t>((size_t)kTopMaxRanges * P * kTopK);
-  const int nr = ranges_for(P, N);
-  const int tiles = (N + kTopTile - 1) / kTopTile;
-  const int per = (tiles + nr - 1) / nr * kTopTile;                  // keys per range: whole tiles
-  const int nru = (N + per - 1) / per;                               // ranges that hold a key
+  const TopRanges tr = top_ranges(P, N);
+  const int per = tr.per, nru = tr.nru;                              // keys per range (whole tiles), ranges that hold a key
+  float* pv = w.take<float>((size_t)nru * P * kTopK);
+  int32_t* pi = w.take<int32_t>((size_t)nru * P * kTopK);
   const dim3 grid((P + kTopThreads - 1) / kTopThreads, nru);
   if (D <= 16) corr_topk_kernel<16><<<grid, kTopThreads, 0, stream>>>(Q, K, P, N, D, ldq, ldk, per, pv, pi);
   else if (D <= 32) corr_topk_kernel<32><<<grid, kTopThreads, 0, stream>>>(Q, K, P, N, D, ldq, ldk, per, pv, pi);

@@ -272,8 +272,10 @@ __device__ __forceinline__ float block_reduce_max(float v, float* red) {   // re
   return m;
 }
 
+// (no occupancy promise in the launch bounds: the compiler reports 3 waves per SIMD at TB = 256 and 5 at TB = 64 — the tile arrays
+// and the per-lane candidate state — and a second argument it cannot meet only earns a warning)
 template <int TB>
-__global__ __launch_bounds__(TB, 8) void nn_tile_search_kernel(
+__global__ __launch_bounds__(TB) void nn_tile_search_kernel(
     const float4* __restrict__ qsorted, const QBlock* __restrict__ qtable, const GridDesc* __restrict__ gq,
     const int32_t* __restrict__ qbstart, int Nq, const GridDesc* __restrict__ g, const int32_t* __restrict__ start,
     const float4* __restrict__ sorted, int Nt, const double* __restrict__ Tq, const double* __restrict__ Tt, int nb,

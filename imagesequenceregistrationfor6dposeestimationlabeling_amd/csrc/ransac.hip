@@ -308,8 +308,8 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
       const float lim = reperr * z;
       c_wave += __popcll(__ballot(z > 0.0f) & __ballot(e2 <= lim * lim) & vmask[c]);
     }
-    // gfx9 allows one SGPR per VALU instruction on the constant bus: the lane select travels in M0
-    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(cntv) : "s"(c_wave), "s"(h - h0) : "m0");
+    // v_writelane_b32 is exempt from the one-SGPR constant-bus rule: value and lane select are both scalar registers
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(c_wave), "s"(h - h0));
   }
   if (lane < kHC && cntv) atomicAdd(&cnt[lane], cntv);
   __syncthreads();

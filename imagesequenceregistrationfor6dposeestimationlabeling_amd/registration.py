@@ -294,11 +294,16 @@ def evaluate_registration(source, target, threshold, init=None):
     return f, r
 
 
+MORTON_MIN_ROWS = 256     # icp_point_to_point sorts its clouds only above this many rows (one target tile of the searches)
+
+
 def morton_order(points: torch.Tensor) -> torch.Tensor:
     """Row permutation that walks a cloud along a Morton (Z-order) curve: 10 bits per axis on a cubic lattice over the
     bounding box, stable on equal codes.  Consecutive rows of the permuted cloud are a compact patch — what the per-wave
     tile cull of the ICP searches (csrc/nn_batched.hip) needs; nothing else depends on the order."""
     p = points.to(torch.float32)
+    if p.shape[0] <= 1:                                  # nothing to order (and min / max of an empty cloud raise)
+        return torch.arange(p.shape[0], device=p.device)
     lo = p.min(0).values
     ext = (p.max(0).values - lo).max().clamp_min(1e-30)
     q = ((p - lo) * (1023.0 / ext)).to(torch.int64).clamp_(0, 1023)
@@ -325,7 +330,9 @@ def icp_point_to_point(source, target, threshold, init=None, max_iter=30, rel_fi
     wave, the target tiles that lie beyond the wave's bound (and beyond the radius), which needs rows that are
     neighbours in space."""
     src, tgt = _dev(source, torch.float32).contiguous(), _dev(target, torch.float32).contiguous()
-    if spatial_order:
+    # the cull works on 256-row target tiles: a cloud of one tile has nothing to skip, and an empty one goes to the C entry
+    # as it is (which reports the argument error)
+    if spatial_order and min(src.shape[0], tgt.shape[0]) > MORTON_MIN_ROWS:
         src, tgt = src[morton_order(src)].contiguous(), tgt[morton_order(tgt)].contiguous()
     dev = src.device
     T0 = np.eye(4) if init is None else np.asarray(init, np.float64)

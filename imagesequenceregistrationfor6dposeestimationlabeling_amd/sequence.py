@@ -404,12 +404,24 @@ def pick_by_chamfer_table(pc1: torch.Tensor, poses_all: torch.Tensor, R_gt_all: 
 _field_cache: dict = {}
 
 
+def cloud_key(pts: torch.Tensor) -> tuple:
+    """(hash1, hash2, shape, dtype, device index) of a cloud's bytes: see surface_field."""
+    flat = pts.detach().contiguous().view(-1)
+    bits = flat.view(torch.int32 if flat.element_size() == 4 else torch.int64).to(torch.int64)
+    i = torch.arange(bits.numel(), device=bits.device, dtype=torch.int64)
+    h1 = (bits * (2 * i + 1)).sum()                                    # int64 arithmetic wraps: sums modulo 2^64
+    h2 = ((bits ^ (bits >> 15)) * (i * 0x9E3779B1 + 0x7F4A7C15 | 1)).sum()
+    h = torch.stack([h1, h2]).cpu().numpy()
+    return (int(h[0]), int(h[1]), tuple(pts.shape), str(pts.dtype), pts.device.index)
+
+
 def surface_field(surface_pts: torch.Tensor, cells: int = 128) -> "ops.DistField":
     """The distance field of a surface cloud for vote_rows' bounds, built once per cloud."""
-    # keyed by CONTENT (two checksums, one small read-back): an address can be handed to another cloud of the same shape
-    w = torch.arange(1, surface_pts.shape[0] + 1, device=surface_pts.device, dtype=torch.float64)
-    sums = torch.stack([surface_pts.double().sum(), (surface_pts.double() * w[:, None]).sum()]).cpu().numpy()
-    key = (float(sums[0]), float(sums[1]), tuple(surface_pts.shape), surface_pts.device.index, cells)
+    # keyed by CONTENT (one small read-back): an address can be handed to another cloud of the same shape.  The key is a pair of
+    # position-weighted wrapping int64 sums over the coordinates' BIT patterns (element i weighted by an odd multiplier that
+    # depends on i), so a cloud with permuted axes, swapped rows or one changed coordinate gets another key (round 4 keyed on
+    # two f64 sums that a within-row permutation left unchanged).
+    key = cloud_key(surface_pts) + (cells,)
     fld = _field_cache.get(key)
     if fld is None:
         if len(_field_cache) > 4:

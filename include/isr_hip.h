@@ -39,9 +39,10 @@ extern "C" {
 
 #define ISR_DTYPE_BF16 0 /* bf16 inputs, v_mfma_f32_32x32x16_bf16, f32 accumulate */
 #define ISR_DTYPE_F32 1  /* f32 inputs; the index is the arg-max of the k-ordered f32 fmaf-chain logits (lowest key on ties).
-                            D > 16: v_mfma_f32_32x32x2_f32, whose accumulation IS that chain.  D <= 16: every f32 number as three
-                            bf16 numbers, the six plane pairs down to 2^-16 as one 96-wide bf16 dot product on the bf16 matrix
-                            cores (f32-accurate sums), margin test + recheck by the f32 chain of the original rows */
+                            D <= 128 (default): the rows run on the 16-bit matrix cores as f16 planes (x1 | x2s | x1s, three plane
+                            pairs per 16-wide block, f32-accurate sums), margin test + recheck by the f32 chain of the ORIGINAL rows;
+                            a call holding an |element| >= 65 000 falls through, on the device, to v_mfma_f32_32x32x2_f32, whose
+                            accumulation IS that chain.  ISR_TUNE_K1_F32_CHAIN selects the other routes (same indices). */
 #define ISR_DTYPE_BF16_LOG2 2 /* bf16 inputs whose QUERIES were multiplied by log2(e) before their one
                                 rounding to bf16: logits are in log2 units inside the kernel (exp2 + add
                                 per element, nothing else) — the fastest path; outputs stay natural-log */
@@ -69,7 +70,8 @@ int isr_device_count(void);
 #define ISR_TUNE_EP_WSUM_VALU 8  /* 0 (default) the sampler's chunk sums form their logits on the f32 MFMA | 1 on VALU fma chains (same bits) */
 #define ISR_TUNE_K1_F32_CHAIN 9  /* f32 queries: 0 / 3 (default) f16 planes on the matrix cores, exact f32-chain recheck, falls through to the chain kernel when a descriptor does not fit f16 | 1 the f32-MFMA chain kernel | 2 three bf16 planes (D <= 64; chain kernel above) | 4 round 3 96-wide rows (D <= 16) */
 #define ISR_TUNE_K1_SPLIT 10     /* 0 (default) K1 picks its number of key ranges | n > 0 forced (capped); results do not depend on it */
-#define ISR_TUNE_COUNT 11
+#define ISR_TUNE_K1_SKIP 11      /* EXPERIMENT (bf16 log2, D = 64): 0 off | 1 skip every tile (timing only) | 2 skip none | 3 bounds from the shipped kernel's winners */
+#define ISR_TUNE_COUNT 12
 int isr_tuning_set(int knob, int value);
 int isr_tuning_get(int knob);
 
@@ -298,8 +300,10 @@ int isr_nn_batched(const float* qry, int Nq, const float* tgt, int Nt, const dou
  * grid (origin grid_min, edge h; the caller builds it once per cloud, e.g. through isr_nn_batched on the centres) — dist(., S)
  * is 1-Lipschitz, so a vertex x lies within |x - centre(c)| of field[c] for the cell c that holds it (or, outside the grid, the
  * nearest cell of the grid; its distance to surface_bbox (lo xyz, hi xyz) is then a second lower bound): both sums are
- * finite for every pose.  verts (V,3) f32, Tq / Tt (B,12) f64 rigid
- * [R|t] (Tt nullable = identity), field on the device; grid_min (3 doubles) and surface_bbox (6 floats) on the HOST.
+ * finite for every pose.  verts (V,3) f32, Tq / Tt (B,12) f64
+ * [R|t] (Tt nullable = identity), field on the device.  Tt is inverted as a rigid motion (R^T, -R^T t); where it is only
+ * nearly one (f32-born rotations, ||R^T R - I|| = eta ~ 1e-7) every vertex's bracket is widened by eta (max|s| + its upper
+ * bound), so the sums stay rigorous bounds of isr_nn_batched's sum_d for the matrix AS GIVEN; grid_min (3 doubles) and surface_bbox (6 floats) on the HOST.
  * lb_sum, ub_sum (B) f64 on the device.  An item whose bounds straddle the threshold is evaluated exactly by the caller. */
 int isr_adds_bounds(const float* verts, int V, const double* Tq, const double* Tt, int B, const float* field,
                     const double* grid_min, double h, int nx, int ny, int nz, const float* surface_bbox,

@@ -22,3 +22,18 @@ def test_plain_multi_gpu_invocation_spawns_ranks_and_fails_cleanly_without_a_gpu
     assert "torch.distributed.run" in r.stderr and "--nproc-per-node=2" in r.stderr
     assert r.stderr.count("needs a HIP device") >= 2, r.stderr[-2000:]
     assert not any(ln.lstrip().startswith("{") for ln in r.stdout.splitlines())      # no JSON line from a failed run
+
+
+def test_child_command_of_the_eight_gpu_invocation():
+    """`python bench.py --gpus 8 ...` launches `torch.distributed.run --nnodes=1 --nproc-per-node=8 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 8 ...` — the driver's own line (the 8-rank run itself cannot be rehearsed on a
+    one-GPU pool; the command that would start it can be checked)."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    argv = ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    cmd = bench.rank_command(8, 29511, argv)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(str(ROOT / "bench.py"))
+    assert cmd[i + 1:] == argv

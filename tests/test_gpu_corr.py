@@ -103,6 +103,9 @@ def test_corr_logsoftmax_and_topk_leaves(cuda0, dt):
     idx, vals = registration.getCors(q.to(cuda0), k.to(cuda0), leaves=3)
     rv, ri = torch.topk(ref, k=3, dim=-1)
     assert idx.shape == (70, 3) and not idx.is_cuda and vals.is_cuda
+    # 99 %, not equality: `ref` is an f64 matmul, the kernel ranks by the k-ordered f32 chain (bf16: by the f32 MFMA logits), so
+    # two of a row's top-3 whose f64 logits differ by less than the f32 rounding may swap places; the strict check of the
+    # ranking against the chain's own logits is test_corr_topk_without_the_matrix
     assert (idx == ri).float().mean() > 0.99
     np.testing.assert_allclose(vals.cpu().numpy(), rv.numpy(), atol=5e-5)
 
@@ -772,3 +775,24 @@ def test_corr_f32_screened_maxima_near_ties_in_skipped_looking_tiles(cuda0, orac
     assert np.isin(got, np.concatenate([pos_dom, pos_riv, [3]])).all()
     assert (np.isin(got, pos_riv)).sum() > 0 and (np.isin(got, pos_dom)).sum() > 0
     np.testing.assert_allclose(logp.cpu().numpy(), o["maxlogit"].astype(np.float64) - o["lse"], atol=3e-5)
+
+
+@pytest.mark.gpu
+def test_mfma_f16_keeps_subnormal_inputs(cuda0, tmp_path):
+    """split_eabs (corr_argmax.hip) prices subnormal x1s plane elements at 2^-25 ABSOLUTE each, which is true only if
+    v_mfma_f32_32x32x16_f16 keeps subnormal f16 INPUTS (MI200 flushed them).  The probe in tools/mfma_f16_denorm.hip is
+    built and run here (the claim used to rest on a committed binary)."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not on this box")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "mfma_f16_denorm.hip")
+    exe = str(tmp_path / "mfma_f16_denorm")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-w", "-o", exe, src], check=True, timeout=300)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout.splitlines()
+    kept = float(out[0].split(":")[1].split()[0])          # 16 products of 2^-20 (subnormal) x 2^10
+    tiny = float(out[1].split(":")[1].split()[0])          # 16 products of 2^-14 x 2^-24 (the smallest subnormal)
+    assert kept == 2.0 ** -6
+    assert tiny == 16.0 * 2.0 ** -38
