@@ -75,7 +75,15 @@ struct CorrWs {
   const int32_t* only;   // leave at once when *only == 0
   // tile skip (SKIP instantiations of the direct kernel): per query a LOWER bound of its maximum logit (raw units), or null
   const float* lower;
+  int lower_stride;      // floats per query in `lower` (the bound first)
+  float skip_T;          // log2 units below the bound at which a piece stops counting
   float* lowbuf;         // (P) where the call's own pre-pass leaves those bounds
+  // the screened route (corr_sparse.hpp): block-scaled FP6 images of the rows, the queries' {|q|, |dq|}, max |dk|^2 and max |k~|^2
+  uint8_t* q6;           // (P, 64 B)
+  uint8_t* k6;           // (N, 64 B)
+  float* qnrm;           // (P, 2)
+  uint32_t* kmax;        // (2) float bit patterns
+  unsigned long long* redone;   // diagnostics: tile items redone exactly
   float skip_default;    // the threshold when `lower` is null (experiments: +inf skips every tile, -inf none)
 };
 
@@ -675,7 +683,10 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
   __syncthreads();
   if (threadIdx.x == 0) {
     ws.kn2[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * inflate;   // inflate > 1: the split-f32 route's extra error terms
-    if (blockIdx.x == 0) { ws.rcount[0] = 0; ws.rcount[1] = 0; }
+    if (blockIdx.x == 0) {
+      ws.rcount[0] = 0; ws.rcount[1] = 0; ws.rcount[2] = 0; ws.rcount[3] = 0;
+      if (ws.kmax) { ws.kmax[0] = 0u; ws.kmax[1] = 0u; ws.redone[0] = 0ull; }
+    }
   }
 }
 
@@ -739,6 +750,7 @@ __device__ __forceinline__ float kn2_max(const CorrWs& ws) {      // every lane 
 }
 
 #include "corr_direct.hpp"   // corr_bf16_direct_kernel: the VALU-minimal bf16 loop (log2 and natural units)
+#include "corr_sparse.hpp"   // the screened route for D = 64: FP6 screen, exact bf16 pieces
 
 template <int MODE>
 __global__ __launch_bounds__(256) void corr_finalize_kernel(int P, int D, float eabs, int nsplit, int range_chunks,
@@ -1108,10 +1120,17 @@ size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   o->rlist = bf16 ? w.take<int32_t>(P) : nullptr;
   o->rval = bf16 ? w.take<double>((size_t)rs * P) : nullptr;
   o->ridx = bf16 ? w.take<int32_t>((size_t)rs * P) : nullptr;
-  o->lowbuf = bf16 ? w.take<float>(P) : nullptr;
+  o->lowbuf = bf16 ? w.take<float>((size_t)P * 10) : nullptr;     // kLowStride floats per query
+  o->q6 = bf16 ? w.take<uint8_t>((size_t)P * 64) : nullptr;
+  o->k6 = bf16 ? w.take<uint8_t>((size_t)N * 64) : nullptr;
+  o->qnrm = bf16 ? w.take<float>((size_t)P * 2) : nullptr;
+  o->kmax = bf16 ? w.take<uint32_t>(4) : nullptr;
+  o->redone = bf16 ? w.take<unsigned long long>(2) : nullptr;
   o->skip = nullptr;
   o->only = nullptr;
   o->lower = nullptr;
+  o->lower_stride = 1;
+  o->skip_T = 42.f;
   o->skip_default = -__builtin_inff();
   return w.off;
 }
@@ -1213,6 +1232,22 @@ extern "C" int isr_corr_argmax_recheck_count(const void* ws_, size_t ws_bytes, i
   carve(w, P, N, dtype, &ws);
   hipStream_t stream = isr::as_stream(stream_);
   ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.rcount, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+  ISR_CHECK_HIP(hipStreamSynchronize(stream));
+  return ISR_OK;
+}
+
+// Diagnostics of the screened route: tile items redone exactly in the last call on this workspace.  Synchronises the stream.
+extern "C" int isr_corr_argmax_screen_redone(const void* ws_, size_t ws_bytes, int P, int N, int dtype, long long* count_host,
+                                             isr_stream_t stream_) {
+  ISR_REQUIRE(ws_ && count_host && P > 0 && N > 0, "isr_corr_argmax_screen_redone: bad argument");
+  ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, 128, dtype), "isr_corr_argmax_screen_redone: workspace too small");
+  *count_host = 0;
+  if (dtype == ISR_DTYPE_F32) return ISR_OK;
+  isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
+  CorrWs ws;
+  carve(w, P, N, dtype, &ws);
+  hipStream_t stream = isr::as_stream(stream_);
+  ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.redone, sizeof(long long), hipMemcpyDeviceToHost, stream));
   ISR_CHECK_HIP(hipStreamSynchronize(stream));
   return ISR_OK;
 }
@@ -1335,6 +1370,19 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
     if (!lse_only) corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
   } else
+  if (D == 64 && log2 && isr::tuning(ISR_TUNE_K1_SKIP) == 5) {     // the screened route (corr_sparse.hpp): one key range
+    ISR_REQUIRE(p.nsplit == 1, "isr_corr_argmax: the screened route runs one key range");
+    CorrWs w2 = ws;
+    w2.lower = ws.lowbuf;
+    const unsigned gq = (unsigned)((2l * P + 255) / 256), gk = (unsigned)((2l * N + 255) / 256);
+    corr_quant_fp6_kernel<false><<<gk, 256, 0, stream>>>(k, N, ldk, ws.k6, nullptr, ws.kmax, ws);
+    corr_quant_fp6_kernel<true><<<gq, 256, 0, stream>>>(q, P, ldq, ws.q6, ws.qnrm, nullptr, ws);
+    corr_fp6_lower_kernel<<<(P + kQPB0 - 1) / kQPB0, kThreads, 0, stream>>>(ws.q6, ws.k6, q, k, P, N, ldq, ldk, ws.lowbuf, ws);
+    corr_fp6_sparse_kernel<<<(P + kQPB1 - 1) / kQPB1, kThreads, 0, stream>>>(ws.q6, ws.k6, q, k, P, N, ldq, ldk, ws.qnrm, ws.kmax, w2, idx, logp, lse);
+    corr_bf16_kernel<4, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, w2);
+    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, w2, idx, logp, lse);
+    if (!lse_only) corr_recheck_kernel<4><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, w2);
+  } else
   if (D == 64 && log2 && !lse_only && isr::tuning(ISR_TUNE_K1_SKIP) != 0) {     // EXPERIMENT: the tile-skip kernel
     const int mode = isr::tuning(ISR_TUNE_K1_SKIP);
     CorrWs w2 = ws;
@@ -1455,7 +1503,11 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     corr_split_f32_kernel<false><<<(unsigned)(((long)N * 16 + 255) / 256), 256, 0, stream>>>(kf, N, D, ldk, 1.f, k2);
     return launch_bf16(q2, k2, P, N, 128, 128, 128, true, p, ws, idx, logp, lse, F32Rows{qf, kf, ldq, ldk, D}, 1.08f, stream);
   }
-  const CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * kQB * 32);
+  CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * kQB * 32);
+  if (dtype == ISR_DTYPE_BF16_LOG2 && D == 64 && isr::tuning(ISR_TUNE_K1_SKIP) == 5) {     // the screened route: one key range
+    p.nsplit = 1;
+    p.range_chunks = p.nchunks;
+  }
   isr::Workspace w(ws_, ws_bytes);
   CorrWs ws;
   carve(w, P, N, dtype, &ws);

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
     if constexpr (SKIP != 0) {
       // the tile-skip threshold: (a lower bound of the query's maximum) - kSkipT, raw logit units
       const int q = min(q0 + qb * 32 + r, P - 1);
-      st[qb].thr = ws.lower ? ws.lower[q] - kSkipT * (NAT ? 0.6931471805599453f : 1.f) : ws.skip_default;
+      st[qb].thr = ws.lower ? ws.lower[(size_t)q * ws.lower_stride] - ws.skip_T * (NAT ? 0.6931471805599453f : 1.f) : ws.skip_default;
     }
   }
   // the screen's distance below the maximum, in raw logit units: 2 eps of corr_finish (same |q|^2, same max |k|^2) inflated by

@@ -308,8 +308,10 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(
       const float lim = reperr * z;
       c_wave += __popcll(__ballot(z > 0.0f) & __ballot(e2 <= lim * lim) & vmask[c]);
     }
-    // v_writelane_b32 is exempt from the one-SGPR constant-bus rule: value and lane select are both scalar registers
-    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(cntv) : "s"(c_wave), "s"(h - h0));
+    // gfx9 allows one SGPR per VALU instruction on the constant bus: the lane select travels in M0, bound as an INPUT operand
+    // (the compiler loads it and knows the register is in use — round 4 wrote M0 inside the asm and listed it as a clobber,
+    // which hipcc answers with "may not be preserved")
+    asm volatile("v_writelane_b32 %0, %1, m0" : "+v"(cntv) : "s"(c_wave), "{m0}"(h - h0));
   }
   if (lane < kHC && cntv) atomicAdd(&cnt[lane], cntv);
   __syncthreads();

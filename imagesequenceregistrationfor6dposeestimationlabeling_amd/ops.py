@@ -393,6 +393,20 @@ def corr_recheck_count() -> int:
     return int(out.value)
 
 
+def corr_screen_redone() -> int:
+    """Diagnostics: tile items (32 queries x 32 keys) the last bf16 corr_argmax call redid on the bf16 matrix cores behind its
+    FP6 screen (0 on the unscreened routes).  Synchronises the current stream."""
+    import ctypes
+    if _last_corr is None:
+        return 0
+    ws, P, N, dtype, dev = _last_corr
+    out = ctypes.c_longlong(0)
+    with torch.cuda.device(dev):
+        rc = lib().isr_corr_argmax_screen_redone(ptr(ws), ws.numel(), P, N, dtype, ctypes.addressof(out), current_stream(dev))
+    check(rc, "isr_corr_argmax_screen_redone")
+    return int(out.value)
+
+
 def corr_recheck_count_f32(D: int) -> int:
     """Diagnostics: the length of the f32-chain recheck list of the last f32 corr_argmax call with D columns, under the
     knob setting still in force (-1 when that call took the f32-MFMA chain kernel).  Synchronises the current stream."""

@@ -110,6 +110,11 @@ int isr_corr_argmax_recheck_count(const void* ws, size_t ws_bytes, int P, int N,
 int isr_corr_argmax_recheck_count_f32(const void* ws, size_t ws_bytes, int P, int N, int D, int32_t* count_host,
                                       isr_stream_t stream);
 
+/* Diagnostics (the screened bf16 route): how many (32-query block, 32-key tile) items the last isr_corr_argmax call on this
+ * workspace redid on the bf16 matrix cores after its FP6 screen; 0 on every other route.  count_host: HOST pointer (int64). */
+int isr_corr_argmax_screen_redone(const void* ws, size_t ws_bytes, int P, int N, int dtype, long long* count_host,
+                                  isr_stream_t stream);
+
 /* Diagnostics: the shader clock (MHz) the bf16 kernel held during the last isr_corr_argmax call on this
  * workspace, from s_memtime / s_memrealtime over the life of one workgroup; 0 for ISR_DTYPE_F32. */
 int isr_corr_argmax_clock_mhz(const void* ws, size_t ws_bytes, int P, int N, int dtype, double* mhz_host,
