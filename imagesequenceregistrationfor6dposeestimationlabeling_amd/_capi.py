@@ -18,13 +18,14 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["ISR_HIP_LIB"]) if os.environ.get("ISR_HIP_LIB") else _PKG / "libisr_hip.so"
 
 ISR_OK = 0
-ABI_VERSION = 4
+ABI_VERSION = 5
 DTYPE_BF16 = 0
 DTYPE_F32 = 1
 DTYPE_BF16_LOG2 = 2
+DTYPE_BF16_LOG2_SCREENED = 3
 # ISR_TUNE_* knobs of include/isr_hip.h
 TUNE = {"nn_path": 0, "nn_filter": 1, "icp_warm": 2, "nn_plan_rq": 3, "nn_plan_blocks": 4,
-        "nn_tile_st": 5, "nn_tile_sq": 6, "nn_tile_tb": 7, "ep_wsum_valu": 8, "k1_f32_chain": 9, "k1_split": 10, "k1_skip": 11}
+        "nn_tile_st": 5, "nn_tile_sq": 6, "nn_tile_tb": 7, "ep_wsum_valu": 8, "k1_f32_chain": 9, "k1_split": 10}
 
 
 class IsrError(RuntimeError):

@@ -24,7 +24,7 @@ namespace {
 struct Tuning {
   std::atomic<int> v[ISR_TUNE_COUNT];
   Tuning() {
-    const int defaults[ISR_TUNE_COUNT] = {-1, -1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int defaults[ISR_TUNE_COUNT] = {-1, -1, 1, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < ISR_TUNE_COUNT; ++i) v[i].store(defaults[i], std::memory_order_relaxed);
     // the environment is consulted here and nowhere else: once, before any entry point can run
     if (const char* e = getenv("ISR_NN_GRID")) { if (e[0] >= '0' && e[0] <= '2') v[ISR_TUNE_NN_PATH] = e[0] - '0'; }

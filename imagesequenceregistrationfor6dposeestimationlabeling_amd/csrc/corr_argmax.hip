@@ -83,8 +83,10 @@ struct CorrWs {
   uint8_t* k6;           // (N, 64 B)
   float* qnrm;           // (P, 2)
   uint32_t* kmax;        // (2) float bit patterns
-  unsigned long long* redone;   // diagnostics: tile items redone exactly
-  float skip_default;    // the threshold when `lower` is null (experiments: +inf skips every tile, -inf none)
+  unsigned long long* redone;   // diagnostics: [0] tile items redone exactly, [1] query blocks handed to the dense kernel
+  int32_t* hand;         // (query blocks of 256) 1: pass 1 left the block to the dense tile-skip kernel
+  int nhand;             // its length
+  float skip_default;    // the threshold when `lower` is null
 };
 
 __device__ __forceinline__ bool gated_off(const CorrWs& ws) {
@@ -662,6 +664,7 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
   __shared__ float red[4];
   if (gated_off(ws)) return;
   float mx = 0.f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ws.nhand; i += kKnBlocks * 256) ws.hand[i] = 0;     // the screened route's hand-over flags
   for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += kKnBlocks * 256) {
     const uint16_t* row = K + (size_t)n * ldk;
     float s = 0.f;
@@ -685,7 +688,7 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
     ws.kn2[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * inflate;   // inflate > 1: the split-f32 route's extra error terms
     if (blockIdx.x == 0) {
       ws.rcount[0] = 0; ws.rcount[1] = 0; ws.rcount[2] = 0; ws.rcount[3] = 0;
-      if (ws.kmax) { ws.kmax[0] = 0u; ws.kmax[1] = 0u; ws.redone[0] = 0ull; }
+      if (ws.kmax) { ws.kmax[0] = 0u; ws.kmax[1] = 0u; ws.redone[0] = 0ull; ws.redone[1] = 0ull; }
     }
   }
 }
@@ -969,18 +972,6 @@ __global__ __launch_bounds__(256) void corr_recheck_merge_kernel(int P, int N, i
   }
 }
 
-// EXPERIMENT: lower[q] = <q, k[hint[q]]> (f32 fma chain over the bf16 rows) - a little: a lower bound of the query's maximum
-__global__ __launch_bounds__(256) void corr_lower_from_hint_kernel(const uint16_t* __restrict__ Q, const uint16_t* __restrict__ K, int P, int D,
-                                                                   int ldq, int ldk, const int32_t* __restrict__ hint, float* __restrict__ lower) {
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= P) return;
-  const uint16_t* qr = Q + (size_t)q * ldq;
-  const uint16_t* kr = K + (size_t)hint[q] * ldk;
-  float acc = 0.f;
-  for (int d = 0; d < D; ++d) acc = __builtin_fmaf(__uint_as_float((uint32_t)qr[d] << 16), __uint_as_float((uint32_t)kr[d] << 16), acc);
-  lower[q] = acc - 1e-3f * fabsf(acc);
-}
-
 // ------------------------------------------------------------------------------------ plan
 constexpr int kMaxSplit = 64;     // upper bound on key ranges per launch
 constexpr int kSlotCap = 2048;    // device-independent cap on the resident-workgroup estimate
@@ -1054,6 +1045,7 @@ int resident_slots(Kern kern) {
 }
 
 int slots_for(int dtype, int D) {
+  if (dtype == ISR_DTYPE_BF16_LOG2_SCREENED) dtype = ISR_DTYPE_BF16_LOG2;     // (a screened call plans one key range whatever this says)
   // cached per (kernel family, padded D): the occupancy query costs tens of microseconds
   static int cache[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
   int v = 0;
@@ -1120,12 +1112,15 @@ size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   o->rlist = bf16 ? w.take<int32_t>(P) : nullptr;
   o->rval = bf16 ? w.take<double>((size_t)rs * P) : nullptr;
   o->ridx = bf16 ? w.take<int32_t>((size_t)rs * P) : nullptr;
-  o->lowbuf = bf16 ? w.take<float>((size_t)P * 10) : nullptr;     // kLowStride floats per query
-  o->q6 = bf16 ? w.take<uint8_t>((size_t)P * 64) : nullptr;
-  o->k6 = bf16 ? w.take<uint8_t>((size_t)N * 64) : nullptr;
-  o->qnrm = bf16 ? w.take<float>((size_t)P * 2) : nullptr;
-  o->kmax = bf16 ? w.take<uint32_t>(4) : nullptr;
-  o->redone = bf16 ? w.take<unsigned long long>(2) : nullptr;
+  const bool scr = dtype == ISR_DTYPE_BF16_LOG2_SCREENED;
+  o->lowbuf = scr ? w.take<float>((size_t)P * 10) : nullptr;      // kLowStride floats per query
+  o->q6 = scr ? w.take<uint8_t>((size_t)P * 64) : nullptr;
+  o->k6 = scr ? w.take<uint8_t>((size_t)N * 64) : nullptr;
+  o->qnrm = scr ? w.take<float>((size_t)P * 2) : nullptr;
+  o->kmax = scr ? w.take<uint32_t>(4) : nullptr;
+  o->redone = scr ? w.take<unsigned long long>(2) : nullptr;
+  o->hand = scr ? w.take<int32_t>(qblocks) : nullptr;
+  o->nhand = scr ? qblocks : 0;
   o->skip = nullptr;
   o->only = nullptr;
   o->lower = nullptr;
@@ -1241,13 +1236,14 @@ extern "C" int isr_corr_argmax_screen_redone(const void* ws_, size_t ws_bytes, i
                                              isr_stream_t stream_) {
   ISR_REQUIRE(ws_ && count_host && P > 0 && N > 0, "isr_corr_argmax_screen_redone: bad argument");
   ISR_REQUIRE(ws_bytes >= isr_corr_argmax_workspace_bytes(P, N, 128, dtype), "isr_corr_argmax_screen_redone: workspace too small");
-  *count_host = 0;
-  if (dtype == ISR_DTYPE_F32) return ISR_OK;
+  count_host[0] = 0;
+  count_host[1] = 0;
+  if (dtype != ISR_DTYPE_BF16_LOG2_SCREENED) return ISR_OK;
   isr::Workspace w(const_cast<void*>(ws_), ws_bytes);
   CorrWs ws;
   carve(w, P, N, dtype, &ws);
   hipStream_t stream = isr::as_stream(stream_);
-  ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.redone, sizeof(long long), hipMemcpyDeviceToHost, stream));
+  ISR_CHECK_HIP(hipMemcpyAsync(count_host, ws.redone, 2 * sizeof(long long), hipMemcpyDeviceToHost, stream));
   ISR_CHECK_HIP(hipStreamSynchronize(stream));
   return ISR_OK;
 }
@@ -1283,7 +1279,7 @@ namespace {
 // f16: the planes are f16 (RowFrags), eabs the margin test's absolute term.
 int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int ldq, int ldk, bool log2, const CorrPlan& p,
                 const CorrWs& ws, int32_t* idx, float* logp, float* lse, F32Rows f32, float kn_inflate, hipStream_t stream,
-                int sp = 0, bool f16 = false) {
+                int sp = 0, bool f16 = false, bool screened = false) {
   const float eabs = (sp && f16) ? split_eabs(sp) : 0.f;
   const bool lse_only = idx == nullptr;      // no maxima, no recovery, no recheck (LSE instantiations where they exist)
   const dim3 grid(p.qblocks, p.nsplit);
@@ -1370,34 +1366,23 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
     if (!lse_only) corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
   } else
-  if (D == 64 && log2 && isr::tuning(ISR_TUNE_K1_SKIP) == 5) {     // the screened route (corr_sparse.hpp): one key range
-    ISR_REQUIRE(p.nsplit == 1, "isr_corr_argmax: the screened route runs one key range");
+  if (screened) {     // the screened route (corr_sparse.hpp): one key range, D = 64, log2 domain
+    ISR_REQUIRE(p.nsplit == 1 && D == 64 && log2, "isr_corr_argmax: the screened route runs D = 64 log2-domain rows over one key range");
     CorrWs w2 = ws;
     w2.lower = ws.lowbuf;
+    w2.lower_stride = kLowStride;
+    w2.skip_T = (float)screen_T(N);
     const unsigned gq = (unsigned)((2l * P + 255) / 256), gk = (unsigned)((2l * N + 255) / 256);
     corr_quant_fp6_kernel<false><<<gk, 256, 0, stream>>>(k, N, ldk, ws.k6, nullptr, ws.kmax, ws);
     corr_quant_fp6_kernel<true><<<gq, 256, 0, stream>>>(q, P, ldq, ws.q6, ws.qnrm, nullptr, ws);
     corr_fp6_lower_kernel<<<(P + kQPB0 - 1) / kQPB0, kThreads, 0, stream>>>(ws.q6, ws.k6, q, k, P, N, ldq, ldk, ws.lowbuf, ws);
     corr_fp6_sparse_kernel<<<(P + kQPB1 - 1) / kQPB1, kThreads, 0, stream>>>(ws.q6, ws.k6, q, k, P, N, ldq, ldk, ws.qnrm, ws.kmax, w2, idx, logp, lse);
-    corr_bf16_kernel<4, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, w2);
-    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, w2, idx, logp, lse);
-    if (!lse_only) corr_recheck_kernel<4><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, w2);
-  } else
-  if (D == 64 && log2 && !lse_only && isr::tuning(ISR_TUNE_K1_SKIP) != 0) {     // EXPERIMENT: the tile-skip kernel
-    const int mode = isr::tuning(ISR_TUNE_K1_SKIP);
-    CorrWs w2 = ws;
-    if (mode == 1) w2.skip_default = __builtin_inff();
-    if (mode == 3) {         // bounds from the shipped kernel's own winners (timing experiment)
-      ISR_LAUNCH_BF16(4);
-      corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, N, p.rsplit, ws, idx);
-      corr_lower_from_hint_kernel<<<(P + 255) / 256, 256, 0, stream>>>(q, k, P, D, ldq, ldk, idx, ws.lowbuf);
-      corr_keynorm_kernel<false><<<kKnBlocks, 256, 0, stream>>>(k, N, D, ldk, kn_inflate, ws);     // (zeroes the counters again)
-      w2.lower = ws.lowbuf;
-    }
+    // query blocks pass 1 handed over (most of their first tiles had to be redone: flat logits): the dense kernel with the same
+    // rule — a piece counts when its exact maximum reaches L_q - T — on the same bf16 logits; every other block leaves at once
     corr_bf16_direct_kernel<4, kQB, false, 4, 0, false, false, 1><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, w2, idx, logp, lse);
     corr_bf16_kernel<4, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, w2);
     corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, w2, idx, logp, lse);
-    corr_recheck_kernel<4><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, w2);
+    if (!lse_only) corr_recheck_kernel<4><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, w2);
   } else
   switch (D) {
     case 16: ISR_LAUNCH_BF16(1); break;
@@ -1438,7 +1423,7 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
               "isr_corr_argmax: null pointer (idx may be null only for an lse-only call: logp null, lse given)");
   ISR_REQUIRE(P > 0 && N > 0 && D > 0, "isr_corr_argmax: P=%d N=%d D=%d must be positive", P, N, D);
   ISR_REQUIRE(ldq >= D && ldk >= D, "isr_corr_argmax: ldq=%d ldk=%d < D=%d", ldq, ldk, D);
-  ISR_REQUIRE(dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2 || dtype == ISR_DTYPE_F32,
+  ISR_REQUIRE(dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2 || dtype == ISR_DTYPE_F32 || dtype == ISR_DTYPE_BF16_LOG2_SCREENED,
               "isr_corr_argmax: dtype %d", dtype);
   if (!ws_ || ws_bytes < isr_corr_argmax_workspace_bytes(P, N, D, dtype)) {
     isr::set_error("isr_corr_argmax: workspace %zu < %zu", ws_bytes,
@@ -1504,16 +1489,17 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     return launch_bf16(q2, k2, P, N, 128, 128, 128, true, p, ws, idx, logp, lse, F32Rows{qf, kf, ldq, ldk, D}, 1.08f, stream);
   }
   CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * kQB * 32);
-  if (dtype == ISR_DTYPE_BF16_LOG2 && D == 64 && isr::tuning(ISR_TUNE_K1_SKIP) == 5) {     // the screened route: one key range
+  const bool screened = screened_route(dtype, N, D);
+  if (screened) {     // one key range: L_q and the pieces' canonical order are defined over the whole range
     p.nsplit = 1;
     p.range_chunks = p.nchunks;
   }
   isr::Workspace w(ws_, ws_bytes);
   CorrWs ws;
   carve(w, P, N, dtype, &ws);
-  if (dtype == ISR_DTYPE_BF16 || dtype == ISR_DTYPE_BF16_LOG2) {
+  if (dtype != ISR_DTYPE_F32) {
     return launch_bf16(static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), P, N, D, ldq, ldk,
-                       dtype == ISR_DTYPE_BF16_LOG2, p, ws, idx, logp, lse, F32Rows{nullptr, nullptr, 0, 0, 0}, 1.f, stream);
+                       dtype != ISR_DTYPE_BF16, p, ws, idx, logp, lse, F32Rows{nullptr, nullptr, 0, 0, 0}, 1.f, stream, 0, false, screened);
   }
   return launch_f32_chain(static_cast<const float*>(Q), static_cast<const float*>(K), P, N, D, ldq, ldk, p, ws, idx, logp, lse, stream);
 }

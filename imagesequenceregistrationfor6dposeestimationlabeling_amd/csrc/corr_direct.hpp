@@ -33,7 +33,6 @@ constexpr float kLow = -100.f;     // log2 units: a maximum below this sends the
 // maximum of -inf (no key), an overflowed sum (+inf).  A NaN cannot arise from FINITE descriptors (no inf - inf, no 0 x inf:
 // products of finite bf16 / f16 values are finite in f32 and the sums' only non-finite value is +inf); finite descriptors
 // are a stated precondition of K1, and nothing here relies on a NaN taking either branch.
-constexpr float kSkipT = 42.f;     // log2 units: a tile whose maximum lies this far below a lower bound of the query's maximum adds nothing to an f32 sum
 
 struct DirectState {
   float m;   // largest tile maximum so far (raw logit)
@@ -104,6 +103,9 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
   // already hide the maxima and the branch behind the item costs more than they did (2.56 -> 2.77 ms, profiles/r04_k1_screen.txt)
   constexpr bool SCR = ISR_K1_SCREEN != 0 && (SP == 0 || ((ISR_K1_SCREEN_PLANES >> SP) & 1) != 0);
   if (gated_off(ws)) return;
+  if constexpr (SKIP != 0) {                    // behind the screened route: only the query blocks its pass 1 handed over
+    if (ws.hand && !ws.hand[blockIdx.x]) return;
+  }
   static_assert(SP == 0 || DK == 3 * SP, "split rows: DK counts the 3 SP blocks of a row");
   constexpr int NCH = 2 * NFR;
   constexpr bool POW2 = (NCH & (NCH - 1)) == 0;
@@ -512,8 +514,9 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
           else load_a(buf, sub + 1);
         }
         if constexpr (SKIP != 0) {
-          // EXPERIMENT (tile skip): the tile's maximum first; its 16 exponentials only when some lane's maximum reaches its
-          // query's threshold (wave-uniform branch), each lane adding its own tile sum only when ITS maximum does
+          // The dense form of the screened route's rule (corr_sparse.hpp): the tile's maximum first; its 16 exponentials only
+          // when some lane's maximum reaches its query's threshold L_q - T (wave-uniform branch), each lane adding its own
+          // piece's sum only when ITS maximum does — the pieces, their order and their bits are corr_fp6_sparse_kernel's
           float t = tile_max(cur);
           constexpr int GS = (9 + NMF - 1) / NMF;
 #pragma unroll

@@ -34,6 +34,16 @@ constexpr int kScreenTBase = 21;    // T = kScreenTBase + ceil(log2 N)
 constexpr int kLowStride = 10;      // floats pass 0 leaves per query: L_q, its tile T (int bits), {piece maximum, piece sum, runner-up, winner key} of lane halves 0, 1
 constexpr int kScreenMaxN = 1 << 18; // pass 0 carries the tile index in 13 mantissa bits
 
+// T of a call: a piece more than T below L_q is left out of the sum; all N keys' worth of such pieces stay below 2^-kScreenTBase of it
+inline int screen_T(int N) {
+  int tl = 0;
+  while ((1 << tl) < N) ++tl;
+  return kScreenTBase + tl;
+}
+// which calls take the screened route: the dtype asks for it, the rows are 64 wide and the tile index fits pass 0's 13 bits;
+// every other ISR_DTYPE_BF16_LOG2_SCREENED call runs the unscreened log2-domain kernels
+inline bool screened_route(int dtype, int N, int D) { return dtype == ISR_DTYPE_BF16_LOG2_SCREENED && D == 64 && N <= kScreenMaxN; }
+
 // ------------------------------------------------------------------------------------------ quantisation
 // One thread per 32-element half of a row.  e2m3 codes c = 0..31 of |x| / 2^e: c / 8 below 2, 2 + (c - 16) / 4 below 4, 4 + (c - 24) / 2
 // up to 7.5 (c = 31); bit 5 the sign; 2^e the smallest power of two with max |x| / 2^e <= 7.5.  The norms are those of the
@@ -240,7 +250,7 @@ __device__ __forceinline__ f32x16 exact_tile(const uint16_t* __restrict__ K, int
 // ------------------------------------------------------------------------------------------ pass 0: L_q
 // grid = query blocks of 512 (4 waves x kQB0 x 32 queries), the whole key range per workgroup.
 #ifndef ISR_Q6_QB0
-#define ISR_Q6_QB0 2
+#define ISR_Q6_QB0 4
 #endif
 #ifndef ISR_Q6_QB1
 #define ISR_Q6_QB1 2
@@ -248,7 +258,7 @@ __device__ __forceinline__ f32x16 exact_tile(const uint16_t* __restrict__ K, int
 constexpr int kQB0 = ISR_Q6_QB0;                              // 32-query blocks per wave in pass 0
 constexpr int kQPB0 = kWaves * kQB0 * 32;                      // queries per workgroup
 #ifndef ISR_Q6_W0
-#define ISR_Q6_W0 (ISR_Q6_QB0 <= 2 ? 3 : 2)
+#define ISR_Q6_W0 3
 #endif
 #ifndef ISR_Q6_W1
 #define ISR_Q6_W1 (ISR_Q6_QB1 <= 2 ? 3 : 2)
@@ -355,6 +365,7 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W0) void corr_fp6_lower_kernel(con
 // Everything that reaches sums, maxima and indices comes from exact_tile (bf16 MFMA, C = 0: the logits of the dense kernels).
 // hand (nullable): a workgroup most of whose first kHandStages stages were redone writes its block index there and leaves;
 // the dense tile-skip kernel behind this one owns the listed blocks (same rule, same logits: the same bits).
+constexpr int kHandMinStages = 8;                             // key ranges shorter than this many stages (2 048 keys) are never handed over
 constexpr int kQB1 = ISR_Q6_QB1;                              // 32-query blocks per wave in pass 1
 constexpr int kQPB1 = kWaves * kQB1 * 32;                      // queries per workgroup: kNB1 of the dense kernels' 256-query blocks
 constexpr int kNB1 = kQPB1 / 256;
@@ -365,6 +376,7 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W1) void corr_fp6_sparse_kernel(co
                                                                       float* __restrict__ lse_out) {
   __shared__ uint4 lds[2 * kQ6Chunks];
   __shared__ int bad_half[2];
+  __shared__ int hand_cnt;
   if (gated_off(ws)) return;
   constexpr int QB = kQB1, NFR = 4, DEFF = 64;
   static_assert(kQPB1 % 256 == 0 && kNB1 <= 2, "a workgroup covers whole 256-query blocks of the fallback / finalize kernels");
@@ -375,6 +387,7 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W1) void corr_fp6_sparse_kernel(co
   const long long t_sclk0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
   const long long t_ref0 = probe ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
   if (tid < 2) bad_half[tid] = 0;
+  if (tid == 0) hand_cnt = 0;
 
   auto load_q = [&](int qb, bf16x8 (&dst)[NFR]) __attribute__((always_inline)) {            // the bf16 fragments of query block qb (its rows are L2-warm)
     const uint16_t* src = Q + (size_t)min(q0 + qb * 32 + r, P - 1) * ldq + 8 * h;
@@ -419,9 +432,7 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W1) void corr_fp6_sparse_kernel(co
   }
   // thresholds: thr_x = L_q - T decides what a piece's exact maximum must reach to enter the sum; thr_s = thr_x - E_q what its
   // approximate maximum must stay below for the piece to be skipped unseen
-  int tl = 0;
-  while ((1 << tl) < N) ++tl;
-  const float T = (float)(kScreenTBase + tl);
+  const float T = ws.skip_T;                                  // screen_T(N), the same number the dense tile-skip kernel is given
   float thr_x[QB], thr_s[QB];
   int tstar[QB];                                              // pass 0's tile of the query, and this lane's two exact values there
   float pt[QB], pts[QB];
@@ -460,6 +471,29 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W1) void corr_fp6_sparse_kernel(co
   __syncthreads();
   int redone = 0;                                            // items this wave redid exactly (wave-uniform)
   const int nfull = N / kTKQ;
+  // Flat logits: when more than a quarter of the block's FIRST stage's items would have to be fetched and redone, the screen is
+  // not paying for itself; the block goes to the dense tile-skip kernel behind this one, which forms the same pieces from the
+  // same logits by the same rule.  A speed decision only: the bits do not depend on it.  (A plain loop over the stage ahead of
+  // the main loop — 1.3 % of the screening done twice — so that the main loop keeps a single exit.)
+  if (nstage >= kHandMinStages) {                             // block-uniform
+    int marked = 0;
+#pragma nounroll
+    for (int sub = 0; sub < kTKQ / 32; ++sub) {
+      const i32x8 a = ks.frag(0, sub, r, h);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float t6 = tile_max(mfma_fp6(a, bq6[qb]));
+        marked += __builtin_amdgcn_ballot_w64(t6 >= thr_s[qb] && sub * 32 != tstar[qb]) != 0ull ? 1 : 0;
+      }
+    }
+    if (lane == 0) atomicAdd(&hand_cnt, marked);
+    __syncthreads();
+    if (hand_cnt * 4 > kWaves * (kTKQ / 32) * QB) {
+      if (tid < kNB1 && (kNB1 * blockIdx.x + tid) * 256 < P) ws.hand[kNB1 * blockIdx.x + tid] = 1;
+      if (tid == 0) atomicAdd(&ws.redone[1], (unsigned long long)kNB1);
+      return;                                                 // (nothing of this wave's is in flight: vmcnt(0) above)
+    }
+  }
   // An item that fails the screen is only MARKED (one scalar instruction: its bit in the stage's item mask); the marked items of
   // a stage are redone behind the stage's screening loop by ONE copy of the heavy code (inlined at each of the 16 unrolled
   // sites, the heavy path made the kernel 36 KB of code and every visit to it a run of instruction-cache misses: ~5 500

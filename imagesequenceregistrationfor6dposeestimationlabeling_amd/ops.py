@@ -255,13 +255,17 @@ def prescale_queries_log2(queries: torch.Tensor) -> torch.Tensor:
 
 
 def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = False,
-                log2_prescaled: bool = False):
+                log2_prescaled: bool = False, screened: bool = False):
     """isr_corr_argmax.  queries (P,D), keys (N,D); bf16 tensors take the bf16 MFMA path, f32
     tensors the exact f32 MFMA path (f16/f64 are converted to f32).  Zero columns are appended
     where the kernel needs a padded D (exact: they add 0 to every logit).
     log2_prescaled: the bf16 queries already carry a factor log2(e) (prescale_queries_log2): the
     kernel works in log2 units with the -M2 reference folded into the MFMA contraction; outputs are
-    still natural-log.  Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32] on the device."""
+    still natural-log.
+    screened (with log2_prescaled): ISR_DTYPE_BF16_LOG2_SCREENED — the rows also go through a block-scaled FP6 screen, and
+    pieces of the log-sum-exp proven to lie more than T = 21 + ceil(log2 N) log2 units below the query's maximum are never
+    formed (indices stay exact, lse moves by < 5e-7; D = 64 only, other shapes run unscreened).  For peaked softmaxes.
+    Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32] on the device."""
     dev = require_cuda(queries, keys)
     if queries.ndim != 2 or keys.ndim != 2 or queries.shape[1] != keys.shape[1]:
         raise ValueError(f"queries {tuple(queries.shape)} / keys {tuple(keys.shape)} must be (P,D),(N,D)")
@@ -269,8 +273,10 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     N = keys.shape[0]
     if P == 0 or N == 0:
         raise ValueError("empty queries or keys")
+    if screened and not log2_prescaled:
+        raise ValueError("screened needs log2-prescaled bf16 queries")
     if queries.dtype == torch.bfloat16 and keys.dtype == torch.bfloat16:
-        dtype = _capi.DTYPE_BF16_LOG2 if log2_prescaled else _capi.DTYPE_BF16
+        dtype = (_capi.DTYPE_BF16_LOG2_SCREENED if screened else _capi.DTYPE_BF16_LOG2) if log2_prescaled else _capi.DTYPE_BF16
         Dp = next((d for d in (16, 32, 64, 128) if d >= D), None)
         if Dp is None:
             raise ValueError(f"bf16 path supports D <= 128, got {D}")
@@ -298,7 +304,7 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     return (idx, logp, lse) if want_lse else (idx, logp)
 
 
-def corr_lse(queries: torch.Tensor, keys: torch.Tensor, log2_prescaled: bool = False) -> torch.Tensor:
+def corr_lse(queries: torch.Tensor, keys: torch.Tensor, log2_prescaled: bool = False, screened: bool = False) -> torch.Tensor:
     """The row log-sum-exps of queries @ keys.T alone — pose_refine.py:56's denominator image, estimate_pose's row sums
     (poseEstSurf.py:68-71) — as an lse-only call of isr_corr_argmax (idx = logp = NULL): no maxima are tracked, no index is
     certified, and the values are the bits corr_argmax(..., want_lse=True) returns."""
@@ -310,7 +316,7 @@ def corr_lse(queries: torch.Tensor, keys: torch.Tensor, log2_prescaled: bool = F
     if P == 0 or N == 0:
         raise ValueError("empty queries or keys")
     if queries.dtype == torch.bfloat16 and keys.dtype == torch.bfloat16:
-        dtype = _capi.DTYPE_BF16_LOG2 if log2_prescaled else _capi.DTYPE_BF16
+        dtype = (_capi.DTYPE_BF16_LOG2_SCREENED if screened else _capi.DTYPE_BF16_LOG2) if log2_prescaled else _capi.DTYPE_BF16
         Dp = next((d for d in (16, 32, 64, 128) if d >= D), None)
         if Dp is None:
             raise ValueError(f"bf16 path supports D <= 128, got {D}")
@@ -393,18 +399,19 @@ def corr_recheck_count() -> int:
     return int(out.value)
 
 
-def corr_screen_redone() -> int:
-    """Diagnostics: tile items (32 queries x 32 keys) the last bf16 corr_argmax call redid on the bf16 matrix cores behind its
-    FP6 screen (0 on the unscreened routes).  Synchronises the current stream."""
+def corr_screen_redone() -> tuple[int, int]:
+    """Diagnostics of the last screened corr_argmax call: (tile items — 32 queries x 32 keys — fetched again and redone on the
+    bf16 matrix cores behind the FP6 screen, 256-query blocks handed to the dense kernel); zeros on the unscreened routes.
+    Synchronises the current stream."""
     import ctypes
     if _last_corr is None:
-        return 0
+        return 0, 0
     ws, P, N, dtype, dev = _last_corr
-    out = ctypes.c_longlong(0)
+    out = (ctypes.c_longlong * 2)(0, 0)
     with torch.cuda.device(dev):
         rc = lib().isr_corr_argmax_screen_redone(ptr(ws), ws.numel(), P, N, dtype, ctypes.addressof(out), current_stream(dev))
     check(rc, "isr_corr_argmax_screen_redone")
-    return int(out.value)
+    return int(out[0]), int(out[1])
 
 
 def corr_recheck_count_f32(D: int) -> int:

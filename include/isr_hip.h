@@ -28,8 +28,10 @@ extern "C" {
 #endif
 
 /* v4 (round 4): isr_corr_argmax accepts idx = logp = NULL (lse-only call), f32 rows run as f16 planes by default
- * (ISR_TUNE_K1_F32_CHAIN values 0-4), new isr_corr_topk / isr_corr_topk_workspace_bytes. */
-#define ISR_ABI_VERSION 4
+ * (ISR_TUNE_K1_F32_CHAIN values 0-4), new isr_corr_topk / isr_corr_topk_workspace_bytes.
+ * v5 (round 5): ISR_DTYPE_BF16_LOG2_SCREENED, isr_corr_argmax_screen_redone; isr_corr_topk_workspace_bytes sized by the key
+ * ranges a call uses. */
+#define ISR_ABI_VERSION 5
 
 #define ISR_OK 0
 #define ISR_ERR_ARG (-1)         /* bad shape / null pointer / unsupported value */
@@ -46,6 +48,18 @@ extern "C" {
 #define ISR_DTYPE_BF16_LOG2 2 /* bf16 inputs whose QUERIES were multiplied by log2(e) before their one
                                 rounding to bf16: logits are in log2 units inside the kernel (exp2 + add
                                 per element, nothing else) — the fastest path; outputs stay natural-log */
+
+#define ISR_DTYPE_BF16_LOG2_SCREENED 3 /* ISR_DTYPE_BF16_LOG2 rows behind a rigorous low-precision screen (round 5; D = 64, N <= 262 144 —
+                                other shapes run the ISR_DTYPE_BF16_LOG2 kernels).  The rows are ALSO held as block-scaled FP6; one
+                                v_mfma_scale_f32_32x32x64_f8f6f4 per 32 x 32 tile gives approximate logits with a proven error bound,
+                                and a (16-key lane group, 32-key tile) PIECE enters the log-sum-exp only when its largest exact logit
+                                reaches L_q - T:  L_q a true logit of the query found by a first FP6 pass (its maximum wherever the
+                                softmax has a clear winner), T = 21 + ceil(log2 N) log2 units.  Pieces the screen proves to lie below
+                                that are never formed; the others are formed on the bf16 matrix cores from the original rows.
+                                idx: as ISR_DTYPE_BF16_LOG2 (exact).  logp / lse: the left-out pieces sum to < 2^-21 of the total (5e-7
+                                in lse); a function of (query, keys) only, bit-identical whatever else is in the launch.  For data
+                                whose softmax is peaked (descriptor matching); on flat logits nothing can be skipped and the call
+                                costs about 1.5 x the unscreened one (a first pass, then the dense kernel with the same rule). */
 
 typedef void* isr_stream_t; /* hipStream_t */
 
@@ -70,8 +84,7 @@ int isr_device_count(void);
 #define ISR_TUNE_EP_WSUM_VALU 8  /* 0 (default) the sampler's chunk sums form their logits on the f32 MFMA | 1 on VALU fma chains (same bits) */
 #define ISR_TUNE_K1_F32_CHAIN 9  /* f32 queries: 0 / 3 (default) f16 planes on the matrix cores, exact f32-chain recheck, falls through to the chain kernel when a descriptor does not fit f16 | 1 the f32-MFMA chain kernel | 2 three bf16 planes (D <= 64; chain kernel above) | 4 round 3 96-wide rows (D <= 16) */
 #define ISR_TUNE_K1_SPLIT 10     /* 0 (default) K1 picks its number of key ranges | n > 0 forced (capped); results do not depend on it */
-#define ISR_TUNE_K1_SKIP 11      /* EXPERIMENT (bf16 log2, D = 64): 0 off | 1 skip every tile (timing only) | 2 skip none | 3 bounds from the shipped kernel's winners */
-#define ISR_TUNE_COUNT 12
+#define ISR_TUNE_COUNT 11
 int isr_tuning_set(int knob, int value);
 int isr_tuning_get(int knob);
 
@@ -110,8 +123,10 @@ int isr_corr_argmax_recheck_count(const void* ws, size_t ws_bytes, int P, int N,
 int isr_corr_argmax_recheck_count_f32(const void* ws, size_t ws_bytes, int P, int N, int D, int32_t* count_host,
                                       isr_stream_t stream);
 
-/* Diagnostics (the screened bf16 route): how many (32-query block, 32-key tile) items the last isr_corr_argmax call on this
- * workspace redid on the bf16 matrix cores after its FP6 screen; 0 on every other route.  count_host: HOST pointer (int64). */
+/* Diagnostics (ISR_DTYPE_BF16_LOG2_SCREENED): count_host[0] = how many (32-query block, 32-key tile) items the last
+ * isr_corr_argmax call on this workspace fetched again and redid on the bf16 matrix cores behind its FP6 screen,
+ * count_host[1] = how many 256-query blocks it handed to the dense kernel; zeros on every other route.  HOST pointer
+ * (two int64). */
 int isr_corr_argmax_screen_redone(const void* ws, size_t ws_bytes, int P, int N, int dtype, long long* count_host,
                                   isr_stream_t stream);
 

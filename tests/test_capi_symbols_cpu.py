@@ -30,7 +30,7 @@ def test_no_stub_left():
 
 
 def test_abi_version_and_errors(hip_lib):
-    assert hip_lib.isr_abi_version() == 4
+    assert hip_lib.isr_abi_version() == 5
     assert hip_lib.isr_nn_batched_workspace_bytes(0, 10, 1) == 0
     # null clouds -> ISR_ERR_ARG with a message, no device access
     rc = hip_lib.isr_nn_batched(None, 4, None, 4, None, None, 1, -1.0, None, None, None, None, None, None,

@@ -22,18 +22,18 @@ def data(P, N, seed, planted=True, scale=1.0):
 
 
 def run(q, k, mode, reps=0):
-    with ops.tuning(k1_skip=mode):
-        idx, logp, lse = ops.corr_argmax(q, k, want_lse=True, log2_prescaled=True)
+    if True:
+        idx, logp, lse = ops.corr_argmax(q, k, want_lse=True, log2_prescaled=True, screened=(mode == 5))
         torch.cuda.synchronize()
         ms = 0.0
         if reps:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                ops.corr_argmax(q, k, want_lse=True, log2_prescaled=True)
+                ops.corr_argmax(q, k, want_lse=True, log2_prescaled=True, screened=(mode == 5))
             e1.record(); torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-        red = ops.corr_screen_redone()
+        red = ops.corr_screen_redone()[0]
         rc = ops.corr_recheck_count()
         clk = ops.corr_clock_mhz()
     return idx, logp, lse, ms, red, rc, clk

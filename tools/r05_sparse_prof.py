@@ -13,8 +13,8 @@ K = 8.0 * K / K.norm(dim=1, keepdim=True)
 gt = torch.randint(N, (P,), device=dev, generator=g)
 Q = K[gt] + 0.35 * torch.randn(P, D, device=dev, generator=g)
 q, k = ops.prescale_queries_log2(Q), K.bfloat16()
-with ops.tuning(k1_skip=mode):
+if True:
     for _ in range(12):
-        ops.corr_argmax(q, k, want_lse=True, log2_prescaled=True)
+        ops.corr_argmax(q, k, want_lse=True, log2_prescaled=True, screened=(mode == 5))
     torch.cuda.synchronize()
 print("done")
