@@ -67,9 +67,12 @@ def parse_args():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the images are pipelined over")
     ap.add_argument("--group", type=int, default=32, help="images per K1 launch (1 = one launch per image)")
     ap.add_argument("--refine-iters", type=int, default=6, help="Gauss-Newton refit iterations after RANSAC")
-    ap.add_argument("--k1", choices=("log2", "natural"), default="log2",
+    ap.add_argument("--k1", choices=("log2", "natural", "screened"), default="log2",
                     help="log2: descriptors multiplied by log2(e) before their one rounding to bf16 "
-                         "(ISR_DTYPE_BF16_LOG2, the direct-sum kernel); natural: plain bf16 (ISR_DTYPE_BF16)")
+                         "(ISR_DTYPE_BF16_LOG2, the direct-sum kernel); natural: plain bf16 (ISR_DTYPE_BF16); screened: the log2 "
+                         "rows behind the FP6 screen (ISR_DTYPE_BF16_LOG2_SCREENED, round 5) — pays only where the softmax is "
+                         "peaked beyond f32 resolution (--tau >= 7); at the bench's tau = 5 every term of the sums counts, the "
+                         "screen can skip nothing and the call costs 1.4 x the unscreened one (profiles/r05_k1_screen.txt)")
     ap.add_argument("--tau", type=float, default=5.0, help="descriptor norm |k| (softmax sharpness), see make_model")
     ap.add_argument("--depth", type=int, default=1,
                     help="how many batches the registration may run ahead of the verification (step overlap)")
@@ -164,7 +167,7 @@ def cpu_baseline(args, keys_bf16, pts, Q0, pix0, Kcam, upper, lower, cad, R_gt, 
     cores = min(len(os.sched_getaffinity(0)), args.cpu_threads)
     P, N = Q0.shape[0], keys_bf16.shape[0]
     Ps = min(P, 4096)
-    scale = ops.LOG2E if args.k1 == "log2" else 1.0
+    scale = ops.LOG2E if args.k1 != "natural" else 1.0
     q_full = Q0.float().cpu() / scale
     q = q_full[:Ps]
     k = keys_bf16.float().cpu()
@@ -398,7 +401,7 @@ def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower,
     rows = min(1024, Q_rows.shape[0])
     step = max(1, Q_rows.shape[0] // rows)
     q = Q_rows[::step][:rows].contiguous()
-    idx_dev, _ = ops.corr_argmax(q, keys, log2_prescaled=model.log2_queries)
+    idx_dev, _ = ops.corr_argmax(q, keys, log2_prescaled=model.log2_queries, screened=model.screened)
     bits = lambda x: x.cpu().view(torch.int16).numpy().view(np.uint16)
     o = cbind.corr_argmax_bf16(bits(q), bits(keys), logit_scale=float(np.log(2.0)) if model.log2_queries else 1.0)
     out["k1_rows_checked"] = int(rows)
@@ -408,7 +411,7 @@ def parity_check(args, model, Q_rows, keys, pts, last, R_gt, t_gt, upper, lower,
         # rank's first image, against the same rows through a launch of their own with the GPU idle: a result is a function
         # of (query, keys) only, so both must be the same bits
         idx_step, logp_step = last["_k1_first"]
-        idx_alone, logp_alone = ops.corr_argmax(Q_rows, keys, log2_prescaled=model.log2_queries)
+        idx_alone, logp_alone = ops.corr_argmax(Q_rows, keys, log2_prescaled=model.log2_queries, screened=model.screened)
         out["k1_in_step_equals_alone"] = bool(torch.equal(idx_step, idx_alone) and torch.equal(logp_step, logp_alone))
     poses = np.asarray(last["poses_all"], np.float64).reshape(-1, 3, 4)
     n = poses.shape[0]
@@ -537,7 +540,7 @@ def main():
     Kcam = synth.camera(args.width, args.height)
     keys_f32, pts, upper, lower, cad = make_model(dev, N, D, args.tau, args.object)
     keys = keys_f32.bfloat16().contiguous()
-    model = sequence.SequenceModel(keys=keys, pts=pts, log2_queries=args.k1 == "log2")
+    model = sequence.SequenceModel(keys=keys, pts=pts, log2_queries=args.k1 != "natural", screened=args.k1 == "screened")
     cad_d = torch.from_numpy(cad).to(dev)
     diameter = synth.diameter(pts.cpu().numpy())
     rng = np.random.default_rng(99)
@@ -547,7 +550,7 @@ def main():
     Q_all = torch.empty((n_local, P, D), dtype=torch.bfloat16, device=dev)
     pix_all = torch.empty((n_local, P, 2), dtype=torch.float32, device=dev)
     for j, i in enumerate(range(lo, hi)):
-        Q_all[j], pix_all[j] = make_image(dev, keys_f32, pts, Kcam, R_gt[i], t_gt[i], P, i, args.k1 == "log2")
+        Q_all[j], pix_all[j] = make_image(dev, keys_f32, pts, Kcam, R_gt[i], t_gt[i], P, i, args.k1 != "natural")
     images = [(Q_all[j], pix_all[j]) for j in range(n_local)]
     torch.cuda.synchronize()
 
@@ -664,20 +667,37 @@ def main():
     run_steps(0, args.warmup, args.confidence)
     # K1 with the chip to itself (untimed region, rank 0): the in-step figure below shares the GPU with the
     # RANSAC chains and the previous batch's verification, this one is the kernel alone
-    k1_alone_ms = k1_clock_mhz = k1_rechecked = None
+    k1_alone_ms = k1_clock_mhz = k1_rechecked = k1_screen = None
     if rank == 0:
         g_rows = Q_all[:max(args.group, 1)].reshape(-1, D)
-        ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries)
+        ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries, screened=model.screened)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(2):
-            ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries)
+            ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries, screened=model.screened)
         e1.record()
         torch.cuda.synchronize()
         k1_alone_ms = e0.elapsed_time(e1) / 2
         k1_clock_mhz = ops.corr_clock_mhz()        # shader clock held under the kernel (s_memtime / s_memrealtime)
         k1_rechecked = ops.corr_recheck_count()
+        if model.screened:
+            redone, handed = ops.corr_screen_redone()
+            items = (g_rows.shape[0] // 32) * ((N + 31) // 32)
+            # the same rows through the unscreened log2-domain kernel, alone: what the screen is measured against
+            ops.corr_argmax(g_rows, model.keys, log2_prescaled=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(2):
+                ops.corr_argmax(g_rows, model.keys, log2_prescaled=True)
+            e1.record()
+            torch.cuda.synchronize()
+            k1_screen = {"tile_items_fetched_and_redone_frac": redone / items, "query_blocks_handed_to_the_dense_kernel": handed,
+                         "T_log2_units": 21 + int(np.ceil(np.log2(N))),
+                         "unscreened_kernel_alone_ms_per_launch": e0.elapsed_time(e1) / 2,
+                         "note": "ISR_DTYPE_BF16_LOG2_SCREENED: every tile through one FP6 matrix instruction twice (pass 0: the "
+                                 "query's lower bound L_q; pass 1: the screen), bf16 logits only for tiles that can hold a piece "
+                                 "within T of L_q; flop_per_launch stays the ALGORITHMIC 2 P N D"}
     # untimed region, rank 0: the brute-force NN rate at the Chamfer-pair shape and the exact-f32 K1 on one image
     nn_live = f32_exact = nn_vote = k2_live = None
     if rank == 0:
@@ -685,7 +705,7 @@ def main():
         k2_live = measure_ransac(dev, pts, Kcam, M=int(0.8 * P), H=max(args.itr, 4096))
         if args.verify == "vote":
             nn_vote = measure_nn_vote(cad_d, pts, dev, items=min(4096, n_local * n_total))
-        f32_exact = measure_k1_f32(Q_all[0], keys_f32, dev, args.k1 == "log2")
+        f32_exact = measure_k1_f32(Q_all[0], keys_f32, dev, args.k1 != "natural")
     ops.enable_timing(True)
     last, dt, dts = timed(args.warmup, args.steps, args.confidence)
     timing = ops.drain_timing()
@@ -768,8 +788,11 @@ def main():
             "per_rank_ms_per_step": {"min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
                                      "all": [d / args.steps * 1e3 for d in dts]},
             "ransac_all_hypotheses": all_hyp,
-            "roofline": {"kernel": ("corr_bf16_direct_kernel" if args.k1 == "log2" else "corr_bf16_kernel")
+            "roofline": {"kernel": ({"screened": "corr_quant_fp6_kernel x2 + corr_fp6_lower_kernel + corr_fp6_sparse_kernel (the whole "
+                                                 "isr_corr_argmax call; HIP events around it)",
+                                     "log2": "corr_bf16_direct_kernel", "natural": "corr_bf16_kernel"}[args.k1])
                                    + " (K1 getCors: MFMA GEMM + online LSE + argmax)",
+                         "screen": k1_screen,
                          "k1_domain": args.k1,
                          "bound": "mfma", "achieved": k1 * 1e-12, "peak": PEAK_BF16_MFMA * 1e-12,
                          "unit": "TFLOP/s", "frac": k1 / PEAK_BF16_MFMA, "traffic": traffic, "traffic_source": traffic_src,

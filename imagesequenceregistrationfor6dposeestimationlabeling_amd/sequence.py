@@ -21,6 +21,7 @@ class SequenceModel:
     keys: torch.Tensor   # (N, D) descriptors on the device, bf16 (MFMA bf16 path) or f32 (exact path)
     pts: torch.Tensor    # (N, 3) f32 surface points, mm
     log2_queries: bool = False   # bf16 queries carry a log2(e) prescale (ops.prescale_queries_log2)
+    screened: bool = False       # with log2_queries: ISR_DTYPE_BF16_LOG2_SCREENED (K1 behind the FP6 screen; peaked softmaxes)
 
 
 @dataclass
@@ -44,7 +45,7 @@ def register_image(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
     if timing is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    idx, logp = ops.corr_argmax(queries, model.keys, log2_prescaled=model.log2_queries)
+    idx, logp = ops.corr_argmax(queries, model.keys, log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
     if timing is not None:
         e1.record()
         timing.append((e0, e1))
@@ -72,7 +73,7 @@ def register_crop(model: SequenceModel, feat: torch.Tensor, mask: torch.Tensor, 
         dtype = "f32"
     Q, pix, n_dev = ops.prep_queries(feat, mask, c0=c0, D=D, step=down_sample, dtype=dtype)
     keys = model.keys if model.keys.shape[1] == Q.shape[1] else ops._pad_cols(model.keys, Q.shape[1])
-    idx, logp = ops.corr_argmax(Q, keys, log2_prescaled=model.log2_queries)
+    idx, logp = ops.corr_argmax(Q, keys, log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
     keep, M, _ = ops.select_top(logp, n_dev=n_dev)
     p3d, p2d = ops.gather_corr(idx, keep, M, model.pts, pix)
     r = ops.pnp_ransac(p3d, p2d, cam, H=itr, reperr=reperr, seed=seed, refine_iters=refine_iters, M_dev=M,
@@ -144,7 +145,7 @@ def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tenso
             if keys is None:
                 keys = model.keys if model.keys.shape[1] == Q.shape[2] else ops._pad_cols(model.keys, Q.shape[2])
             S = Q.shape[1]
-            idx_g, logp_g = ops.corr_argmax(Q.view(B * S, -1), keys, log2_prescaled=model.log2_queries)
+            idx_g, logp_g = ops.corr_argmax(Q.view(B * S, -1), keys, log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
             if not serial:
                 done = torch.cuda.Event()
                 done.record(k1_stream)
@@ -236,7 +237,7 @@ def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: f
     out = []
     for j, (q, pix) in enumerate(images):
         with torch.cuda.stream(k1_stream):
-            idx, logp = ops.corr_argmax(q, model.keys, log2_prescaled=model.log2_queries)
+            idx, logp = ops.corr_argmax(q, model.keys, log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
             done = torch.cuda.Event()
             done.record(k1_stream)
         s = side[j % len(side)]
@@ -296,7 +297,7 @@ def register_block(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
         g1 = min(n, g0 + group)
         with torch.cuda.stream(k1_stream):
             idx_g, logp_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys,
-                                             log2_prescaled=model.log2_queries)
+                                             log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
             done = torch.cuda.Event()
             done.record(k1_stream)
         s = side[gi % len(side)]
