@@ -204,11 +204,48 @@ __device__ __forceinline__ f32x16 mfma16(const bf16x8& a, const bf16x8& b, const
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// TIMING-ONLY ablation ISR_ABL_MFMA16 (profiles/r05_k1_mfma_shape_ab.txt): two 16-wide blocks (a0, b0), (a1, b1) of a 32 x 32
+// tile through FOUR v_mfma_f32_16x16x32 sub-tile instructions instead of two v_mfma_f32_32x32x16 — the same matrix cycles from
+// the same fragments; the numbers are not the tile's logits (the fragments keep the 32x32x16 layout)
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma16_pair_as_16x16x32(const bf16x8& a0, const bf16x8& a1, const bf16x8& b0, const bf16x8& b1, f32x16 c) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    f32x4 t = f32x4{c[4 * u], c[4 * u + 1], c[4 * u + 2], c[4 * u + 3]};
+    const bf16x8& a = (u & 1) ? a1 : a0;
+    const bf16x8& b = (u >> 1) ? b1 : b0;
+    if constexpr (F16) t = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), t, 0, 0, 0);
+    else t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, t, 0, 0, 0);
+    c[4 * u] = t[0]; c[4 * u + 1] = t[1]; c[4 * u + 2] = t[2]; c[4 * u + 3] = t[3];
+  }
+  return c;
+}
+
 template <int DK, int SP, bool F16 = false>
 __device__ __forceinline__ f32x16 tile_chain(const bf16x8 (&a)[RowFrags<DK, SP>::NFR], const bf16x8 (&b)[RowFrags<DK, SP>::NFR],
                                              f32x16 c) {
   using RF = RowFrags<DK, SP, F16>;
   if constexpr (SP == 0) {
+#if defined(ISR_ABL_MFMA16)
+    // TIMING-ONLY ablation (profiles/r05_k1_mfma_shape_ab.txt): the item's operand registers through v_mfma_f32_16x16x32_bf16 —
+    // per 32 x 32 item four 16 x 16 sub-tiles x DK / 2 k-steps of 32, i.e. 2 DK instructions of half the cycles from the same
+    // 2 DK fragments, 16 results per lane.  The fragments are the 32x32x16 layout's, so the numbers are NOT the tile's logits
+    // (random dot products of the same rows): instruction mix, register use, LDS traffic and operand data are the real loop's.
+    if constexpr (DK % 2 == 0) {
+      using f32x4 = __attribute__((ext_vector_type(4))) float;
+      f32x4 t[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t[u] = f32x4{c[4 * u], c[4 * u + 1], c[4 * u + 2], c[4 * u + 3]};
+#pragma unroll
+      for (int ks = 0; ks < DK / 2; ++ks)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          t[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(u & 1) * (DK / 2) + ks], b[(u >> 1) * (DK / 2) + ks], t[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { c[4 * u] = t[u][0]; c[4 * u + 1] = t[u][1]; c[4 * u + 2] = t[u][2]; c[4 * u + 3] = t[u][3]; }
+    } else
+#endif
 #pragma unroll
     for (int s = 0; s < DK; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], b[s], c, 0, 0, 0);
   } else {

@@ -415,7 +415,14 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
           auto phase = [&](auto ph_tag) {
             constexpr int ph = decltype(ph_tag)::value;
 #pragma unroll
+#if defined(ISR_ABL_MFMA16)
+            for (int j = 0; j + 1 < SP; j += 2)
+              c = mfma16_pair_as_16x16x32<F16>(a[RF::PA[ph] * SP + j], a[RF::PA[ph] * SP + j + 1], bq[qbn][RF::PB[ph] * SP + j],
+                                               bq[qbn][RF::PB[ph] * SP + j + 1], c);
+            if constexpr (SP % 2 == 1) c = mfma16<F16>(a[RF::PA[ph] * SP + SP - 1], bq[qbn][RF::PB[ph] * SP + SP - 1], c);
+#else
             for (int j = 0; j < SP; ++j) c = mfma16<F16>(a[RF::PA[ph] * SP + j], bq[qbn][RF::PB[ph] * SP + j], c);
+#endif
             if constexpr (RF::RD[ph] >= 0) reads(RF::RD[ph]);
 #pragma unroll
             for (int i = RF::E0[ph]; i < RF::E0[ph + 1]; ++i) {
@@ -428,7 +435,11 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
             constexpr int gv = (nv + SP - 1) / SP;
 #pragma unroll
             for (int j = 0; j < SP; ++j) {
+#if defined(ISR_ABL_MFMA16)
+              __builtin_amdgcn_sched_group_barrier(0x008, SP % 2 == 0 ? 2 : 1, 0);
+#else
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#endif
               if (reload && RF::RD[ph] >= 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
               if constexpr (gv > 0) __builtin_amdgcn_sched_group_barrier(0x002, gv, 0);
             }
@@ -465,7 +476,14 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
           auto phase = [&](auto ph_tag) {
             constexpr int ph = decltype(ph_tag)::value;
 #pragma unroll
+#if defined(ISR_ABL_MFMA16)
+            for (int j = 0; j + 1 < SP; j += 2)
+              c = mfma16_pair_as_16x16x32<F16>(a[RF::PA[ph] * SP + j], a[RF::PA[ph] * SP + j + 1], bq[qbn][RF::PB[ph] * SP + j],
+                                               bq[qbn][RF::PB[ph] * SP + j + 1], c);
+            if constexpr (SP % 2 == 1) c = mfma16<F16>(a[RF::PA[ph] * SP + SP - 1], bq[qbn][RF::PB[ph] * SP + SP - 1], c);
+#else
             for (int j = 0; j < SP; ++j) c = mfma16<F16>(a[RF::PA[ph] * SP + j], bq[qbn][RF::PB[ph] * SP + j], c);
+#endif
             if constexpr (RF::RD[ph] >= 0) reads(RF::RD[ph]);
             if constexpr (ph == 0 && TRK) {
               const float t = tile_max(cur);
@@ -481,7 +499,11 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
             constexpr int gv = (nv + SP - 1) / SP;
 #pragma unroll
             for (int j = 0; j < SP; ++j) {
+#if defined(ISR_ABL_MFMA16)
+              __builtin_amdgcn_sched_group_barrier(0x008, SP % 2 == 0 ? 2 : 1, 0);
+#else
               __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+#endif
               if (reload && RF::RD[ph] >= 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
               if constexpr (gv > 0) __builtin_amdgcn_sched_group_barrier(0x002, gv, 0);
             }
