@@ -93,6 +93,7 @@ def parse_args():
                          "surface of revolution of BASELINE configs[3], descriptors constant along the azimuth up to a weak term")
     ap.add_argument("--no-estimate-pose", action="store_true", help="skip the untimed estimate_pose / reference-shape timings")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed oracle re-computation of the last step")
+    ap.add_argument("--no-f32-step", action="store_true", help="skip the untimed step on f32 descriptors (the reference's precision)")
     return ap.parse_args()
 
 
@@ -327,13 +328,20 @@ def measure_k1_f32(Q_img, keys_f32, dev, log2_domain):
     ms_chain, out_chain, _ = timed(1)
     planes = rechecked >= 0
     Dp = 16 if D <= 16 else 32 if D <= 32 else 64
+    issued = 3.0 * flop * Dp / D                      # f16 planes: three plane pairs per 16-wide block, padded width Dp
     return {"kernel": ("corr_bf16_direct_kernel<.., SP, F16> (f16 planes of the f32 rows, 3 plane pairs per block, exact f32-chain "
                        "recheck)" if planes else "corr_f32_kernel (exact f32 MFMA path)"),
-            "ms_per_image": ms, "achieved": flop / (ms * 1e-3) * 1e-12, "peak": PEAK_FP32_MFMA * 1e-12, "unit": "TFLOP/s",
-            "frac": flop / (ms * 1e-3) / PEAK_FP32_MFMA,
-            "matrix_instruction_flop_frac_of_16bit_peak": (3.0 * flop * Dp / D / (ms * 1e-3) / PEAK_BF16_MFMA) if planes else None,
+            "ms_per_image": ms,
+            # a roofline fraction is ISSUED work over the peak of the pipe it is issued on (round 4 divided the useful f32 FLOPs by
+            # the f32 matrix peak for a kernel that runs on the 16-bit pipe: 2.03, not a fraction)
+            "bound": "mfma (16-bit pipe)" if planes else "mfma (f32 pipe)",
+            "achieved": (issued if planes else flop) / (ms * 1e-3) * 1e-12, "peak": (PEAK_BF16_MFMA if planes else PEAK_FP32_MFMA) * 1e-12,
+            "unit": "TFLOP/s", "frac": (issued / PEAK_BF16_MFMA if planes else flop / PEAK_FP32_MFMA) / (ms * 1e-3),
+            "useful_f32_tflops": flop / (ms * 1e-3) * 1e-12,
+            "useful_f32_flops_over_f32_matrix_peak": flop / (ms * 1e-3) / PEAK_FP32_MFMA,
             "queries_decided_by_f32_chain_recheck": rechecked,
-            "bf16_planes": {"ms_per_image": ms_bf, "frac": flop / (ms_bf * 1e-3) / PEAK_FP32_MFMA,
+            "bf16_planes": {"ms_per_image": ms_bf, "frac": 6.0 * flop * Dp / D / (ms_bf * 1e-3) / PEAK_BF16_MFMA,
+                            "useful_f32_flops_over_f32_matrix_peak": flop / (ms_bf * 1e-3) / PEAK_FP32_MFMA,
                             "idx_equal": bool(torch.equal(out[0], out_bf[0]))},
             "f32_mfma_chain_kernel": {"ms_per_image": ms_chain, "achieved": flop / (ms_chain * 1e-3) * 1e-12,
                                       "frac": flop / (ms_chain * 1e-3) / PEAK_FP32_MFMA},
@@ -561,7 +569,7 @@ def main():
         the next step's first K1 launch must not inherit that wait."""
         with torch.cuda.stream(reg_streams[s & 1]):
             if args.group > 1:
-                res = sequence.register_block(model, Q_all, pix_all, Kcam, itr=args.itr, reperr=2.0,
+                res = sequence.register_block(cur["model"], cur["Q"], pix_all, Kcam, itr=args.itr, reperr=2.0,
                                               seed0=(s << 20) + lo, refine_iters=args.refine_iters,
                                               n_streams=args.streams, group=args.group, confidence=confidence)
             else:
@@ -574,6 +582,7 @@ def main():
             ev.record(reg_streams[s & 1])
         return poses, status, n_eval, ev, (res[0].idx, res[0].logp)
 
+    cur = {"model": model, "Q": Q_all}      # what register() runs on (the f32 step below swaps both)
     reg_streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
     tail_stream = torch.cuda.Stream(device=dev, priority=-1)
 
@@ -746,6 +755,31 @@ def main():
                    "ransac_confidence": 1.0, "hypotheses_scored_mean": last_all.get("hypotheses_scored_mean"),
                    "note": "same step, every one of the --itr hypotheses scored (round 1's rule); not `value`"}
 
+    # UNTIMED: the same step at the reference's own precision (inference.py:142-149 is an f32 matmul): f32 keys, f32 queries,
+    # K1 on the f16-plane route; a few steps, every rank (the step has collectives)
+    f32_step = None
+    if args.group > 1 and args.ablate != "noverify" and not args.no_f32_step:
+        k = max(2, min(4, args.steps))
+        cur["model"] = sequence.SequenceModel(keys=keys_f32, pts=pts)
+        cur["Q"] = (Q_all.float() / (ops.LOG2E if args.k1 != "natural" else 1.0)).contiguous()
+        run_steps(args.warmup + 2 * args.steps, 1, args.confidence)
+        last32, dt32, _ = timed(args.warmup + 2 * args.steps + 1, k, args.confidence)
+        f32_step = {"value": n_total * k / dt32, "unit": "images/s", "steps": k, "ms_per_step": dt32 / k * 1e3,
+                    "dtype": "f32 descriptors (K1: f16 planes on the 16-bit matrix cores, exact f32-chain indices)",
+                    "final_chamfer": last32.get("final_chamfer"), "registered_this_rank": last32.get("registered_this_rank"),
+                    "note": "the same step on f32 keys and queries — the reference's precision; not `value`"}
+        if rank == 0 and not args.no_parity_check:
+            from oracle import cbind
+            rows = cur["Q"][0][:: max(1, P // 1024)][:1024].contiguous()
+            idx_dev, logp_dev = ops.corr_argmax(rows, keys_f32)
+            o = cbind.corr_argmax_f32(rows.cpu().numpy(), keys_f32.cpu().numpy())
+            f32_step["parity_check"] = {"k1_rows_checked": int(rows.shape[0]),
+                                        "k1_idx_equal_rows": int((idx_dev.cpu().numpy() == o["idx"]).sum()),
+                                        "k1_logp_max_abs": float(np.abs(logp_dev.cpu().numpy() - (o["maxlogit"].astype(np.float64) - o["lse"])).max()),
+                                        "picked_image": last32.get("picked_image"), "rot_err_rad": last32.get("rot_err_rad"),
+                                        "trans_err_mm": last32.get("trans_err_mm")}
+        cur["model"], cur["Q"] = model, Q_all
+
     if rank == 0:
         calls, ms, flop = timing.get("corr_argmax", (0, 0.0, 0.0))
         k1_ms = ms / max(calls, 1)
@@ -788,6 +822,7 @@ def main():
             "per_rank_ms_per_step": {"min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
                                      "all": [d / args.steps * 1e3 for d in dts]},
             "ransac_all_hypotheses": all_hyp,
+            "f32_step": f32_step,
             "roofline": {"kernel": ({"screened": "corr_quant_fp6_kernel x2 + corr_fp6_lower_kernel + corr_fp6_sparse_kernel (the whole "
                                                  "isr_corr_argmax call; HIP events around it)",
                                      "log2": "corr_bf16_direct_kernel", "natural": "corr_bf16_kernel"}[args.k1])

@@ -796,3 +796,30 @@ def test_mfma_f16_keeps_subnormal_inputs(cuda0, tmp_path):
     tiny = float(out[1].split(":")[1].split()[0])          # 16 products of 2^-14 x 2^-24 (the smallest subnormal)
     assert kept == 2.0 ** -6
     assert tiny == 16.0 * 2.0 ** -38
+
+
+@pytest.mark.gpu
+def test_corr_f32_full_size_properties(cuda0, oracle_lib):
+    """The reference's precision at BASELINE configs[1]'s full size: 640 x 480 f32 queries of 64 dimensions against
+    20 000 f32 keys (inference.py:142-149 is an f32 matmul) on the default f16-plane route.  768 sampled rows against the C
+    oracle's k-ordered f32 chain (indices array_equal, logp 3e-5); the whole index vector torch.equal to the f32-MFMA chain
+    kernel's (ISR_TUNE_K1_F32_CHAIN = 1); a slice computed in a launch of its own carries the same bits."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(64)
+    P, N, D = 307200, 20000, 64
+    Q, K, gt = _planted(rng, P, N, D, tau=5.0)
+    q, k = torch.from_numpy(Q).to(cuda0), torch.from_numpy(K).to(cuda0)
+    idx, logp, lse = ops.corr_argmax(q, k, want_lse=True)
+    torch.cuda.synchronize()
+    assert ops.corr_recheck_count_f32(D) >= 0                      # the plane route ran (not the fall-through)
+    rows = rng.choice(P, 768, replace=False)
+    o = oracle_lib.corr_argmax_f32(Q[rows], K)
+    assert np.array_equal(idx.cpu().numpy()[rows], o["idx"])
+    np.testing.assert_allclose(logp.cpu().numpy()[rows], o["maxlogit"].astype(np.float64) - o["lse"], atol=3e-5)
+    np.testing.assert_allclose(lse.cpu().numpy()[rows], o["lse"], rtol=2e-6, atol=3e-5)
+    with ops.tuning(k1_f32_chain=1):
+        idx_c, logp_c = ops.corr_argmax(q, k)
+    assert torch.equal(idx, idx_c)
+    assert float((logp - logp_c).abs().max()) < 3e-5
+    part = ops.corr_argmax(q[200000:200900].contiguous(), k, want_lse=True)
+    assert torch.equal(part[0], idx[200000:200900]) and torch.equal(part[1], logp[200000:200900]) and torch.equal(part[2], lse[200000:200900])
