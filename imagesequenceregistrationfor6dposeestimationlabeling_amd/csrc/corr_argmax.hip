@@ -782,11 +782,15 @@ __device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, b
   }
 }
 
-__device__ __forceinline__ float kn2_max(const CorrWs& ws) {      // every lane of the wave gets max_n |k_n|^2
+// max_n |k_n|^2 as a SCALAR (every lane holds the same value after the butterfly; readfirstlane moves it to an SGPR, where it
+// costs the loop nothing to keep: called twice from the direct kernel, the vector form left its six shuffle addresses alive
+// across the loop for the second call, and in the 168-register plain-row kernel that was three spilled registers per lane —
+// the 12 B per query of scratch traffic behind profiles/k1_hbm_traffic.json's 2.5 x write figure)
+__device__ __forceinline__ float kn2_max(const CorrWs& ws) {
   float v = ws.kn2[threadIdx.x & 63];
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  return __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(v)));
 }
 
 #include "corr_direct.hpp"   // corr_bf16_direct_kernel: the VALU-minimal bf16 loop (log2 and natural units)

@@ -153,7 +153,12 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
   // every chunk of its queries, adds the chunk sums in f64 in ascending order itself — the very operations
   // corr_finalize_kernel performs on the stored chunk sums — and finishes its good queries in its epilogue.
   const bool whole = gridDim.y == 1;
-  // |q|^2 for the error bound of the margin test (f32, upper bound to rounding; corr_finish inflates it)
+  const float kn2_all = kn2_max(ws);            // max |k|^2, a scalar: read once, used by the screen, the range bound and the epilogue
+  // |q|^2 for the error bound of the margin test (f32, upper bound to rounding; corr_finish inflates it).  The epilogue's copy
+  // waits in LDS (2 KB per workgroup), not in registers: the plain-row kernel sits at its 168-register budget and used to
+  // spill three registers per lane to scratch — 12 B written and read back per query, the whole of the 2.5 x write traffic
+  // profiles/k1_hbm_traffic.json showed against 8 B of outputs per query.
+  __shared__ float qn2_keep[QB][kThreads];
   float qn2[QB];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
@@ -167,6 +172,7 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
       }
     n2 += __shfl_xor(n2, 32, 64);
     qn2[qb] = n2;
+    qn2_keep[qb][tid] = n2;
     const int q = q0 + qb * 32 + r;
     if (!whole && split == 0 && h == 0 && q < P) ws.qn2[q] = n2;
   }
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
     }
     if (!__syncthreads_or(nonzero ? 1 : 0)) {
       if (whole) {
-        const float kn2z = kn2_max(ws);
+        const float kn2z = kn2_all;
 #pragma unroll
         for (int qb = 0; qb < QB; ++qb) {
           const int q = q0 + qb * 32 + r;
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
   // 1 %, plus 1e-4 for v_exp_f32 (1 ulp), the 15 additions of ts and the rounding of M - dlt (|M| < 128: 8e-6)
   float dlt[QB];
   {
-    const float kn2s = kn2_max(ws);
+    const float kn2s = kn2_all;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb)
       dlt[qb] = 2.02f * ((float)(DEFF + 2) * 1.1920929e-7f * 1.0001f * __builtin_sqrtf(qn2[qb] * kn2s) +
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
   // log2 units keeps every term a normal f32 and the maximum above kLow: the full kernel calls such a query good too.)
   bool trk = true;
   if constexpr (LSE) {
-    const float kn2l = kn2_max(ws);
+    const float kn2l = kn2_all;
     bool unsure = false;
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) unsure |= !((NAT ? kLog2e * kLog2e : 1.f) * qn2[qb] * kn2l < kLseBound2);
@@ -791,7 +797,7 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
   if (!whole) return;
   // ---- one key range: finish the good queries here (corr_finalize_kernel only revisits workgroups with a
   // bad query, and needs the per-query marks only then)
-  const float kn2 = kn2_max(ws);
+  const float kn2 = kn2_all;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + qb * 32 + r;
@@ -800,10 +806,10 @@ __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_PLAIN_WAVES
       ws.pbad[q] = over[qb] ? 1 : 0;
       // corr_finalize_kernel finishes the bad queries of this block and reads |q|^2 for the margin test from the
       // workspace (this launch stored it nowhere else: the split == 0 store above is the key-split route's)
-      if (over[qb]) ws.qn2[q] = qn2[qb];
+      if (over[qb]) ws.qn2[q] = qn2_keep[qb][tid];
     }
     if (!over[qb])
       corr_finish<NAT ? 2 : 1>(q, LSE ? 0.f : st[qb].m, LSE ? 0.f : st[qb].m2, LSE ? 0 : st[qb].tb, false, st[qb].L, 0.0, DEFF, EABS,
-                               qn2[qb], kn2, ws, LSE ? nullptr : idx_out, LSE ? nullptr : logp_out, lse_out);
+                               qn2_keep[qb][tid], kn2, ws, LSE ? nullptr : idx_out, LSE ? nullptr : logp_out, lse_out);
   }
 }
