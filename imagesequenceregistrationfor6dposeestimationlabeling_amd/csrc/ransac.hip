@@ -418,7 +418,10 @@ __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __r
 #define ISR_GN_SPLIT_SOLVE 1      // 0: the solve in gn_accumulate_kernel's last workgroup (round 3 .. first half of round 4)
 #endif
 constexpr int kRefThreads = 256;
-constexpr int kRefBlocks = 64;
+#ifndef ISR_REF_BLOCKS
+#define ISR_REF_BLOCKS 64
+#endif
+constexpr int kRefBlocks = ISR_REF_BLOCKS;      // workgroups per image of a Gauss-Newton accumulation
 constexpr int kNAcc = 29;  // 21 (upper J^T J) + 6 (J^T r) + 1 (sum r^2) + 1 (number of correspondences used)
 
 // One block: 28 lanes sum the block partials in order (fixed order: reproducible), lane 0 solves
