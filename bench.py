@@ -94,6 +94,7 @@ def parse_args():
     ap.add_argument("--no-estimate-pose", action="store_true", help="skip the untimed estimate_pose / reference-shape timings")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the untimed oracle re-computation of the last step")
     ap.add_argument("--no-f32-step", action="store_true", help="skip the untimed step on f32 descriptors (the reference's precision)")
+    ap.add_argument("--no-screened-step", action="store_true", help="skip the untimed |k| = 8 step pair (K1 unscreened / behind the FP6 screen)")
     return ap.parse_args()
 
 
@@ -780,6 +781,50 @@ def main():
                                         "trans_err_mm": last32.get("trans_err_mm")}
         cur["model"], cur["Q"] = model, Q_all
 
+    # UNTIMED: the step on SURVEY 8(d)'s first recipe, |k| = 8 — a softmax peaked beyond f32 resolution, where K1's FP6 screen
+    # (ISR_DTYPE_BF16_LOG2_SCREENED) can skip — unscreened and screened on the same data.  (At the bench's |k| = 5 every term
+    # of the sums counts and the screened dtype hands every block to the dense kernel: DESIGN.md section 4 K1d.)
+    screened_step = None
+    if args.group > 1 and args.ablate != "noverify" and not args.no_screened_step and D == 64 and args.k1 != "natural" and args.object == "tless":
+        keys8 = make_model(dev, N, D, tau=8.0, obj=args.object)[0]
+        Q8 = torch.empty_like(Q_all)
+        for j, i in enumerate(range(lo, hi)):
+            Q8[j] = make_image(dev, keys8, pts, Kcam, R_gt[i], t_gt[i], P, i, True)[0]
+        k = max(2, min(4, args.steps))
+        screened_step = {"descriptor_norm": 8.0, "note": "SURVEY 8(d)'s |k| = 8 data; not `value`"}
+        for name, scr in (("unscreened", False), ("screened", True)):
+            cur["model"] = sequence.SequenceModel(keys=keys8.bfloat16(), pts=pts, log2_queries=True, screened=scr)
+            cur["Q"] = Q8
+            base = args.warmup + 3 * args.steps + (8 if scr else 0)
+            run_steps(base, 1, args.confidence)
+            last8, dt8, _ = timed(base + 1, k, args.confidence)
+            screened_step[name] = {"value": n_total * k / dt8, "unit": "images/s", "ms_per_step": dt8 / k * 1e3,
+                                   "final_chamfer": last8.get("final_chamfer"), "registered_this_rank": last8.get("registered_this_rank"),
+                                   "picked_image": last8.get("picked_image")}
+            if rank == 0:
+                g_rows = Q8[:max(args.group, 1)].reshape(-1, D)
+                out8 = ops.corr_argmax(g_rows, cur["model"].keys, log2_prescaled=True, screened=scr)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(2):
+                    ops.corr_argmax(g_rows, cur["model"].keys, log2_prescaled=True, screened=scr)
+                e1.record()
+                torch.cuda.synchronize()
+                ms8 = e0.elapsed_time(e1) / 2
+                screened_step[name]["k1_alone_ms_per_launch"] = ms8
+                screened_step[name]["k1_alone_frac_of_bf16_peak"] = 2.0 * g_rows.shape[0] * N * D / (ms8 * 1e-3) / PEAK_BF16_MFMA
+                if scr:
+                    redone, handed = ops.corr_screen_redone()
+                    screened_step[name]["tile_items_fetched_and_redone_frac"] = redone / ((g_rows.shape[0] // 32) * ((N + 31) // 32))
+                    screened_step[name]["query_blocks_handed_to_the_dense_kernel"] = handed
+                    screened_step["k1_idx_equal"] = bool(torch.equal(out8[0], idx8_ref))
+                    screened_step["k1_logp_max_abs_diff"] = float((out8[1] - logp8_ref).abs().max())
+                else:
+                    idx8_ref, logp8_ref = out8
+        cur["model"], cur["Q"] = model, Q_all
+        del Q8
+
     if rank == 0:
         calls, ms, flop = timing.get("corr_argmax", (0, 0.0, 0.0))
         k1_ms = ms / max(calls, 1)
@@ -823,6 +868,7 @@ def main():
                                      "all": [d / args.steps * 1e3 for d in dts]},
             "ransac_all_hypotheses": all_hyp,
             "f32_step": f32_step,
+            "screened_step": screened_step,
             "roofline": {"kernel": ({"screened": "corr_quant_fp6_kernel x2 + corr_fp6_lower_kernel + corr_fp6_sparse_kernel (the whole "
                                                  "isr_corr_argmax call; HIP events around it)",
                                      "log2": "corr_bf16_direct_kernel", "natural": "corr_bf16_kernel"}[args.k1])

@@ -172,7 +172,7 @@ struct Q6Stream {
     u32x4 hi = *reinterpret_cast<const u32x4*>(&lds[buf * kQ6Chunks + row * 4 + key_slot<4, 0>(row, 2 * h + 1)]);
     // all four dwords of the second chunk are "used": left alone, the compiler narrows the read to ds_read_b96 (the matrix
     // instruction reads six registers and the scale), which the swizzle is not conflict-free for — 39 % of the kernels' LDS
-    // cycles were bank conflicts (profiles/r05_k1_screen_pmc.txt)
+    // cycles were bank conflicts (profiles/r05_k1_screen.txt, section 4)
     asm volatile("" : "+v"(hi));
     return i32x8{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
   }
