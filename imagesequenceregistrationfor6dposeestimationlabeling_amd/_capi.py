@@ -54,6 +54,7 @@ SIGNATURES = {
     "isr_corr_argmax_recheck_count": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_corr_argmax_recheck_count_f32": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_corr_argmax_screen_redone": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
+    "isr_corr_quantize_fp6": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "isr_corr_argmax_clock_mhz": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_adds_bounds": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _d, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "isr_corr_topk_workspace_bytes": (_sz, [_i, _i]),

@@ -1272,6 +1272,22 @@ extern "C" int isr_corr_argmax_recheck_count(const void* ws_, size_t ws_bytes, i
   return ISR_OK;
 }
 
+// Parity hook of the screened route: the block-scaled FP6 image of bf16 rows of 64 columns exactly as isr_corr_argmax forms it
+// (tests compare it with oracle/fp6_screen_oracle.py bit for bit; a caller could also keep a key image across calls one day).
+extern "C" int isr_corr_quantize_fp6(const void* X, int R, int ld, void* out, float* nrm, float* kmax, isr_stream_t stream_) {
+  ISR_REQUIRE(X && out && nrm && kmax && R > 0 && ld >= 64 && ld % 8 == 0 && ((uintptr_t)X % 16 == 0) && ((uintptr_t)out % 16 == 0),
+              "isr_corr_quantize_fp6: null pointer, R=%d, or rows not 16-byte aligned (ld=%d)", R, ld);
+  hipStream_t stream = isr::as_stream(stream_);
+  CorrWs ws{};
+  const unsigned g = (unsigned)((2l * R + 255) / 256);
+  ISR_CHECK_HIP(hipMemsetAsync(kmax, 0, 2 * sizeof(float), stream));
+  corr_quant_fp6_kernel<true><<<g, 256, 0, stream>>>(static_cast<const uint16_t*>(X), R, ld, static_cast<uint8_t*>(out), nrm, nullptr, ws);
+  corr_quant_fp6_kernel<false><<<g, 256, 0, stream>>>(static_cast<const uint16_t*>(X), R, ld, static_cast<uint8_t*>(out), nullptr,
+                                                      reinterpret_cast<uint32_t*>(kmax), ws);
+  ISR_CHECK_LAUNCH("fp6 quantisation kernels");
+  return ISR_OK;
+}
+
 // Diagnostics of the screened route: tile items redone exactly in the last call on this workspace.  Synchronises the stream.
 extern "C" int isr_corr_argmax_screen_redone(const void* ws_, size_t ws_bytes, int P, int N, int dtype, long long* count_host,
                                              isr_stream_t stream_) {

@@ -399,6 +399,23 @@ def corr_recheck_count() -> int:
     return int(out.value)
 
 
+def corr_quantize_fp6(rows: torch.Tensor):
+    """isr_corr_quantize_fp6 (parity hook of the screened K1 route): rows (R, 64) bf16 on the device ->
+    (image (R, 64) uint8, norms (R, 2) f32 {|x|, |x - x~|}, maxima (2,) f32 {max |x - x~|^2, max |x~|^2})."""
+    dev = require_cuda(rows)
+    if rows.ndim != 2 or rows.shape[1] != 64 or rows.dtype != torch.bfloat16:
+        raise ValueError(f"rows must be (R, 64) bf16, got {tuple(rows.shape)} {rows.dtype}")
+    rows = rows.contiguous()
+    R = rows.shape[0]
+    out = torch.empty((R, 64), dtype=torch.uint8, device=dev)
+    nrm = torch.empty((R, 2), dtype=torch.float32, device=dev)
+    kmax = torch.empty(2, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib().isr_corr_quantize_fp6(ptr(rows), R, 64, ptr(out), ptr(nrm), ptr(kmax), current_stream(dev))
+    check(rc, "isr_corr_quantize_fp6")
+    return out, nrm, kmax
+
+
 def corr_screen_redone() -> tuple[int, int]:
     """Diagnostics of the last screened corr_argmax call: (tile items — 32 queries x 32 keys — fetched again and redone on the
     bf16 matrix cores behind the FP6 screen, 256-query blocks handed to the dense kernel); zeros on the unscreened routes.

@@ -123,6 +123,13 @@ int isr_corr_argmax_recheck_count(const void* ws, size_t ws_bytes, int P, int N,
 int isr_corr_argmax_recheck_count_f32(const void* ws, size_t ws_bytes, int P, int N, int D, int32_t* count_host,
                                       isr_stream_t stream);
 
+/* Parity hook (ISR_DTYPE_BF16_LOG2_SCREENED): the block-scaled FP6 image of R bf16 rows of 64 columns, exactly as isr_corr_argmax
+ * forms it.  out (R, 64) bytes: per 32-element half 24 B of e2m3 codes (element j in bits [6j, 6j + 6) of the little-endian
+ * stream; bit 5 the sign), byte 24 the E8M0 scale (2^(b - 127), the smallest power of two with max|x| / scale <= 7.5), 7 zero
+ * bytes.  nrm (R, 2) f32 = {|x|, |x - x~|} inflated by 1.00001; kmax (2) f32 = max over rows of |x - x~|^2 and |x~|^2.  All on
+ * the device; X rows 16-byte aligned. */
+int isr_corr_quantize_fp6(const void* X, int R, int ld, void* out, float* nrm, float* kmax, isr_stream_t stream);
+
 /* Diagnostics (ISR_DTYPE_BF16_LOG2_SCREENED): count_host[0] = how many (32-query block, 32-key tile) items the last
  * isr_corr_argmax call on this workspace fetched again and redid on the bf16 matrix cores behind its FP6 screen,
  * count_host[1] = how many 256-query blocks it handed to the dense kernel; zeros on every other route.  HOST pointer

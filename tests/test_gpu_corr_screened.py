@@ -191,3 +191,28 @@ def test_screened_dtype_on_other_shapes_runs_the_unscreened_kernels(cuda0):
     b = ops.corr_argmax(qb, kb, want_lse=True, log2_prescaled=True, screened=True)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
     assert ops.corr_screen_redone() == (0, 0)
+
+
+def test_device_quantiser_equals_the_oracle_s_image_byte_for_byte(cuda0):
+    """isr_corr_quantize_fp6 (the kernel isr_corr_argmax runs on queries and keys) against oracle/fp6_screen_oracle.py: the 64-byte
+    row images — codes, scale bytes, padding — are equal, the norms agree to f32 rounding.  With tests/test_oracle_fp6_screen_cpu.py
+    (the bound holds for that image, and is tight) this pins the numbers the screen's proof is made of."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    from oracle import fp6_screen_oracle as fo
+    rng = np.random.default_rng(8)
+    X = np.concatenate([fo.bf16_round((rng.normal(0, 1, (3000, 64)) * s).astype(np.float32)) for s in (1.0, 0.003, 500.0, 1e-20, 1e20)])
+    X[5] = 0.0
+    X[6, 32:] = 0.0
+    X[7, 9] = 2.0e30
+    sig = np.where(rng.random(64) < 0.5, -1.0, 1.0)
+    X[8] = sig * 1.0625 * 0.25                                  # rounding midpoints (ties to even: toward zero here)
+    X[9] = sig * 1.1875
+    X[10] = 7.5
+    X[11] = 7.53                                                 # bf16(7.53) = 7.53125 > 7.5: the next scale
+    X = fo.bf16_round(X)
+    img, nrm, kmax = ops.corr_quantize_fp6(torch.from_numpy(X).bfloat16().to(cuda0))
+    torch.cuda.synchronize()
+    o = fo.quantize_e2m3(X)
+    assert np.array_equal(img.cpu().numpy(), o["image"])
+    np.testing.assert_allclose(nrm.cpu().numpy(), o["nrm"], rtol=3e-7)
+    np.testing.assert_allclose(kmax.cpu().numpy(), [o["d2"].max(), o["t2"].max()], rtol=3e-7)
