@@ -16,15 +16,17 @@
 //     |s - s~| <= |q| |dk| + |dq| |k~| + (f32 accumulation)  =: E_q       (dk = k - k~, dq = q - q~; Cauchy-Schwarz)
 // with the norms computed exactly when the rows are quantised.  A tile whose s~ stay below L_q - T - E_q for every lane is
 // skipped after 1 matrix instruction + 9 VALU; the others (the tile of a query's winner, and the few a noise tail reaches:
-// 6 % on the bench's data) are redone on the bf16 matrix cores from the ORIGINAL rows, and only those results enter sums and
-// maxima: indices, logp and lse never see an FP6 number.
+// 5 % + 1.5 % on |k| = 8 planted data) are formed on the bf16 matrix cores from the ORIGINAL rows, and only those results enter
+// sums and maxima: indices, logp and lse never see an FP6 number.
 //
 // L_q: pass 0 (corr_fp6_lower_kernel) finds, per query, the LOWEST 32-key tile holding the largest s~ (a deterministic
 // function of the two quantised rows), redoes that tile in bf16 and takes its largest logit: a true logit of the query, hence
 // a lower bound of its maximum — on data with a clear winner it IS the maximum.
-// Worst case (flat logits: nothing can be skipped) the route costs the screen on top of the dense work; corr_fp6_sparse_kernel
-// counts its redone tiles and hands a query block whose first stages are mostly redone to the dense tile-skip kernel
-// (corr_bf16_direct_kernel<.., SKIP = 1>), which applies the same rule to the same bf16 logits: identical bits either way.
+// Worst case (flat logits: nothing can be skipped): corr_fp6_sparse_kernel screens its first stage ahead of its main loop and hands
+// a 256-query block with more than a quarter of those items flagged to the dense tile-skip kernel
+// (corr_bf16_direct_kernel<.., SKIP = 1>), which applies the same rule to the same bf16 logits: identical bits either way, and
+// the call then costs pass 0 + the dense kernel (1.4 x the unscreened one).  That is also what happens on the bench's own data
+// (|k| = 5: every term of the sums counts to 5e-7) — the route is an opt-in for softmaxes peaked beyond f32 resolution.
 #pragma once
 
 using i32x8 = __attribute__((ext_vector_type(8))) int;
@@ -362,9 +364,9 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W0) void corr_fp6_lower_kernel(con
 }
 
 // ------------------------------------------------------------------------------------------ pass 1: screen + exact pieces
-// Everything that reaches sums, maxima and indices comes from exact_tile (bf16 MFMA, C = 0: the logits of the dense kernels).
-// hand (nullable): a workgroup most of whose first kHandStages stages were redone writes its block index there and leaves;
-// the dense tile-skip kernel behind this one owns the listed blocks (same rule, same logits: the same bits).
+// Everything that reaches sums, maxima and indices comes from bf16 MFMA chains with C = 0 (the logits of the dense kernels).
+// ws.hand: a workgroup whose first stage is mostly flagged marks its 256-query block(s) there and leaves; the dense tile-skip
+// kernel behind this one owns the marked blocks (same rule, same logits: the same bits).
 constexpr int kHandMinStages = 8;                             // key ranges shorter than this many stages (2 048 keys) are never handed over
 constexpr int kQB1 = ISR_Q6_QB1;                              // 32-query blocks per wave in pass 1
 constexpr int kQPB1 = kWaves * kQB1 * 32;                      // queries per workgroup: kNB1 of the dense kernels' 256-query blocks
