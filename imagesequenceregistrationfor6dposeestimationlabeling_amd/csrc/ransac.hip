@@ -418,6 +418,13 @@ __global__ void best_mask_kernel(const float* __restrict__ p3d, const float* __r
 #define ISR_GN_SPLIT_SOLVE 1      // 0: the solve in gn_accumulate_kernel's last workgroup (round 3 .. first half of round 4)
 #endif
 constexpr int kRefThreads = 256;
+#ifndef ISR_GN_STOP_ROT2
+#define ISR_GN_STOP_ROT2 1e-18      // (1e-9 rad)^2
+#endif
+#ifndef ISR_GN_STOP_TRANS2
+#define ISR_GN_STOP_TRANS2 1e-14    // (1e-7 |t|)^2
+#endif
+constexpr double kGnStopRot2 = ISR_GN_STOP_ROT2, kGnStopTrans2 = ISR_GN_STOP_TRANS2;
 #ifndef ISR_REF_BLOCKS
 #define ISR_REF_BLOCKS 64
 #endif
@@ -491,11 +498,15 @@ __device__ void gn_solve(const double* __restrict__ partial, int nblocks, double
     O[4 * r + 3] += x[3 + r];
   }
   for (int i = 0; i < 12; ++i) Rt[i] = O[i];
-  // converged: rotation step below 1e-12 rad and translation step below 1e-10 of |t|
+  // converged: the step just APPLIED was below kGnStopRot rad and kGnStopTrans of |t| (squared: dw, dt).  Gauss-Newton on
+  // this problem converges quadratically near the solution, so the step after one of 1e-9 would be ~1e-18: the pose is final to
+  // double precision already, and the remaining launches of the fixed iteration count leave at once.  (Until round 5 the bounds
+  // were 1e-12 rad / 1e-10: one more working iteration per refit for nothing.)  oracle/pnp_oracle.py:refine applies the same
+  // rule with the same numbers.
   const double dw = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
   const double dt = x[3] * x[3] + x[4] * x[4] + x[5] * x[5];
   const double tt = O[3] * O[3] + O[7] * O[7] + O[11] * O[11];
-  if (dw < 1e-24 && dt < 1e-20 * (tt + 1.0)) state[0] = 1;
+  if (dw < kGnStopRot2 && dt < kGnStopTrans2 * (tt + 1.0)) state[0] = 1;
 }
 
 

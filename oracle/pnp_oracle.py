@@ -175,6 +175,9 @@ def _rodrigues(w):
     return np.eye(3) + np.sin(th) / th * Kx + (1 - np.cos(th)) / th ** 2 * (Kx @ Kx)
 
 
+GN_STOP_ROT2, GN_STOP_TRANS2 = 1e-18, 1e-14      # csrc/ransac.hip: kGnStopRot2, kGnStopTrans2
+
+
 def refine(p3d, p2d, K, Rt, sel, iters=10):
     """Gauss-Newton on the reprojection error over correspondences sel (bool or index)."""
     X = p3d[sel].astype(np.float64)
@@ -202,6 +205,10 @@ def refine(p3d, p2d, K, Rt, sel, iters=10):
             break
         Q = _rodrigues(dx[:3])
         R, t = Q @ R, Q @ t + dx[3:]
+        # csrc/ransac.hip:gn_solve's stopping rule (kGnStopRot2, kGnStopTrans2): the step just applied was below 1e-9 rad and
+        # 1e-7 of |t| — quadratic convergence makes the next one ~1e-18
+        if float(dx[:3] @ dx[:3]) < GN_STOP_ROT2 and float(dx[3:] @ dx[3:]) < GN_STOP_TRANS2 * (float(t @ t) + 1.0):
+            break
     return np.concatenate([R, t[:, None]], axis=1)
 
 

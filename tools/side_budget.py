@@ -40,3 +40,13 @@ for name, a in sorted(agg.items(), key=lambda kv: -kv[1][3]):
     print(f"{name:54s} {a[0] / steps:8.1f} {a[1] / max(a[0], 1):10.0f} {a[1] / steps:11.0f} {a[2] / steps:22.2f} {a[3] / steps:10.2f} {a[4]:6d}")
     tot[0] += a[0] / steps; tot[1] += a[1] / steps; tot[2] += a[2] / steps; tot[3] += a[3] / steps
 print(f"{'total (listed)':54s} {tot[0]:8.1f} {'':10s} {tot[1]:11.0f} {tot[2]:22.2f} {tot[3]:10.2f}")
+
+# how many of the Gauss-Newton launches still do work (the refit stops on a step-norm criterion, csrc/ransac.hip gn_solve: later
+# launches of the fixed 6 x 2 leave at once)
+gn = sorted((r for r in rows if "gn_accumulate_kernel" in r["Kernel_Name"] and t0 <= r["s"] <= t1), key=lambda r: r["s"])
+if gn:
+    import statistics
+    d = [(r["e"] - r["s"]) * 1e-3 for r in gn]
+    short = sum(1 for x in d if x < 25.0)
+    print(f"gn_accumulate_kernel: {len(d) / steps:.1f} launches per step, {short / steps:.1f} of them shorter than 25 us (every image converged: "
+          f"early exit), median of the others {statistics.median([x for x in d if x >= 25.0]):.0f} us")
