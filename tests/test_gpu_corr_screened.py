@@ -216,3 +216,19 @@ def test_device_quantiser_equals_the_oracle_s_image_byte_for_byte(cuda0):
     assert np.array_equal(img.cpu().numpy(), o["image"])
     np.testing.assert_allclose(nrm.cpu().numpy(), o["nrm"], rtol=3e-7)
     np.testing.assert_allclose(kmax.cpu().numpy(), [o["d2"].max(), o["t2"].max()], rtol=3e-7)
+
+
+def test_screened_dtype_beyond_the_tile_index_range_runs_unscreened(cuda0):
+    """N > 262 144 keys: pass 0 carries the tile index in 13 mantissa bits, so such calls take the unscreened kernels (the same
+    bits as ISR_DTYPE_BF16_LOG2)."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    g = torch.Generator(device=cuda0).manual_seed(4)
+    K = torch.randn(300000, D, device=cuda0, generator=g)
+    K = 8.0 * K / K.norm(dim=1, keepdim=True)
+    gt = torch.randint(300000, (200,), device=cuda0, generator=g)
+    qb = ops.prescale_queries_log2(K[gt] + 0.35 * torch.randn(200, D, device=cuda0, generator=g))
+    kb = K.bfloat16()
+    a = ops.corr_argmax(qb, kb, want_lse=True, log2_prescaled=True)
+    b = ops.corr_argmax(qb, kb, want_lse=True, log2_prescaled=True, screened=True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b)) and ops.corr_screen_redone() == (0, 0)
+    assert bool((a[0].long() == gt).all())
