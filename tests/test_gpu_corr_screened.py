@@ -200,7 +200,7 @@ def test_device_quantiser_equals_the_oracle_s_image_byte_for_byte(cuda0):
     from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
     from oracle import fp6_screen_oracle as fo
     rng = np.random.default_rng(8)
-    X = np.concatenate([fo.bf16_round((rng.normal(0, 1, (3000, 64)) * s).astype(np.float32)) for s in (1.0, 0.003, 500.0, 1e-20, 1e20)])
+    X = np.concatenate([fo.bf16_round((rng.normal(0, 1, (3000, 64)) * s).astype(np.float32)) for s in (1.0, 0.003, 500.0, 1e-20, 1e20, 3e-38, 2e37)])
     X[5] = 0.0
     X[6, 32:] = 0.0
     X[7, 9] = 2.0e30

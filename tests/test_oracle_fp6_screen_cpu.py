@@ -46,9 +46,9 @@ def test_quantiser_values_are_e2m3_numbers_within_half_a_step():
 
 def test_screen_bound_holds_on_random_rows():
     rng = np.random.default_rng(2)
-    for sq, sk in ((1.5, 1.0), (0.01, 300.0), (40.0, 0.002), (1e-12, 1e12)):
+    for sq, sk in ((1.5, 1.0), (0.01, 300.0), (40.0, 0.002), (1e-12, 1e12), (3e-38, 1.0)):
         err, E = _check(_rows(rng, 300, sq), _rows(rng, 700, sk))
-        assert err > 0 and E < 40 * err + 1e-30       # a bound, not a wild over-estimate (Cauchy-Schwarz over 64 random signs)
+        assert err > 0 and E < 40 * err + 2e-6        # a bound, not a wild over-estimate (Cauchy-Schwarz over 64 random signs; + E's 1e-6 absolute term)
     K = _rows(rng, 400, 1.0)
     K[::7, 3] *= 1000.0                                 # blocks dominated by one element
     Q = _rows(rng, 100, 1.0)
