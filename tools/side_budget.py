@@ -50,3 +50,21 @@ if gn:
     short = sum(1 for x in d if x < 25.0)
     print(f"gn_accumulate_kernel: {len(d) / steps:.1f} launches per step, {short / steps:.1f} of them shorter than 25 us (every image converged: "
           f"early exit), median of the others {statistics.median([x for x in d if x >= 25.0]):.0f} us")
+
+# K1's duty cycle over the timed region: gaps between consecutive K1 launches are time the chip runs side work only (or idles)
+gaps = [(k1[i + 1]["s"] - k1[i]["e"]) * 1e-3 for i in range(len(k1) - 1)]
+busy = sum(b - a for a, b in win)
+print(f"K1 duty cycle {busy / (t1 - t0):.4f}: {len(gaps)} gaps, mean {sum(gaps) / len(gaps):.0f} us, max {max(gaps):.0f} us; "
+      f"even gaps (inside a step) mean {sum(gaps[0::2]) / len(gaps[0::2]):.0f} us, odd gaps (between steps) mean {sum(gaps[1::2]) / max(len(gaps[1::2]), 1):.0f} us")
+
+# what runs in the gap between two steps: the kernels alive between the end of a step's second K1 launch and the next step's first
+odd = sorted(range(1, len(gaps), 2), key=lambda j: gaps[j])
+if odd:
+    i = odd[len(odd) // 2]                       # the median between-step gap
+    a, b = k1[i]["e"], k1[i + 1]["s"]
+    print(f"gap of {(b - a) * 1e-3:.0f} us between K1 launches {i} and {i + 1}; kernels overlapping it (start / end relative to the gap's start, us):")
+    for r in sorted(rows, key=lambda r: r["s"]):
+        if r["e"] > a - 100_000 and r["s"] < b + 50_000 and r not in k1:
+            nm = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0][:44]
+            print(f"   {nm:46s} {(r['s'] - a) * 1e-3:9.0f} {(r['e'] - a) * 1e-3:9.0f}  wgs {r['wgs']:6d}  queue {r.get('Queue_Id', '?')} stream {r.get('Stream_Id', '?')}")
+    print(f"   next K1 starts at {(b - a) * 1e-3:.0f}")
