@@ -139,7 +139,10 @@ __device__ __forceinline__ f32x16 mfma_fp6(const i32x8& a, const i32x8& b) {
 // ------------------------------------------------------------------------------------------ shared staging
 // The quantised keys stream through LDS like 64-byte bf16 rows (four 16-byte chunks per row, XOR-swizzled: key_slot<4, 0>),
 // by buffer_load ... lds, TKQ keys per stage, two buffers.
-constexpr int kTKQ = 256;                              // keys per stage of the quantised stream
+#ifndef ISR_Q6_TKQ
+#define ISR_Q6_TKQ 256
+#endif
+constexpr int kTKQ = ISR_Q6_TKQ;                       // keys per stage of the quantised stream
 constexpr int kQ6Chunks = kTKQ * 4;                    // 16-byte chunks per stage
 constexpr int kQ6Nld = kQ6Chunks / kThreads;           // DMA instructions per thread and stage
 
