@@ -756,6 +756,15 @@ def main():
                    "ransac_confidence": 1.0, "hypotheses_scored_mean": last_all.get("hypotheses_scored_mean"),
                    "note": "same step, every one of the --itr hypotheses scored (round 1's rule); not `value`"}
 
+    def final_of(last_x):
+        """final Chamfer of an untimed extra step on every rank (it lives on the rank that owned the picked image)."""
+        fc = last_x.get("final_chamfer")
+        if world > 1:
+            v = torch.tensor([fc if (fc is not None and rank == last_x["icp_rank"]) else 0.0], dtype=torch.float64, device=shard._coll_device())
+            torch.distributed.broadcast(v, src=last_x["icp_rank"])
+            fc = float(v.cpu()[0])
+        return fc
+
     # UNTIMED: the same step at the reference's own precision (inference.py:142-149 is an f32 matmul): f32 keys, f32 queries,
     # K1 on the f16-plane route; a few steps, every rank (the step has collectives)
     f32_step = None
@@ -767,7 +776,7 @@ def main():
         last32, dt32, _ = timed(args.warmup + 2 * args.steps + 1, k, args.confidence)
         f32_step = {"value": n_total * k / dt32, "unit": "images/s", "steps": k, "ms_per_step": dt32 / k * 1e3,
                     "dtype": "f32 descriptors (K1: f16 planes on the 16-bit matrix cores, exact f32-chain indices)",
-                    "final_chamfer": last32.get("final_chamfer"), "registered_this_rank": last32.get("registered_this_rank"),
+                    "final_chamfer": final_of(last32), "registered_this_rank": last32.get("registered_this_rank"),
                     "note": "the same step on f32 keys and queries — the reference's precision; not `value`"}
         if rank == 0 and not args.no_parity_check:
             from oracle import cbind
@@ -799,7 +808,7 @@ def main():
             run_steps(base, 1, args.confidence)
             last8, dt8, _ = timed(base + 1, k, args.confidence)
             screened_step[name] = {"value": n_total * k / dt8, "unit": "images/s", "ms_per_step": dt8 / k * 1e3,
-                                   "final_chamfer": last8.get("final_chamfer"), "registered_this_rank": last8.get("registered_this_rank"),
+                                   "final_chamfer": final_of(last8), "registered_this_rank": last8.get("registered_this_rank"),
                                    "picked_image": last8.get("picked_image")}
             if rank == 0:
                 g_rows = Q8[:max(args.group, 1)].reshape(-1, D)
