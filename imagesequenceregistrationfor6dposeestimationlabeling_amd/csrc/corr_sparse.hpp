@@ -504,7 +504,7 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W1) void corr_fp6_sparse_kernel(co
   // sites, the heavy path made the kernel 36 KB of code and every visit to it a run of instruction-cache misses: ~5 500
   // cycles per item).  The rows of marked item j + 1 are requested before item j's exponentials are taken.
   bf16x8 ka[NFR], qa[NFR];                                   // the current item's key and query fragments
-  unsigned heavy = 0u;                                       // wave-uniform: bit (sub * QB + qb) of the current stage
+  unsigned heavy = 0u, star = 0u;                            // wave-uniform: bit (sub * QB + qb) of the current stage's marked items
   auto request = [&](int qb, int kb) __attribute__((always_inline)) {
     int row = kb + r;
     row = row < N ? row : N - 1;
@@ -513,55 +513,74 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W1) void corr_fp6_sparse_kernel(co
     for (int s = 0; s < NFR; ++s) ka[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
     load_q(qb, qa);
   };
+  // The marked items of the stage, in ITEM order (= tile order per query block): a piece enters its lane's sum and maxima at the
+  // position the dense kernel gives it, whichever way it is obtained — `star` items (every flagged lane sits in its query's
+  // pass-0 tile) from the stored pieces, `heavy` items by fetching the rows.  (Round-5 stress test: with the stored pieces applied
+  // inline and the fetched ones behind the stage, a zero query's "first tile reaching the maximum" came out as its LAST tile.)
   auto redo_marked = [&](int kbase) __attribute__((always_inline)) {
-    if (heavy == 0u) return;
-    int j = __builtin_ctz(heavy);
-    heavy &= heavy - 1u;
-    request(j % QB, kbase + (j / QB) * 32);
-    while (true) {                                           // wave-uniform
+    unsigned all = heavy | star;
+    if (all == 0u) return;
+    if (heavy != 0u) { const int j0 = __builtin_ctz(heavy); request(j0 % QB, kbase + (j0 / QB) * 32); }
+    while (all != 0u) {                                      // wave-uniform
+      const int j = __builtin_ctz(all);
+      all &= all - 1u;
       const int qbj = j % QB, kb = kbase + (j / QB) * 32;
-      ++redone;
-      f32x16 c = splat16(0.f);
+      if ((heavy >> j) & 1u) {
+        ++redone;
+        f32x16 c = splat16(0.f);
 #pragma unroll
-      for (int s = 0; s < NFR; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s], qa[s], c, 0, 0, 0);
-      const bool more = heavy != 0u;
-      if (more) {                                            // the next marked item's rows travel under this one's epilogue
-        j = __builtin_ctz(heavy);
-        heavy &= heavy - 1u;
-        request(j % QB, kbase + (j / QB) * 32);
-      }
-      if (kb + 32 > N) mask_tail(c, kb + 4 * h, N);
-      const float t = tile_max(c);
-      float ts = __builtin_amdgcn_exp2f(c[0]);
-#pragma unroll
-      for (int i = 1; i < 16; ++i) ts += __builtin_amdgcn_exp2f(c[i]);
-#pragma unroll
-      for (int qb = 0; qb < QB; ++qb)
-        if (qbj == qb) {                                     // wave-uniform
-          sl[qb] += (t >= thr_x[qb]) ? ts : 0.f;              // the canonical rule, per lane (16 keys of the tile)
-          sm2[qb] = __builtin_amdgcn_fmed3f(sm[qb], sm2[qb], t);
-          stb[qb] = (t > sm[qb]) ? kb : stb[qb];
-          sm[qb] = fmaxf(sm[qb], t);
+        for (int s = 0; s < NFR; ++s) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s], qa[s], c, 0, 0, 0);
+        heavy &= heavy - 1u;                                 // (j is heavy's lowest bit: heavy items are met in order)
+        if (heavy != 0u) {                                   // the next fetched item's rows travel under this one's epilogue
+          const int jn = __builtin_ctz(heavy);
+          request(jn % QB, kbase + (jn / QB) * 32);
         }
-      if (!more) break;
+        if (kb + 32 > N) mask_tail(c, kb + 4 * h, N);
+        const float t = tile_max(c);
+#if defined(ISR_ABL_P1) && (ISR_ABL_P1 & 2)     // timing-only ablation: no exponentials
+        float ts = c[0];
+#else
+        float ts = __builtin_amdgcn_exp2f(c[0]);
+#pragma unroll
+        for (int i = 1; i < 16; ++i) ts += __builtin_amdgcn_exp2f(c[i]);
+#endif
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          if (qbj == qb) {                                   // wave-uniform
+            sl[qb] += (t >= thr_x[qb]) ? ts : 0.f;            // the canonical rule, per lane (16 keys of the tile)
+            sm2[qb] = __builtin_amdgcn_fmed3f(sm[qb], sm2[qb], t);
+            stb[qb] = (t > sm[qb]) ? kb : stb[qb];
+            sm[qb] = fmaxf(sm[qb], t);
+          }
+      } else {
+        // the exact values of the lanes whose query has this tile as its pass-0 tile are at hand (the same chain, the same
+        // order of the sum); every other lane was shown by the screen to hold nothing that counts here
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb)
+          if (qbj == qb) {                                   // wave-uniform
+            if (kb == tstar[qb]) {
+              sl[qb] += (pt[qb] >= thr_x[qb]) ? pts[qb] : 0.f;
+              sm2[qb] = __builtin_amdgcn_fmed3f(sm[qb], sm2[qb], pt[qb]);
+              stb[qb] = (pt[qb] > sm[qb]) ? kb : stb[qb];
+              sm[qb] = fmaxf(sm[qb], pt[qb]);
+            }
+          }
+      }
     }
+    star = 0u;
   };
   int kbase_cur = 0;
   auto consume = [&](const f32x16& c6, int qb, int kb) __attribute__((always_inline)) {
     const float t6 = tile_max(c6);
     const bool f = t6 >= thr_s[qb];
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(f) != 0ull, 0)) {     // wave-uniform
-      if (__builtin_amdgcn_ballot_w64(f && kb != tstar[qb]) == 0ull) {
-        // every flagged piece is its query's pass-0 tile: the exact values are at hand (the same chain, the same order)
-        if (f) {
-          sl[qb] += (pt[qb] >= thr_x[qb]) ? pts[qb] : 0.f;
-          sm2[qb] = __builtin_amdgcn_fmed3f(sm[qb], sm2[qb], pt[qb]);
-          stb[qb] = (pt[qb] > sm[qb]) ? kb : stb[qb];
-          sm[qb] = fmaxf(sm[qb], pt[qb]);
-        }
-      } else {
-        heavy |= 1u << (((kb - kbase_cur) >> 5) * QB + qb);
-      }
+      const unsigned bit = 1u << (((kb - kbase_cur) >> 5) * QB + qb);
+#if defined(ISR_ABL_P1) && (ISR_ABL_P1 & 8)     // timing-only ablation: every flagged item is treated as a pass-0 tile
+      star |= bit;
+#else
+      if (__builtin_amdgcn_ballot_w64(f && kb != tstar[qb]) == 0ull) star |= bit;
+      else heavy |= bit;
+#endif
     }
   };
   static_assert((kTKQ / 32) * QB <= 32, "the stage's item mask is one 32-bit word");

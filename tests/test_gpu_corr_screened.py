@@ -232,3 +232,51 @@ def test_screened_dtype_beyond_the_tile_index_range_runs_unscreened(cuda0):
     b = ops.corr_argmax(qb, kb, want_lse=True, log2_prescaled=True, screened=True)
     assert all(torch.equal(x, y) for x, y in zip(a, b)) and ops.corr_screen_redone() == (0, 0)
     assert bool((a[0].long() == gt).all())
+
+
+@pytest.mark.parametrize("N", [33, 167, 232, 256, 300, 1000])
+def test_screened_pieces_enter_in_tile_order(cuda0, oracle_lib, N):
+    """Round-5 stress find: zero rows INSIDE a live block (every logit equal: the arg-max is key 0, the first tile reaching the
+    maximum) came out as the first key of the query's pass-0 tile, because that tile's stored pieces were applied while the stage
+    was screened and the fetched tiles behind it.  Also: keys repeated across tiles (equal maxima in several tiles), and queries
+    with several pieces that count — their sums must carry the dense kernel's order of additions, so the bytes of the sparse
+    kernel (few flagged items) and of the dense kernel (block handed over) agree; checked against the unscreened route's index
+    and, for the order, through a launch in which the same queries sit in a block that is handed over."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(N)
+    P = 4096
+    Q, K, _ = _planted(rng, P, N, tau=8.0)
+    K[N // 2:] = K[: N - N // 2]                               # every key twice, in different tiles for N > 64
+    Q[rng.random(P) < 0.2] = 0.0                               # padding rows scattered through live blocks
+    (idx, logp, lse), o, (qb, kb) = _check(ops, oracle_lib, cuda0, Q, K)
+    zero = np.nonzero(~Q.any(axis=1))[0]
+    assert len(zero) > 100 and (idx.numpy()[zero] == 0).all()
+    a = ops.corr_argmax(qb.to(cuda0), kb.to(cuda0), want_lse=True, log2_prescaled=True)
+    assert torch.equal(a[0].cpu(), idx)
+
+
+def test_screened_sparse_and_dense_kernels_add_in_the_same_order(cuda0):
+    """Queries with SEVERAL pieces that count (their key copied, at 0.8 ... 1.0 of its length, into five other tiles) placed (a)
+    among planted queries, whose block stays with the sparse kernel, and (b) among flat queries, whose block goes to the dense
+    kernel: the same bytes in both, so the fetched pieces, the stored pass-0 pieces and the dense kernel's tiles all enter a sum
+    at the same position."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(77)
+    N = 6000
+    _, K, gt = _planted(rng, 512, N, tau=8.0)
+    g = rng.choice(N, size=64, replace=False)
+    for s_ in (0.8, 0.9, 0.95, 0.99, 1.0):
+        K[rng.choice(N, size=64, replace=False)] = K[g] * s_
+    Qp = (K[gt] + 0.35 * rng.normal(0, 1, (512, D))).astype(np.float32)    # planted on the keys as they now are
+    mid = (K[g] + 0.35 * rng.normal(0, 1, (64, D))).astype(np.float32)
+    flat = rng.normal(0, 1, (512, D)).astype(np.float32)
+    kb = torch.from_numpy(K).bfloat16()
+    A = np.concatenate([Qp[:192], mid, Qp[192:256 + 192]])    # block 0: 256 queries, 64 of them `mid`: stays sparse
+    B = np.concatenate([flat[:192], mid, flat[192:]])          # block 0: flat company: handed over
+    ra = _run(ops, cuda0, ops.prescale_queries_log2(torch.from_numpy(A)), kb)
+    red_a, handed_a = ops.corr_screen_redone()
+    rb = _run(ops, cuda0, ops.prescale_queries_log2(torch.from_numpy(B)), kb)
+    red_b, handed_b = ops.corr_screen_redone()
+    assert handed_a == 0 and handed_b >= 1 and red_a >= 64 * 3, (handed_a, handed_b, red_a)
+    for x, y in zip(ra, rb):
+        assert torch.equal(x[192:256], y[192:256])

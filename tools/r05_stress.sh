@@ -1,0 +1,6 @@
+set -e
+mkdir -p gpurun_out/r05
+timeout -k 10 300 python -m pytest tests/test_gpu_corr_screened.py -x -q > gpurun_out/r05/screened_tests.txt 2>&1 || { tail -30 gpurun_out/r05/screened_tests.txt; exit 1; }
+tail -3 gpurun_out/r05/screened_tests.txt
+for s in 1 2 3 4 5; do timeout -k 10 200 python tools/stress_corr_screened.py $s 120 >> gpurun_out/r05/stress.txt 2>&1 || { tail -5 gpurun_out/r05/stress.txt; exit 1; }; done
+cat gpurun_out/r05/stress.txt
