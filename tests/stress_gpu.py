@@ -1,0 +1,161 @@
+"""Randomised stress of the HIP path against the C oracle (a script, not collected by pytest: minutes, not seconds).
+    python tests/stress_gpu.py [seed] [cases]
+Round 5: tools/stress_corr_screened.py found a tie-order bug no fixed-size test held; this is the same net under the other
+routes of K1 and under the nearest-neighbour search.  Per case random shapes (ragged), random composition of rows:
+  corr   f32 / bf16 / bf16-log2 routes of isr_corr_argmax, D in 1..128, planted / unplanted / zero / huge / tiny / duplicated rows:
+         indices array_equal to the oracle's exact arg-max (lowest key on ties); logp and lse to 3e-5 (relative to
+         max(1, |lse|)); a random slice of the queries in a launch of its own: indices torch.equal, values torch.equal for
+         the queries inside the direct sums' range.
+  nn     isr_nn_batched with random transforms, radius, lattice clouds (exact ties), duplicated targets: winners and f64
+         distances bit for bit, counts equal, sums to 1e-12.
+  ransac random M (4 ...), H, thresholds, outlier fractions, pixel-rounded observations: Philox samples array_equal to the numpy
+         oracle's; inlier counts, best hypothesis and its bit mask array_equal to the C oracle's on the device's own poses."""
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops  # noqa: E402
+from oracle import cbind  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+dev = torch.device("cuda:0")
+rng = np.random.default_rng(seed)
+cbind.build()
+
+
+def bits(t):
+    return t.cpu().view(torch.int16).numpy().view(np.uint16)
+
+
+def corr_case(c):
+    route = str(rng.choice(["f32", "bf16", "log2"]))
+    D = int(rng.choice([rng.integers(1, 129), 64, 64, 32, 128, 16]))
+    P = int(rng.integers(1, 6000))
+    N = int(rng.choice([rng.integers(1, 300), rng.integers(300, 5000), rng.integers(5000, 30000)]))
+    tau = float(rng.choice([0.5, 2.0, 5.0, 8.0, 12.0]))
+    K = rng.normal(0, 1, (N, D)).astype(np.float32)
+    K *= tau / np.maximum(np.linalg.norm(K, axis=1, keepdims=True), 1e-6)
+    if N > 10 and rng.random() < 0.5:
+        j = rng.integers(N, size=N // 10); i = rng.integers(N, size=N // 10)
+        K[j] = K[i] * (1.0 + rng.choice([0.0, 1e-3, 1e-2], size=(N // 10, 1)))
+    gt = rng.integers(N, size=P)
+    Q = (K[gt] + float(rng.choice([0.05, 0.35, 1.0])) * rng.normal(0, 1, (P, D))).astype(np.float32)
+    kind = rng.random(P)
+    Q[kind < 0.15] = rng.normal(0, 1, (int((kind < 0.15).sum()), D))
+    Q[(kind > 0.15) & (kind < 0.20)] = 0.0
+    Q[(kind > 0.20) & (kind < 0.23)] *= 10.0
+    Q[(kind > 0.23) & (kind < 0.26)] *= 1e-3
+    tag = f"corr case {c}: {route} P={P} N={N} D={D} tau={tau}"
+    if route == "f32":
+        q, k = torch.from_numpy(Q).to(dev), torch.from_numpy(K).to(dev)
+        g = ops.corr_argmax(q, k, want_lse=True)
+        o = cbind.corr_argmax_f32(Q, K)
+        mx, lse_o = o["maxlogit"].astype(np.float64), o["lse"]
+        kw = {}
+    else:
+        qb = ops.prescale_queries_log2(torch.from_numpy(Q)) if route == "log2" else torch.from_numpy(Q).bfloat16()
+        kb = torch.from_numpy(K).bfloat16()
+        q, k = qb.to(dev), kb.to(dev)
+        kw = dict(log2_prescaled=route == "log2")
+        g = ops.corr_argmax(q, k, want_lse=True, **kw)
+        o = cbind.corr_argmax_bf16(bits(qb), bits(kb), logit_scale=np.log(2.0) if route == "log2" else 1.0)
+        mx, lse_o = o["maxlogit"], o["lse"]
+    idx, logp, lse = (x.cpu().numpy() for x in g)
+    bad = np.nonzero(idx != o["idx"])[0]
+    assert len(bad) == 0, f"{tag}: {len(bad)} index mismatches, first {bad[:4]}, margins {(mx - o['top2'])[bad][:4]}"
+    scale = np.maximum(1.0, np.abs(lse_o))
+    e1 = np.max(np.abs(lse - lse_o) / scale)
+    e2 = np.max(np.abs(logp - (mx - lse_o)) / scale)
+    assert e1 <= 3e-5 and e2 <= 3e-5, f"{tag}: lse off by {e1:.3g}, logp by {e2:.3g}"
+    lo = int(rng.integers(0, P)); hi = min(P, lo + int(rng.integers(1, 2000)))
+    s = ops.corr_argmax(q[lo:hi].contiguous(), k, want_lse=True, **kw)
+    # (a query whose logits leave the direct sums' range, |log2-unit logit| >= 100 here, is still decided exactly, but which of
+    # its key ranges are redone with a per-query reference — and with that the last bit of its values — follows the launch's
+    # key split: DESIGN.md K1a "launch independence")
+    inr = torch.from_numpy((np.abs(mx[lo:hi]) * 1.4427 < 100.0) & (np.abs(lse_o[lo:hi]) * 1.4427 < 100.0)).to(dev)
+    assert torch.equal(g[0][lo:hi], s[0]), f"{tag}: slice [{lo}, {hi}) indices differ"
+    assert all(torch.equal(x[lo:hi][inr], y[inr]) for x, y in zip(g, s)), f"{tag}: slice [{lo}, {hi}) differs"
+    return max(e1, e2)
+
+
+def rand_pose():
+    a = rng.normal(0, 1, 4); a /= np.linalg.norm(a)
+    w, x, y, z = a
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return np.concatenate([R, rng.normal(0, 30, (3, 1))], axis=1)
+
+
+def nn_case(c):
+    Nq = int(rng.choice([rng.integers(1, 200), rng.integers(200, 6000)]))
+    Nt = int(rng.choice([rng.integers(1, 300), rng.integers(300, 9000)]))
+    B = int(rng.choice([1, 1, 2, 5, 17]))
+    lattice = rng.random() < 0.3
+    if lattice:
+        q = rng.integers(-4, 5, (Nq, 3)).astype(np.float32)
+        t = rng.integers(-4, 5, (Nt, 3)).astype(np.float32)
+    else:
+        q = rng.normal(0, 40, (Nq, 3)).astype(np.float32)
+        t = rng.normal(0, 40, (Nt, 3)).astype(np.float32)
+        if Nt > 4 and rng.random() < 0.5:
+            t[Nt // 2:] = t[: Nt - Nt // 2]
+    mode = int(rng.integers(0, 4))
+    Tq = np.stack([rand_pose() for _ in range(B)]) if (mode & 1 or B > 1) else None
+    Tt = np.stack([rand_pose() for _ in range(B)]) if (mode & 2 and not lattice) else None
+    if lattice and Tq is not None:                           # keep the ties exact: integer translations, axis permutations
+        Tq = np.stack([np.concatenate([np.eye(3)[rng.permutation(3)], rng.integers(-2, 3, (3, 1)).astype(float)], axis=1)
+                       for _ in range(B)])
+    if Tq is None and Tt is not None and B > 1:
+        Tq = np.stack([np.concatenate([np.eye(3), np.zeros((3, 1))], axis=1)] * B)
+    radius = float(rng.choice([-1.0, 3.0, 20.0, 60.0]))
+    tag = f"nn case {c}: Nq={Nq} Nt={Nt} B={B} lattice={lattice} radius={radius} Tq={Tq is not None} Tt={Tt is not None}"
+    r = ops.nn_batched(torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev),
+                       None if Tq is None else torch.from_numpy(Tq).to(dev), None if Tt is None else torch.from_numpy(Tt).to(dev),
+                       radius=radius, want_idx=True, want_dist=True, want_cov=True)
+    g = {k: getattr(r, k).cpu().numpy() for k in ("sum_d", "sum_d2", "n_in", "nn_idx", "nn_d")}
+    o = cbind.nn_batched(q, t, Tq, Tt, radius)
+    assert np.array_equal(g["nn_idx"], o["nn_idx"]), f"{tag}: {(g['nn_idx'] != o['nn_idx']).sum()} winners differ"
+    assert np.array_equal(g["nn_d"], o["nn_d"]), f"{tag}: distances differ"
+    assert np.array_equal(g["n_in"], o["n_in"]), f"{tag}: counts differ"
+    np.testing.assert_allclose(g["sum_d"], o["sum_d"], rtol=1e-12, err_msg=tag)
+    np.testing.assert_allclose(g["sum_d2"], o["sum_d2"], rtol=1e-12, err_msg=tag)
+
+
+def ransac_case(c):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import synth
+    from oracle import pnp_oracle as po
+    M = int(rng.choice([rng.integers(4, 100), rng.integers(100, 5000), rng.integers(5000, 60000)]))
+    H = int(rng.choice([1, 7, 64, 500, 1000]))
+    sd = int(rng.integers(1 << 31))
+    reperr = float(rng.choice([0.5, 2.0, 8.0]))
+    pts = synth.tless_like(rng, 2000)
+    Kc = synth.camera()
+    R, t = synth.random_poses(rng, 1)
+    p3d, p2d, _ = synth.pnp_case(rng, pts, Kc, R[0], t[0], M, float(rng.choice([0.0, 0.5, 2.0])), float(rng.choice([0.0, 0.3, 0.9])))
+    if rng.random() < 0.3:
+        p2d = np.round(p2d)                                   # pixel centres: reprojection errors that tie across hypotheses
+    tag = f"ransac case {c}: M={M} H={H} reperr={reperr}"
+    d3, d2 = torch.from_numpy(p3d).to(dev), torch.from_numpy(p2d).to(dev)
+    Rt, ok, smp = ops.p3p_hypotheses(d3, d2, Kc, H, seed=sd, want_samples=True)
+    n_inl, best, mask = ops.ransac_score(d3, d2, Kc, Rt, ok, reperr)
+    assert np.array_equal(smp.cpu().numpy(), po.sample_indices(H, M, sd)), f"{tag}: samples differ"
+    Rt_h, ok_h = Rt.cpu().numpy(), ok.cpu().numpy()
+    sc = cbind.ransac_score(p3d, p2d, Kc, Rt_h.reshape(H, 12), ok_h, reperr)
+    assert np.array_equal(n_inl.cpu().numpy(), sc["n_inl"]), f"{tag}: inlier counts differ"
+    assert int(best.item()) == sc["best"], f"{tag}: best differs"
+    assert np.array_equal(mask.cpu().numpy().view(np.uint32), sc["best_mask"]), f"{tag}: mask differs"
+
+
+worst = 0.0
+for c in range(cases):
+    worst = max(worst, corr_case(c))
+    nn_case(c)
+    ransac_case(c)
+    if c % 10 == 9:
+        print(f"  seed {seed}: {c + 1} cases", flush=True)
+print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac cases ok; worst corr value error {worst:.3g} (relative to max(1, |lse|))")
