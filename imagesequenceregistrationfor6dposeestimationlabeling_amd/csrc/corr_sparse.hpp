@@ -513,6 +513,8 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W1) void corr_fp6_sparse_kernel(co
     for (int s = 0; s < NFR; ++s) ka[s] = *reinterpret_cast<const bf16x8*>(src + 16 * s);
     load_q(qb, qa);
   };
+  constexpr unsigned kItemsOfQb0 = QB == 1 ? 0xFFFFFFFFu : QB == 2 ? 0x55555555u : QB == 4 ? 0x11111111u : 0u;   // bits j with j % QB == 0
+  static_assert(kItemsOfQb0 != 0u, "QB is 1, 2 or 4");
   // The marked items of the stage, in ITEM order (= tile order per query block): a piece enters its lane's sum and maxima at the
   // position the dense kernel gives it, whichever way it is obtained — `star` items (every flagged lane sits in its query's
   // pass-0 tile) from the stored pieces, `heavy` items by fetching the rows.  (Round-5 stress test: with the stored pieces applied
@@ -578,8 +580,22 @@ __global__ __launch_bounds__(kThreads, ISR_Q6_W1) void corr_fp6_sparse_kernel(co
 #if defined(ISR_ABL_P1) && (ISR_ABL_P1 & 8)     // timing-only ablation: every flagged item is treated as a pass-0 tile
       star |= bit;
 #else
-      if (__builtin_amdgcn_ballot_w64(f && kb != tstar[qb]) == 0ull) star |= bit;
-      else heavy |= bit;
+      if (__builtin_amdgcn_ballot_w64(f && kb != tstar[qb]) == 0ull) {
+        // every flagged lane sits in its query's pass-0 tile: the stored pieces serve.  At once when no earlier item of this
+        // query block waits for the handler (then this IS its position in the order), behind the waiting ones otherwise.
+        if (((heavy | star) & (kItemsOfQb0 << qb)) == 0u) {
+          if (kb == tstar[qb]) {
+            sl[qb] += (pt[qb] >= thr_x[qb]) ? pts[qb] : 0.f;
+            sm2[qb] = __builtin_amdgcn_fmed3f(sm[qb], sm2[qb], pt[qb]);
+            stb[qb] = (pt[qb] > sm[qb]) ? kb : stb[qb];
+            sm[qb] = fmaxf(sm[qb], pt[qb]);
+          }
+        } else {
+          star |= bit;
+        }
+      } else {
+        heavy |= bit;
+      }
 #endif
     }
   };
