@@ -9,7 +9,11 @@ routes of K1 and under the nearest-neighbour search.  Per case random shapes (ra
   nn     isr_nn_batched with random transforms, radius, lattice clouds (exact ties), duplicated targets: winners and f64
          distances bit for bit, counts equal, sums to 1e-12.
   ransac random M (4 ...), H, thresholds, outlier fractions, pixel-rounded observations: Philox samples array_equal to the numpy
-         oracle's; inlier counts, best hypothesis and its bit mask array_equal to the C oracle's on the device's own poses."""
+         oracle's; inlier counts, best hypothesis and its bit mask array_equal to the C oracle's on the device's own poses.
+  filter the top-80 % cut on exponential / plateau / half-zero / -inf log-probabilities, 2 ... 400 000 values: kept set array_equal
+         to inference.py:282-290 restated.
+  icp    random cloud sizes (3 ...), initial poses, thresholds (few / all points inside), Morton order on and off: fitness equal,
+         rmse to 1e-9, pose to 1e-9 rad / 1e-7 mm of the oracle loop with exact f64 neighbours."""
 import sys
 from pathlib import Path
 
@@ -151,11 +155,61 @@ def ransac_case(c):
     assert np.array_equal(mask.cpu().numpy().view(np.uint32), sc["best_mask"]), f"{tag}: mask differs"
 
 
+def filter_case(c):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration as reg
+    from oracle import registration_oracle as ro
+    P = int(rng.choice([rng.integers(2, 501), rng.integers(501, 3000), rng.integers(3000, 400000)]))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        x = -rng.exponential(3.0, P)
+    elif kind == 1:
+        x = -rng.integers(0, 6, P).astype(np.float64)          # plateaus: the threshold sits inside a run of equal values
+    elif kind == 2:
+        x = -np.abs(rng.normal(0, 1e-6, P)); x[rng.random(P) < 0.5] = 0.0     # the bench's tau = 8 case: half the values are 0
+    else:
+        x = -rng.exponential(3.0, P); x[rng.random(P) < 0.01] = -np.inf
+    x = x.astype(np.float32)
+    tag = f"filter case {c}: P={P} kind={kind}"
+    got = reg.filter_top(torch.from_numpy(x).to(dev).reshape(-1, 1))
+    want = ro.filter_top(torch.from_numpy(x).reshape(-1, 1))
+    assert np.array_equal(got, want), f"{tag}: kept sets differ ({len(got)} vs {len(want)})"
+
+
+def icp_case(c):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration as reg, synth
+    from oracle import registration_oracle as ro
+    n = int(rng.choice([rng.integers(3, 300), rng.integers(300, 3000), rng.integers(3000, 9000)]))
+    m = int(rng.choice([n, rng.integers(3, 9000)]))
+    cloud = synth.bumpy_ellipsoid(rng, 4 * max(n, m)) if rng.random() < 0.5 else synth.tless_like(rng, 4 * max(n, m))
+    src = cloud[rng.choice(len(cloud), n, replace=False)].astype(np.float32)
+    tgt = cloud[rng.choice(len(cloud), m, replace=False)].astype(np.float32)
+    ang = float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+    ax = rng.normal(0, 1, 3); ax /= np.linalg.norm(ax)
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    init = np.eye(4)
+    init[:3, :3] = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+    init[:3, 3] = rng.normal(0, float(rng.choice([0.0, 0.5, 3.0])), 3)
+    thr = float(rng.choice([0.5, 5.0, 20.0, 200.0]))
+    tag = f"icp case {c}: n={n} m={m} angle={ang} threshold={thr}"
+    T, fit, rmse = reg.icp_point_to_point(src, tgt, thr, init, spatial_order=bool(rng.random() < 0.5))
+    Tr, rfit, rrmse, traj = ro.icp_point_to_point(src, tgt, thr, init, search="f64")
+    # the loop is a fixed point iteration: a neighbour decided differently at a tie of f32 roundings would show as a different
+    # trajectory; the device resolves such ties in f64, so the poses agree to the conditioning of the last Kabsch step
+    rot = synth.rot_angle(T[:3, :3], Tr[:3, :3]); tr = float(np.linalg.norm(T[:3, 3] - Tr[:3, 3]))
+    assert abs(fit - rfit) < 1e-12 and abs(rmse - rrmse) < 1e-9 * max(1.0, rrmse) and rot < 1e-9 and tr < 1e-7, \
+        f"{tag}: fitness {fit} / {rfit}, rmse {rmse} / {rrmse}, rot {rot:.3g} rad, trans {tr:.3g} mm after {len(traj) - 1} iterations"
+    return rot
+
+
 worst = 0.0
+worst_icp = 0.0
 for c in range(cases):
     worst = max(worst, corr_case(c))
     nn_case(c)
     ransac_case(c)
+    filter_case(c)
+    worst_icp = max(worst_icp, icp_case(c))
     if c % 10 == 9:
         print(f"  seed {seed}: {c + 1} cases", flush=True)
-print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac cases ok; worst corr value error {worst:.3g} (relative to max(1, |lse|))")
+print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac + {cases} filter + {cases} icp cases ok; worst corr value error {worst:.3g} "
+      f"(relative to max(1, |lse|)), worst ICP rotation difference {worst_icp:.3g} rad")
