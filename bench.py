@@ -78,6 +78,10 @@ def parse_args():
                     help="how many batches the registration may run ahead of the verification (step overlap)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="finish a step's ICP + final Chamfer before the next step's registration starts")
+    ap.add_argument("--epilogue-digits", action="store_true",
+                    help="A/B: K1 forms the cut's first histogram in its epilogue (isr_corr_argmax_digits + "
+                         "isr_select_top_batch_digits, SURVEY 8(f)-2) instead of the plain isr_corr_argmax + ten-launch "
+                         "isr_select_top_batch pair; same results, 5 %% slower (profiles/r05_epilogue_histogram_ab.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--confidence", type=float, default=0.99,
                     help="RANSAC confidence (cv2.solvePnPRansac's parameter; its default 0.99 is what the reference's "
@@ -544,6 +548,8 @@ def main():
 
     P, N, D = args.width * args.height, args.keys, args.dim
     n_local, n_total = args.images, args.images * world
+    if args.epilogue_digits:
+        sequence.EPILOGUE_DIGITS = True
     if args.tune:
         ops.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
     Kcam = synth.camera(args.width, args.height)
@@ -680,12 +686,13 @@ def main():
     k1_alone_ms = k1_clock_mhz = k1_rechecked = k1_screen = None
     if rank == 0:
         g_rows = Q_all[:max(args.group, 1)].reshape(-1, D)
-        ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries, screened=model.screened)
+        dig = dict(rows_per_image=P) if sequence.EPILOGUE_DIGITS else {}      # the call the step makes
+        ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries, screened=model.screened, **dig)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(2):
-            ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries, screened=model.screened)
+            ops.corr_argmax(g_rows, model.keys, log2_prescaled=model.log2_queries, screened=model.screened, **dig)
         e1.record()
         torch.cuda.synchronize()
         k1_alone_ms = e0.elapsed_time(e1) / 2
@@ -868,6 +875,7 @@ def main():
                        "ransac_confidence": args.confidence,
                        "hypotheses_scored_mean": last.get("hypotheses_scored_mean"),
                        "parallelism": f"image-sharded x{world}",
+                       "cut_first_histogram": "K1 epilogue (isr_corr_argmax_digits)" if sequence.EPILOGUE_DIGITS else "hist_kernel<21,11> (isr_select_top_batch)",
                        "step_overlap": ("none" if args.no_pipeline else
                                         "verification (all-gather, pick/vote, ICP, final Chamfer) of batch s "
                                         "overlaps the registration of batch s+1")},

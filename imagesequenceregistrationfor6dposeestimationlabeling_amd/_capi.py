@@ -51,6 +51,7 @@ SIGNATURES = {
     "isr_tuning_get": (_i, [_i]),
     "isr_corr_argmax_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "isr_corr_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_corr_argmax_digits": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "isr_corr_argmax_recheck_count": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_corr_argmax_recheck_count_f32": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_corr_argmax_screen_redone": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "isr_select_top_dev": (_i, [_vp, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_select_top_batch_workspace_bytes": (_sz, [_i, _i]),
     "isr_select_top_batch": (_i, [_vp, _i, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "isr_select_top_batch_digits": (_i, [_vp, _i, _i, _vp, _d, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_gather_corr_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "isr_pnp_ransac_batch_workspace_bytes": (_sz, [_i, _i, _i]),
     "isr_pnp_ransac_batch": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _vp, _f, _d, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -87,6 +87,12 @@ struct CorrWs {
   int32_t* hand;         // (query blocks of 256) 1: pass 1 left the block to the dense tile-skip kernel
   int nhand;             // its length
   float skip_default;    // the threshold when `lower` is null
+  // isr_corr_argmax_digits: per image (rows [b rows_per_image, (b + 1) rows_per_image) of the queries) the histogram of the
+  // leading digit of the log-probabilities of its first n_rows[b] rows, counted where logp is written (corr_finish)
+  int32_t* digits;       // (images, isr::kDigitBins) or null
+  const int32_t* n_rows; // (images) or null: every row counts
+  int rows_per_image;
+  int ndigits;           // images * isr::kDigitBins
 };
 
 __device__ __forceinline__ bool gated_off(const CorrWs& ws) {
@@ -699,6 +705,9 @@ template <bool F16 = false>
 __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __restrict__ K, int N, int D,
                                                            int ldk, float inflate, CorrWs ws) {
   __shared__ float red[4];
+  // (before the gate: when the f16-plane kernels are gated off, the chain kernels behind them count into the same histogram)
+  if (ws.digits)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < ws.ndigits; i += kKnBlocks * 256) ws.digits[i] = 0;
   if (gated_off(ws)) return;
   float mx = 0.f;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < ws.nhand; i += kKnBlocks * 256) ws.hand[i] = 0;     // the screened route's hand-over flags
@@ -748,6 +757,24 @@ __global__ __launch_bounds__(256) void corr_keynorm_kernel(const uint16_t* __res
 // The last step for one query, shared by corr_finalize_kernel and the direct kernel's own epilogue (same
 // code, same f64 operations: the two routes give bit-identical outputs): log-probability and lse from the
 // canonical sum, then the margin test.
+// One count per finished query in its image's digit histogram: lanes of the wave that hold the same (image, digit) send ONE
+// integer atomic between them (a launch of the bench adds 9.8 M counts to ~20 bins per image) — integer atomics: the
+// histogram does not depend on the order in which the waves arrive.
+__device__ __forceinline__ void digit_count(const CorrWs& ws, int q, float lp) {
+  const int img = q / ws.rows_per_image, r = q - img * ws.rows_per_image;
+  const bool valid = !ws.n_rows || r < ws.n_rows[img];
+  const int key = valid ? img * isr::kDigitBins + (int)(isr::ordered_bits(lp) >> isr::kDigitShift) : -1;
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+  while (todo != 0ull) {                                   // wave-uniform
+    const int leader = (int)__builtin_ctzll(todo);
+    const int k = __builtin_amdgcn_readlane(key, leader);
+    const unsigned long long same = __builtin_amdgcn_ballot_w64(key == k);
+    if (lane == leader) atomicAdd(&ws.digits[k], (int)__builtin_popcountll(same));
+    todo &= ~same;
+  }
+}
+
 template <int MODE>
 __device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, bool anybad, double L, double Rf, int D, float eabs,
                                             float qn2, float kn2, const CorrWs& ws, int32_t* __restrict__ idx,
@@ -762,6 +789,7 @@ __device__ __forceinline__ void corr_finish(int q, float G1, float G2, int bi, b
   if (!idx) return;                       // lse-only call: no index to certify
   idx[q] = bi;
   if (logp) logp[q] = (float)lp;
+  if (ws.digits) digit_count(ws, q, (float)lp);
   // The zero vector (a padding row of a capacity-sized crop batch, isr_prep_queries_batch): every product is an exact
   // zero, every logit is exactly 0, the arg-max is the lowest key — which is what `bi` already holds — and there is
   // nothing an exact recheck could decide differently.  (With eps = 0 the margin test below would list every such row:
@@ -1168,6 +1196,10 @@ size_t carve(isr::Workspace& w, int P, int N, int dtype, CorrWs* o) {
   o->lower_stride = 1;
   o->skip_T = 42.f;
   o->skip_default = -__builtin_inff();
+  o->digits = nullptr;
+  o->n_rows = nullptr;
+  o->rows_per_image = 1;
+  o->ndigits = 0;
   return w.off;
 }
 
@@ -1471,11 +1503,22 @@ int launch_f32_chain(const float* q, const float* k, int P, int N, int D, int ld
   return ISR_OK;
 }
 
-}  // namespace
+struct DigitArgs {
+  int32_t* hist = nullptr;
+  const int32_t* n_rows = nullptr;
+  int rows_per_image = 1;
+  int images = 0;
+  void apply(CorrWs* w) const {
+    w->digits = hist;
+    w->n_rows = n_rows;
+    w->rows_per_image = rows_per_image;
+    w->ndigits = images * isr::kDigitBins;
+  }
+};
 
-extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
-                               int dtype, int32_t* idx, float* logp, float* lse, void* ws_,
-                               size_t ws_bytes, isr_stream_t stream_) {
+int corr_argmax_impl(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
+                     int dtype, int32_t* idx, float* logp, float* lse, void* ws_,
+                     size_t ws_bytes, isr_stream_t stream_, const DigitArgs& dg) {
   ISR_REQUIRE(Q && K && (idx || (lse && !logp)),
               "isr_corr_argmax: null pointer (idx may be null only for an lse-only call: logp null, lse given)");
   ISR_REQUIRE(P > 0 && N > 0 && D > 0, "isr_corr_argmax: P=%d N=%d D=%d must be positive", P, N, D);
@@ -1498,6 +1541,8 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     int32_t* gate;
     CorrWs ws, cws;
     carve_planes(w, P, N, sp, f16, &q3, &k3, &gate, &ws, &cws);
+    dg.apply(&ws);
+    dg.apply(&cws);
     const CorrPlan p = make_plan(P, N, slots_planes(sp, f16), kWaves * kQB * 32);
     const float* qf = static_cast<const float*>(Q);
     const float* kf = static_cast<const float*>(K);
@@ -1538,6 +1583,7 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
     uint16_t *q2, *k2;
     CorrWs ws;
     carve_split(w, P, N, &q2, &k2, &ws);
+    dg.apply(&ws);
     const CorrPlan p = make_plan(P, N, slots_for(ISR_DTYPE_BF16_LOG2, 128), kWaves * kQB * 32);
     const float* qf = static_cast<const float*>(Q);
     const float* kf = static_cast<const float*>(K);
@@ -1554,9 +1600,35 @@ extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D
   isr::Workspace w(ws_, ws_bytes);
   CorrWs ws;
   carve(w, P, N, dtype, &ws);
+  dg.apply(&ws);
   if (dtype != ISR_DTYPE_F32) {
     return launch_bf16(static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), P, N, D, ldq, ldk,
                        dtype != ISR_DTYPE_BF16, p, ws, idx, logp, lse, F32Rows{nullptr, nullptr, 0, 0, 0}, 1.f, stream, 0, false, screened);
   }
+  // (the chain kernels alone: no key-norm kernel runs ahead of them to zero the histogram)
+  if (dg.hist) ISR_CHECK_HIP(hipMemsetAsync(dg.hist, 0, sizeof(int32_t) * (size_t)dg.images * isr::kDigitBins, stream));
   return launch_f32_chain(static_cast<const float*>(Q), static_cast<const float*>(K), P, N, D, ldq, ldk, p, ws, idx, logp, lse, stream);
+}
+
+}  // namespace
+
+extern "C" int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
+                               int dtype, int32_t* idx, float* logp, float* lse, void* ws_,
+                               size_t ws_bytes, isr_stream_t stream_) {
+  return corr_argmax_impl(Q, K, P, N, D, ldq, ldk, dtype, idx, logp, lse, ws_, ws_bytes, stream_, DigitArgs{});
+}
+
+extern "C" int isr_corr_argmax_digits(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
+                                      int dtype, int32_t* idx, float* logp, float* lse, int rows_per_image,
+                                      const int32_t* n_rows, int32_t* digit_hist, void* ws_, size_t ws_bytes,
+                                      isr_stream_t stream_) {
+  ISR_REQUIRE(idx && logp && digit_hist, "isr_corr_argmax_digits: idx, logp and digit_hist are required (the digits are those of logp)");
+  ISR_REQUIRE(rows_per_image > 0 && P > 0 && P % rows_per_image == 0,
+              "isr_corr_argmax_digits: P=%d is not a whole number of images of %d rows", P, rows_per_image);
+  DigitArgs dg;
+  dg.hist = digit_hist;
+  dg.n_rows = n_rows;
+  dg.rows_per_image = rows_per_image;
+  dg.images = P / rows_per_image;
+  return corr_argmax_impl(Q, K, P, N, D, ldq, ldk, dtype, idx, logp, lse, ws_, ws_bytes, stream_, dg);
 }

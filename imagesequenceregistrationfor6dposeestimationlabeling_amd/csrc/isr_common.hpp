@@ -66,4 +66,14 @@ struct Workspace {
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// The order-preserving unsigned image of a float (radix select of the top-80 % cut, csrc/select_top.hip; its leading
+// 11-bit digit is what K1's epilogue counts for isr_corr_argmax_digits): u(a) < u(b)  <=>  a < b for non-NaN a, b.
+__host__ __device__ __forceinline__ uint32_t ordered_bits(float f) {
+  union { float f; uint32_t u; } c;
+  c.f = f;
+  return c.u ^ ((c.u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+constexpr int kDigitBins = 2048;    // bins of the leading digit (bits 21 .. 31 of ordered_bits)
+constexpr int kDigitShift = 21;
+
 }  // namespace isr

@@ -30,10 +30,7 @@ struct SelState {
   int32_t n;           // number of elements (<= capacity)
 };
 
-__device__ __forceinline__ uint32_t ordered(float f) {
-  const uint32_t b = __float_as_uint(f);
-  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
-}
+__device__ __forceinline__ uint32_t ordered(float f) { return isr::ordered_bits(f); }
 __device__ __forceinline__ float unordered(uint32_t u) {
   const uint32_t b = u ^ ((u >> 31) ? 0x80000000u : 0xFFFFFFFFu);
   return __uint_as_float(b);
@@ -231,10 +228,12 @@ __host__ __device__ inline long select_rank(long n, double frac, int min_n) {
 // n_dev == nullptr: n = P (checked on the host).  Otherwise n = min(P, *n_dev); n = 0, or a rank the
 // reference would raise IndexError for, selects nothing: thr = +inf.
 // One block per image: zeroes the image's three histograms (no memset launch) and sets its state.
+// digits != nullptr: the image's first histogram was formed by K1's epilogue (isr_corr_argmax_digits) and is copied in.
 __global__ void init_state_kernel(SelState* st, int32_t* __restrict__ hist, int P, const int32_t* __restrict__ n_dev,
-                                  double frac, int min_n) {
+                                  double frac, int min_n, const int32_t* __restrict__ digits) {
   st += blockIdx.z; hist += (size_t)blockIdx.z * kHistInts;
-  for (int i = threadIdx.x; i < kHistInts; i += blockDim.x) hist[i] = 0;
+  if (digits) digits += (size_t)blockIdx.z * isr::kDigitBins;
+  for (int i = threadIdx.x; i < kHistInts; i += blockDim.x) hist[i] = (digits && i < isr::kDigitBins) ? digits[i] : 0;
   if (threadIdx.x != 0) return;
   int n = P;
   if (n_dev) n = min(P, max(0, n_dev[blockIdx.z]));
@@ -284,9 +283,11 @@ extern "C" size_t isr_select_top_batch_workspace_bytes(int P, int B) {
   return select_ws_bytes(P, B);
 }
 
+static_assert(isr::kDigitBins == 2048 && isr::kDigitShift == 21, "the first pass of the radix select is hist_kernel<21, 11>");
+
 static int select_top_impl(const float* logp, int P, int64_t ld, int B, const int32_t* n_dev, double frac, int min_n,
                            int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
-                           isr_stream_t stream_) {
+                           isr_stream_t stream_, const int32_t* digits = nullptr) {
   if (!ws || ws_bytes < select_ws_bytes(P, B)) {
     isr::set_error("isr_select_top: workspace %zu < %zu", ws_bytes, select_ws_bytes(P, B));
     return ISR_ERR_WORKSPACE;
@@ -301,8 +302,8 @@ static int select_top_impl(const float* logp, int P, int64_t ld, int B, const in
   int32_t* bc = w.take<int32_t>((size_t)nblocks * B);
   const dim3 gI(1, 1, B), gP(nblocks, 1, B);
 
-  init_state_kernel<<<gI, 256, 0, stream>>>(st, h0, P, n_dev, frac, min_n);
-  hist_kernel<21, 11><<<gP, kThreads, 0, stream>>>(logp, ld, st, h0);
+  init_state_kernel<<<gI, 256, 0, stream>>>(st, h0, P, n_dev, frac, min_n, digits);
+  if (!digits) hist_kernel<21, 11><<<gP, kThreads, 0, stream>>>(logp, ld, st, h0);
   pick_kernel<21, 11, false><<<gI, 1024, 0, stream>>>(h0, st, nullptr);
   hist_kernel<10, 11><<<gP, kThreads, 0, stream>>>(logp, ld, st, h1);
   pick_kernel<10, 11, false><<<gI, 1024, 0, stream>>>(h1, st, nullptr);
@@ -343,6 +344,18 @@ extern "C" int isr_select_top_batch(const float* logp, int P, int B, const int32
     ISR_REQUIRE(rank >= 0 && rank < P, "isr_select_top_batch: rank %ld out of range for P=%d", rank, P);
   }
   return select_top_impl(logp, P, P, B, n_dev, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_);
+}
+
+extern "C" int isr_select_top_batch_digits(const float* logp, int P, int B, const int32_t* n_dev, double frac, int min_n,
+                                           const int32_t* digit_hist, int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws,
+                                           size_t ws_bytes, isr_stream_t stream_) {
+  ISR_REQUIRE(logp && keep && M_dev && digit_hist, "isr_select_top_batch_digits: null pointer");
+  ISR_REQUIRE(P > 0 && B > 0 && B <= 65535, "isr_select_top_batch_digits: P=%d B=%d", P, B);
+  if (!n_dev) {
+    const long rank = select_rank(P, frac, min_n);
+    ISR_REQUIRE(rank >= 0 && rank < P, "isr_select_top_batch_digits: rank %ld out of range for P=%d", rank, P);
+  }
+  return select_top_impl(logp, P, P, B, n_dev, frac, min_n, keep, M_dev, thr_dev, ws, ws_bytes, stream_, digit_hist);
 }
 
 static int gather_impl(const int32_t* idx, const int32_t* keep, const int32_t* M_dev, int P, int B, const float* pts,

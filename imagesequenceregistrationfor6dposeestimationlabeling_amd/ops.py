@@ -255,7 +255,8 @@ def prescale_queries_log2(queries: torch.Tensor) -> torch.Tensor:
 
 
 def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = False,
-                log2_prescaled: bool = False, screened: bool = False):
+                log2_prescaled: bool = False, screened: bool = False, rows_per_image: int | None = None,
+                n_rows: torch.Tensor | None = None):
     """isr_corr_argmax.  queries (P,D), keys (N,D); bf16 tensors take the bf16 MFMA path, f32
     tensors the exact f32 MFMA path (f16/f64 are converted to f32).  Zero columns are appended
     where the kernel needs a padded D (exact: they add 0 to every logit).
@@ -265,8 +266,11 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     screened (with log2_prescaled): ISR_DTYPE_BF16_LOG2_SCREENED — the rows also go through a block-scaled FP6 screen, and
     pieces of the log-sum-exp proven to lie more than T = 21 + ceil(log2 N) log2 units below the query's maximum are never
     formed (indices stay exact, lse moves by < 5e-7; D = 64 only, other shapes run unscreened).  For peaked softmaxes.
-    Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32] on the device."""
-    dev = require_cuda(queries, keys)
+    rows_per_image: isr_corr_argmax_digits — the rows are P / rows_per_image images whose top-80 % cut follows; the call also
+    returns digit_hist (images, 2048) i32, the first histogram of that cut's radix select over logp (of image b's first
+    n_rows[b] rows; n_rows None: all), formed where logp is written: pass it to select_top_batch(..., digit_hist=...).
+    Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32][, digit_hist] on the device."""
+    dev = require_cuda(queries, keys, n_rows)
     if queries.ndim != 2 or keys.ndim != 2 or queries.shape[1] != keys.shape[1]:
         raise ValueError(f"queries {tuple(queries.shape)} / keys {tuple(keys.shape)} must be (P,D),(N,D)")
     P, D = queries.shape
@@ -295,13 +299,25 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     L = lib()
     nbytes = L.isr_corr_argmax_workspace_bytes(P, N, Dp, dtype)
     ws = workspace(dev, nbytes, "corr")
+    hist = None
+    if rows_per_image is not None:
+        if rows_per_image <= 0 or P % rows_per_image:
+            raise ValueError(f"corr_argmax: P={P} is not a whole number of images of {rows_per_image} rows")
+        if n_rows is not None and (n_rows.dtype != torch.int32 or n_rows.numel() != P // rows_per_image):
+            raise ValueError("corr_argmax: n_rows must be (images,) int32")
+        hist = torch.empty((P // rows_per_image, 2048), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev), _timed("corr_argmax", 2.0 * P * N * Dp):
-        rc = L.isr_corr_argmax(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, ptr(idx), ptr(logp), ptr(lse),
-                               ptr(ws), ws.numel(), current_stream(dev))
+        if hist is None:
+            rc = L.isr_corr_argmax(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, ptr(idx), ptr(logp), ptr(lse),
+                                   ptr(ws), ws.numel(), current_stream(dev))
+        else:
+            rc = L.isr_corr_argmax_digits(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, ptr(idx), ptr(logp), ptr(lse),
+                                          int(rows_per_image), ptr(n_rows), ptr(hist), ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_corr_argmax")
     global _last_corr
     _last_corr = (ws, P, N, dtype, dev)
-    return (idx, logp, lse) if want_lse else (idx, logp)
+    out = (idx, logp, lse) if want_lse else (idx, logp)
+    return out if hist is None else out + (hist,)
 
 
 def corr_lse(queries: torch.Tensor, keys: torch.Tensor, log2_prescaled: bool = False, screened: bool = False) -> torch.Tensor:
@@ -713,10 +729,13 @@ def pnp_ransac(p3d, p2d, Kcam, H: int = 500, reperr: float = 2.0, seed: int = 0,
 
 
 # ------------------------------------------------------------------ the per-group (batched) chain
-def select_top_batch(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500, n_dev: torch.Tensor | None = None):
+def select_top_batch(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500, n_dev: torch.Tensor | None = None,
+                     digit_hist: torch.Tensor | None = None):
     """isr_select_top_batch: logp (B, P) -> keep (B, P) i32 (first M[b] valid, ascending), M (B,) i32,
-    thr (B,) f32.  One chain of ten launches for the whole group; outputs are not pre-filled."""
-    dev = require_cuda(logp, n_dev)
+    thr (B,) f32.  One chain of ten launches for the whole group; outputs are not pre-filled.
+    digit_hist (B, 2048) i32: the first histogram as corr_argmax(..., rows_per_image=P, n_rows=n_dev) left it for these
+    values (isr_select_top_batch_digits: nine launches, one read of logp less, the same results)."""
+    dev = require_cuda(logp, n_dev, digit_hist)
     logp = _f32c(logp)
     B, P = logp.shape
     keep = torch.empty((B, P), dtype=torch.int32, device=dev)
@@ -724,9 +743,15 @@ def select_top_batch(logp: torch.Tensor, frac: float = 0.8, min_n: int = 500, n_
     thr = torch.empty(B, dtype=torch.float32, device=dev)
     L = lib()
     ws = workspace(dev, L.isr_select_top_batch_workspace_bytes(P, B), "select")
+    if digit_hist is not None and (digit_hist.dtype != torch.int32 or tuple(digit_hist.shape) != (B, 2048) or not digit_hist.is_contiguous()):
+        raise ValueError(f"select_top_batch: digit_hist must be a contiguous ({B}, 2048) int32 tensor")
     with torch.cuda.device(dev), _timed("select_top", 4.0 * P * B):
-        rc = L.isr_select_top_batch(ptr(logp), P, B, ptr(n_dev), float(frac), int(min_n), ptr(keep), ptr(M_dev),
-                                    ptr(thr), ptr(ws), ws.numel(), current_stream(dev))
+        if digit_hist is None:
+            rc = L.isr_select_top_batch(ptr(logp), P, B, ptr(n_dev), float(frac), int(min_n), ptr(keep), ptr(M_dev),
+                                        ptr(thr), ptr(ws), ws.numel(), current_stream(dev))
+        else:
+            rc = L.isr_select_top_batch_digits(ptr(logp), P, B, ptr(n_dev), float(frac), int(min_n), ptr(digit_hist), ptr(keep),
+                                               ptr(M_dev), ptr(thr), ptr(ws), ws.numel(), current_stream(dev))
     check(rc, "isr_select_top_batch")
     return keep, M_dev, thr
 

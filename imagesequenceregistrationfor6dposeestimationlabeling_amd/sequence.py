@@ -24,6 +24,14 @@ class SequenceModel:
     screened: bool = False       # with log2_queries: ISR_DTYPE_BF16_LOG2_SCREENED (K1 behind the FP6 screen; peaked softmaxes)
 
 
+# True: the group routes (register_crops, register_block) let K1's epilogue form the first histogram of the top-80 % cut
+# (isr_corr_argmax_digits -> isr_select_top_batch_digits): the same results, nine launches instead of ten and
+# one read of logp less per group.  OFF by default: K1 is bound by its wave slots, and the counts — one device-scope integer
+# atomic per wave and distinct digit, 770 000 per 32-image launch on ~20 addresses per image — hold the finishing waves' slots:
+# 29.1 against 26.9 ms per launch alone, the step 5 % slower (profiles/r05_epilogue_histogram_ab.txt; bench.py --epilogue-digits).
+EPILOGUE_DIGITS = False
+
+
 @dataclass
 class ImageResult:
     pose: torch.Tensor     # (3,4) f64 device [R|t]
@@ -145,17 +153,25 @@ def register_crops(model: SequenceModel, feats: torch.Tensor, masks: torch.Tenso
             if keys is None:
                 keys = model.keys if model.keys.shape[1] == Q.shape[2] else ops._pad_cols(model.keys, Q.shape[2])
             S = Q.shape[1]
-            idx_g, logp_g = ops.corr_argmax(Q.view(B * S, -1), keys, log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
+            # (the cut's first histogram is formed in K1's epilogue, of each crop's n_dev live rows: SURVEY 8(f)-2)
+            if EPILOGUE_DIGITS:
+                idx_g, logp_g, hist_g = ops.corr_argmax(Q.view(B * S, -1), keys, log2_prescaled=model.log2_queries,
+                                                        screened=model.screened and model.log2_queries, rows_per_image=S, n_rows=n_dev)
+            else:
+                idx_g, logp_g = ops.corr_argmax(Q.view(B * S, -1), keys, log2_prescaled=model.log2_queries,
+                                                screened=model.screened and model.log2_queries)
+                hist_g = None
             if not serial:
                 done = torch.cuda.Event()
                 done.record(k1_stream)
         s = side[gi % len(side)]
         if not serial:
             s.wait_event(done)
-            for t in (idx_g, logp_g, pix, n_dev):
-                t.record_stream(s)
+            for t in (idx_g, logp_g, hist_g, pix, n_dev):
+                if t is not None:
+                    t.record_stream(s)
         with torch.cuda.stream(s):
-            keep, M, _ = ops.select_top_batch(logp_g.view(B, S), n_dev=n_dev)
+            keep, M, _ = ops.select_top_batch(logp_g.view(B, S), n_dev=n_dev, digit_hist=hist_g)
             p3d, p2d = ops.gather_corr_batch(idx_g.view(B, S), keep, M, model.pts, pix)
             r = ops.pnp_ransac_batch(p3d, p2d, cams[g0:g1], M, H=itr, reperr=reperr, seeds=seeds[g0:g1],
                                      refine_iters=refine_iters, confidence=confidence)
@@ -257,14 +273,16 @@ def register_images(model: SequenceModel, images, cam, itr: int = 500, reperr: f
 
 
 def register_group(model: SequenceModel, idx_g: torch.Tensor, logp_g: torch.Tensor, pix_xy: torch.Tensor, cams,
-                   itr: int, reperr: float, seeds, refine_iters: int, confidence: float = 0.99) -> list[ImageResult]:
+                   itr: int, reperr: float, seeds, refine_iters: int, confidence: float = 0.99,
+                   digit_hist: torch.Tensor | None = None) -> list[ImageResult]:
     """inference.py:282-293 for a GROUP of images whose K1 results are idx_g / logp_g (B, P): the
     top-80 % filter, the correspondence assembly and pnp() run as ONE chain of launches with the
     image on blockIdx.z (isr_select_top_batch, isr_gather_corr_batch, isr_pnp_ransac_batch) — the
     same kernels as the per-image calls, so every image's outputs are bit-identical to
-    register_image's.  pix_xy (P, 2) shared or (B, P, 2); cams one 3x3 or (B, 3, 3)."""
+    register_image's.  pix_xy (P, 2) shared or (B, P, 2); cams one 3x3 or (B, 3, 3).  digit_hist (B, 2048): the cut's first
+    histogram when K1 formed it (ops.corr_argmax(..., rows_per_image=P))."""
     B = idx_g.shape[0]
-    keep, M, _ = ops.select_top_batch(logp_g)
+    keep, M, _ = ops.select_top_batch(logp_g, digit_hist=digit_hist)
     p3d, p2d = ops.gather_corr_batch(idx_g, keep, M, model.pts, pix_xy)
     r = ops.pnp_ransac_batch(p3d, p2d, cams, M, H=itr, reperr=reperr, seeds=seeds, refine_iters=refine_iters,
                              confidence=confidence)
@@ -296,18 +314,25 @@ def register_block(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
     for gi, g0 in enumerate(range(0, n, group)):
         g1 = min(n, g0 + group)
         with torch.cuda.stream(k1_stream):
-            idx_g, logp_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys,
-                                             log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
+            if EPILOGUE_DIGITS:
+                idx_g, logp_g, hist_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys,
+                                                        log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries,
+                                                        rows_per_image=P)
+            else:
+                idx_g, logp_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys,
+                                                log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
+                hist_g = None
             done = torch.cuda.Event()
             done.record(k1_stream)
         s = side[gi % len(side)]
         s.wait_event(done)
-        idx_g.record_stream(s)
-        logp_g.record_stream(s)
+        for t in (idx_g, logp_g, hist_g):
+            if t is not None:
+                t.record_stream(s)
         with torch.cuda.stream(s):
             out += register_group(model, idx_g.view(g1 - g0, P), logp_g.view(g1 - g0, P),
                                   pix_xy if pix_xy.ndim == 2 else pix_xy[g0:g1], cams[g0:g1], itr, reperr,
-                                  [seed0 + j for j in range(g0, g1)], refine_iters, confidence)
+                                  [seed0 + j for j in range(g0, g1)], refine_iters, confidence, digit_hist=hist_g)
     for s in pool:
         cur.wait_stream(s)
     _publish(out, cur)

@@ -30,7 +30,7 @@ extern "C" {
 /* v4 (round 4): isr_corr_argmax accepts idx = logp = NULL (lse-only call), f32 rows run as f16 planes by default
  * (ISR_TUNE_K1_F32_CHAIN values 0-4), new isr_corr_topk / isr_corr_topk_workspace_bytes.
  * v5 (round 5): ISR_DTYPE_BF16_LOG2_SCREENED, isr_corr_argmax_screen_redone; isr_corr_topk_workspace_bytes sized by the key
- * ranges a call uses. */
+ * ranges a call uses; isr_corr_argmax_digits + isr_select_top_batch_digits (the cut's first histogram from K1's epilogue). */
 #define ISR_ABI_VERSION 5
 
 #define ISR_OK 0
@@ -114,6 +114,19 @@ size_t isr_corr_argmax_workspace_bytes(int P, int N, int D, int dtype);
 int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk, int dtype,
                     int32_t* idx, float* logp, float* lse, void* ws, size_t ws_bytes,
                     isr_stream_t stream);
+
+/* getCors for a GROUP of images whose top-80 % cut follows (inference.py:142-149 then :282-290): the same
+ * call, the same outputs bit for bit, plus — formed where each logp is written, so the cut does not read logp once more for it —
+ * the first histogram of the cut's radix select.  The P rows are P / rows_per_image images of rows_per_image rows each
+ * (P % rows_per_image == 0); of image b the first n_rows[b] rows count (n_rows NULL: all of them; the padding rows of a
+ * capacity-sized crop batch do not).  digit_hist (P / rows_per_image, 2048) int32 is ZEROED by the call, then
+ *     digit_hist[b][u(logp[q]) >> 21] += 1   for every counted row q of image b,
+ * u = the order-preserving unsigned image of a float (sign bit flipped for x >= 0, all bits for x < 0).  Integer atomics:
+ * the histogram is a function of logp alone.  idx, logp and digit_hist are required; every dtype and route of
+ * isr_corr_argmax.  Hand digit_hist to isr_select_top_batch_digits. */
+int isr_corr_argmax_digits(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk, int dtype,
+                           int32_t* idx, float* logp, float* lse, int rows_per_image, const int32_t* n_rows,
+                           int32_t* digit_hist, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* Diagnostics: number of queries the last isr_corr_argmax call on this workspace (same P, N, dtype)
  * decided by the exact recheck; -1 for ISR_DTYPE_F32.  count_host is a HOST pointer; synchronises. */
@@ -227,6 +240,12 @@ size_t isr_select_top_batch_workspace_bytes(int P, int B);
 int isr_select_top_batch(const float* logp, int P, int B, const int32_t* n_dev, double frac, int min_n,
                          int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws, size_t ws_bytes,
                          isr_stream_t stream);
+/* The same cut with its first histogram supplied: digit_hist (B, 2048) as isr_corr_argmax_digits left it for these logp
+ * (rows_per_image = P, n_rows = n_dev).  Nine launches instead of ten and one read of logp less; results identical to
+ * isr_select_top_batch's (same later passes on the same values).  Workspace: isr_select_top_batch_workspace_bytes. */
+int isr_select_top_batch_digits(const float* logp, int P, int B, const int32_t* n_dev, double frac, int min_n,
+                                const int32_t* digit_hist, int32_t* keep, int32_t* M_dev, float* thr_dev, void* ws,
+                                size_t ws_bytes, isr_stream_t stream);
 
 /* a3  correspondence assembly  (inference.py:274-280, 289-290)
  * p3d[m] = pts[idx[keep[m]]], p2d[m] = pix_xy[keep[m]]  for m < *M_dev.  pts (N,3), pix_xy (P,2)

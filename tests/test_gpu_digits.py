@@ -1,0 +1,101 @@
+"""GPU: the top-80 % cut's first histogram formed in K1's epilogue (isr_corr_argmax_digits +
+isr_select_top_batch_digits), inference.py:142-149 then :282-290.
+  * the histogram is EXACTLY the histogram of the leading 11-bit digit of the order-preserving image of the logp the same call
+    wrote, over each image's counted rows — on every route of K1 (every query is finished exactly once, wherever);
+  * idx / logp / lse are the plain call's bits;
+  * the cut that starts from it keeps the same rows, count and threshold as the ten-launch cut.
+(The group routes of sequence.py use the pair; tests/test_gpu_sequence.py compares them, image by image and bit for bit, with
+register_images, which runs the plain calls.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _digits(logp, S, n_rows):
+    """numpy restatement: u = bits ^ (sign ? ~0 : 0x80000000); bin = u >> 21; per image over its first n rows."""
+    b = logp.view(np.uint32)
+    u = np.where(b >> 31, ~b, b ^ np.uint32(0x80000000)).astype(np.uint32)
+    d = (u >> 21).astype(np.int64).reshape(-1, S)
+    out = np.zeros((d.shape[0], 2048), np.int32)
+    for i in range(d.shape[0]):
+        out[i] = np.bincount(d[i, : n_rows[i]], minlength=2048)
+    return out
+
+
+def _data(rng, B, S, N, D, tau=5.0):
+    K = rng.normal(0, 1, (N, D)).astype(np.float32)
+    K *= tau / np.linalg.norm(K, axis=1, keepdims=True)
+    gt = rng.integers(N, size=B * S)
+    Q = (K[gt] + 0.35 * rng.normal(0, 1, (B * S, D))).astype(np.float32)
+    kind = rng.random(B * S)
+    Q[kind < 0.1] = rng.normal(0, 1, (int((kind < 0.1).sum()), D))    # flat rows: logp far from 0
+    Q[(kind > 0.1) & (kind < 0.2)] = 0.0                              # padding rows: logp = -ln N
+    Q[(kind > 0.2) & (kind < 0.22)] *= 12.0                           # outside the direct sums' range: the fallback finishes them
+    return Q, K
+
+
+@pytest.mark.parametrize("route,B,S,N,D,split", [
+    ("log2", 4, 3000, 20000, 64, 0), ("log2", 3, 1111, 5000, 64, 3), ("bf16", 2, 2048, 9000, 32, 0), ("bf16", 5, 700, 300, 128, 2),
+    ("screened", 4, 3000, 20000, 64, 0), ("f32", 3, 1500, 6000, 64, 0), ("f32", 2, 900, 3000, 12, 0), ("f32chain", 2, 900, 3000, 40, 0),
+    ("log2", 1, 307200, 2000, 64, 0),
+])
+def test_k1_digit_histogram_is_the_histogram_of_its_logp(cuda0, route, B, S, N, D, split):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(B * 1000 + S + N + D)
+    Q, K = _data(rng, B, S, N, D, tau=8.0 if route == "screened" else 5.0)
+    n_rows = rng.integers(0, S + 1, size=B).astype(np.int32)
+    n_rows[0] = S
+    if B > 1:
+        n_rows[1] = 0
+    kw = {}
+    if route in ("f32", "f32chain"):
+        q, k = torch.from_numpy(Q).to(cuda0), torch.from_numpy(K).to(cuda0)
+    else:
+        log2 = route != "bf16"
+        q = (ops.prescale_queries_log2(torch.from_numpy(Q)) if log2 else torch.from_numpy(Q).bfloat16()).to(cuda0)
+        k = torch.from_numpy(K).bfloat16().to(cuda0)
+        kw = dict(log2_prescaled=log2, screened=route == "screened")
+    tune = {}
+    if split:
+        tune["k1_split"] = split
+    if route == "f32chain":
+        tune["k1_f32_chain"] = 1
+    with ops.tuning(**tune):
+        plain = ops.corr_argmax(q, k, want_lse=True, **kw)
+        nd = torch.from_numpy(n_rows).to(cuda0)
+        for n_t, n_h in ((nd, n_rows), (None, np.full(B, S, np.int32))):
+            got = ops.corr_argmax(q, k, want_lse=True, rows_per_image=S, n_rows=n_t, **kw)
+            torch.cuda.synchronize()
+            for a, b in zip(plain, got[:3]):
+                assert torch.equal(a, b)
+            want = _digits(got[1].cpu().numpy(), S, n_h)
+            assert np.array_equal(got[3].cpu().numpy(), want)
+            assert int(got[3].sum().item()) == int(n_h.sum())
+            # the cut from the supplied histogram = the ten-launch cut
+            lv = got[1].view(B, S)
+            k10, m10, t10 = ops.select_top_batch(lv, n_dev=n_t)
+            k9, m9, t9 = ops.select_top_batch(lv, n_dev=n_t, digit_hist=got[3])
+            assert torch.equal(m10, m9) and torch.equal(t10.view(torch.int32), t9.view(torch.int32))
+            for b in range(B):
+                assert torch.equal(k10[b, : int(m10[b])], k9[b, : int(m9[b])])
+
+
+def test_digit_calls_reject_what_they_cannot_do(cuda0):
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    q = torch.randn(1000, 64, device=cuda0).bfloat16()
+    k = torch.randn(500, 64, device=cuda0).bfloat16()
+    with pytest.raises(ValueError):
+        ops.corr_argmax(q, k, rows_per_image=300)                      # 1000 rows are not whole images of 300
+    with pytest.raises(ValueError):
+        ops.corr_argmax(q, k, rows_per_image=500, n_rows=torch.zeros(3, dtype=torch.int32, device=cuda0))
+    idx, logp, hist = ops.corr_argmax(q, k, rows_per_image=500)
+    with pytest.raises(ValueError):
+        ops.select_top_batch(logp.view(2, 500), digit_hist=hist[:1])
+    # the raw entry: rows_per_image must divide P
+    L = ops.lib()
+    ws = ops.workspace(cuda0, L.isr_corr_argmax_workspace_bytes(1000, 500, 64, 1), "corr")
+    rc = L.isr_corr_argmax_digits(ops.ptr(q), ops.ptr(k), 1000, 500, 64, 64, 64, 1, ops.ptr(idx), ops.ptr(logp), None, 300, None,
+                                  ops.ptr(hist), ops.ptr(ws), ws.numel(), ops.current_stream(cuda0))
+    assert rc != 0 and b"whole number of images" in L.isr_last_error()
