@@ -19,9 +19,12 @@
 // 5 % + 1.5 % on |k| = 8 planted data) are formed on the bf16 matrix cores from the ORIGINAL rows, and only those results enter
 // sums and maxima: indices, logp and lse never see an FP6 number.
 //
-// L_q: pass 0 (corr_fp6_lower_kernel) finds, per query, the LOWEST 32-key tile holding the largest s~ (a deterministic
-// function of the two quantised rows), redoes that tile in bf16 and takes its largest logit: a true logit of the query, hence
-// a lower bound of its maximum — on data with a clear winner it IS the maximum.
+// L_q: pass 0 (corr_fp6_lower_kernel) finds, per query, A 32-key tile holding the largest s~ up to the 13 mantissa bits the
+// tile's number displaces in the running maximum (among equal values the bit pattern decides: the highest-numbered tile for
+// positive s~, e.g. the LAST tile for a zero query — a deterministic function of the two quantised rows either way), redoes
+// that tile in bf16 and takes its largest logit: a true logit of the query, hence a lower bound of its maximum — on data with
+// a clear winner it IS the maximum.  Nothing downstream assumes which of several tied tiles it is: pass 1 enters every piece in
+// tile order, so "the first tile reaching the maximum" is found as in the dense kernel.
 // Worst case (flat logits: nothing can be skipped): corr_fp6_sparse_kernel screens its first stage ahead of its main loop and hands
 // a 256-query block with more than a quarter of those items flagged to the dense tile-skip kernel
 // (corr_bf16_direct_kernel<.., SKIP = 1>), which applies the same rule to the same bf16 logits: identical bits either way, and
