@@ -510,6 +510,40 @@ __device__ void gn_solve(const double* __restrict__ partial, int nblocks, double
 }
 
 
+// One correspondence's terms of the Gauss-Newton normal equations (both refit routes: the same operations, the same bits).
+// Explicit fused multiply-adds: the library is built with -ffp-contract=off, and as plain `a * b + c * d` expressions these
+// 60 product-sums were 2 multiplications + 2 additions each — the refit is bound by f64 issue (8 192 waves x ~15
+// correspondences per launch, 24 launches per bench step) and ran ~210 f64 instructions per correspondence; now ~115.
+__device__ __forceinline__ void gn_point(const double (&T)[12], const Cam& cam, double X, double Y, double Z, double ox, double oy,
+                                         double (&acc)[kNAcc]) {
+  const double xc = __builtin_fma(T[0], X, __builtin_fma(T[1], Y, __builtin_fma(T[2], Z, T[3])));
+  const double yc = __builtin_fma(T[4], X, __builtin_fma(T[5], Y, __builtin_fma(T[6], Z, T[7])));
+  const double zc = __builtin_fma(T[8], X, __builtin_fma(T[9], Y, __builtin_fma(T[10], Z, T[11])));
+  const double px = __builtin_fma(cam.k[0], xc, __builtin_fma(cam.k[1], yc, cam.k[2] * zc));
+  const double py = __builtin_fma(cam.k[3], xc, __builtin_fma(cam.k[4], yc, cam.k[5] * zc));
+  const double pz = __builtin_fma(cam.k[6], xc, __builtin_fma(cam.k[7], yc, cam.k[8] * zc));
+  const double ipz = 1.0 / pz;
+  const double u = px * ipz, v = py * ipz;
+  const double ru = u - ox, rv = v - oy;
+  // d(u,v)/dXc = (K_row - (u,v) K_row2) / pz
+  const double a0 = __builtin_fma(-u, cam.k[6], cam.k[0]) * ipz, a1 = __builtin_fma(-u, cam.k[7], cam.k[1]) * ipz,
+               a2 = __builtin_fma(-u, cam.k[8], cam.k[2]) * ipz;
+  const double b0 = __builtin_fma(-v, cam.k[6], cam.k[3]) * ipz, b1 = __builtin_fma(-v, cam.k[7], cam.k[4]) * ipz,
+               b2 = __builtin_fma(-v, cam.k[8], cam.k[5]) * ipz;
+  // Xc' = Xc + w x Xc + dt  ->  dXc/dw = -[Xc]x, dXc/dt = I
+  const double Ju[6] = {__builtin_fma(a2, yc, -(a1 * zc)), __builtin_fma(a0, zc, -(a2 * xc)), __builtin_fma(a1, xc, -(a0 * yc)), a0, a1, a2};
+  const double Jv[6] = {__builtin_fma(b2, yc, -(b1 * zc)), __builtin_fma(b0, zc, -(b2 * xc)), __builtin_fma(b1, xc, -(b0 * yc)), b0, b1, b2};
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = i; j < 6; ++j) { acc[k] = __builtin_fma(Ju[i], Ju[j], __builtin_fma(Jv[i], Jv[j], acc[k])); ++k; }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) acc[21 + i] = __builtin_fma(Ju[i], ru, __builtin_fma(Jv[i], rv, acc[21 + i]));
+  acc[27] = __builtin_fma(ru, ru, __builtin_fma(rv, rv, acc[27]));
+  acc[28] += 1.0;
+}
+
 __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
     const float* __restrict__ p3d, const float* __restrict__ p2d, const int32_t* __restrict__ M_dev, int M_cap,
     const uint32_t* __restrict__ mask, int mask_words, const ImgDev* __restrict__ ib, const double* __restrict__ Rt,
@@ -535,31 +569,7 @@ __global__ __launch_bounds__(kRefThreads) void gn_accumulate_kernel(
     for (int i = 0; i < 12; ++i) T[i] = Rt[i];
     for (int m = blockIdx.x * kRefThreads + threadIdx.x; m < M; m += kRefBlocks * kRefThreads) {
       if (mask && !((mask[m >> 5] >> (m & 31)) & 1u)) continue;
-      const double X = p3d[3 * (size_t)m], Y = p3d[3 * (size_t)m + 1], Z = p3d[3 * (size_t)m + 2];
-      const double xc = T[0] * X + T[1] * Y + T[2] * Z + T[3];
-      const double yc = T[4] * X + T[5] * Y + T[6] * Z + T[7];
-      const double zc = T[8] * X + T[9] * Y + T[10] * Z + T[11];
-      const double px = cam.k[0] * xc + cam.k[1] * yc + cam.k[2] * zc;
-      const double py = cam.k[3] * xc + cam.k[4] * yc + cam.k[5] * zc;
-      const double pz = cam.k[6] * xc + cam.k[7] * yc + cam.k[8] * zc;
-      const double ipz = 1.0 / pz;
-      const double u = px * ipz, v = py * ipz;
-      const double ru = u - (double)p2d[2 * (size_t)m], rv = v - (double)p2d[2 * (size_t)m + 1];
-      // d(u,v)/dXc = (K_row - (u,v) K_row2) / pz
-      const double a0 = (cam.k[0] - u * cam.k[6]) * ipz, a1 = (cam.k[1] - u * cam.k[7]) * ipz, a2 = (cam.k[2] - u * cam.k[8]) * ipz;
-      const double b0 = (cam.k[3] - v * cam.k[6]) * ipz, b1 = (cam.k[4] - v * cam.k[7]) * ipz, b2 = (cam.k[5] - v * cam.k[8]) * ipz;
-      // Xc' = Xc + w x Xc + dt  ->  dXc/dw = -[Xc]x, dXc/dt = I
-      const double Ju[6] = {a2 * yc - a1 * zc, a0 * zc - a2 * xc, a1 * xc - a0 * yc, a0, a1, a2};
-      const double Jv[6] = {b2 * yc - b1 * zc, b0 * zc - b2 * xc, b1 * xc - b0 * yc, b0, b1, b2};
-      int k = 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = i; j < 6; ++j) acc[k++] += Ju[i] * Ju[j] + Jv[i] * Jv[j];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) acc[21 + i] += Ju[i] * ru + Jv[i] * rv;
-      acc[27] += ru * ru + rv * rv;
-      acc[28] += 1.0;
+      gn_point(T, cam, p3d[3 * (size_t)m], p3d[3 * (size_t)m + 1], p3d[3 * (size_t)m + 2], p2d[2 * (size_t)m], p2d[2 * (size_t)m + 1], acc);
     }
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -665,29 +675,7 @@ __global__ __launch_bounds__(kRefThreads) void gn_small_kernel(
       for (int i = 0; i < 12; ++i) T[i] = Ts[i];
       for (int m = tid; m < M; m += kRefThreads) {
         if (!((mask[m >> 5] >> (m & 31)) & 1u)) continue;
-        const double X = p3d[3 * (size_t)m], Y = p3d[3 * (size_t)m + 1], Z = p3d[3 * (size_t)m + 2];
-        const double xc = T[0] * X + T[1] * Y + T[2] * Z + T[3];
-        const double yc = T[4] * X + T[5] * Y + T[6] * Z + T[7];
-        const double zc = T[8] * X + T[9] * Y + T[10] * Z + T[11];
-        const double px = cam.k[0] * xc + cam.k[1] * yc + cam.k[2] * zc;
-        const double py = cam.k[3] * xc + cam.k[4] * yc + cam.k[5] * zc;
-        const double pz = cam.k[6] * xc + cam.k[7] * yc + cam.k[8] * zc;
-        const double ipz = 1.0 / pz;
-        const double u = px * ipz, v = py * ipz;
-        const double ru = u - (double)p2d[2 * (size_t)m], rv = v - (double)p2d[2 * (size_t)m + 1];
-        const double a0 = (cam.k[0] - u * cam.k[6]) * ipz, a1 = (cam.k[1] - u * cam.k[7]) * ipz, a2 = (cam.k[2] - u * cam.k[8]) * ipz;
-        const double b0 = (cam.k[3] - v * cam.k[6]) * ipz, b1 = (cam.k[4] - v * cam.k[7]) * ipz, b2 = (cam.k[5] - v * cam.k[8]) * ipz;
-        const double Ju[6] = {a2 * yc - a1 * zc, a0 * zc - a2 * xc, a1 * xc - a0 * yc, a0, a1, a2};
-        const double Jv[6] = {b2 * yc - b1 * zc, b0 * zc - b2 * xc, b1 * xc - b0 * yc, b0, b1, b2};
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = i; j < 6; ++j) acc[k++] += Ju[i] * Ju[j] + Jv[i] * Jv[j];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] += Ju[i] * ru + Jv[i] * rv;
-        acc[27] += ru * ru + rv * rv;
-        acc[28] += 1.0;
+        gn_point(T, cam, p3d[3 * (size_t)m], p3d[3 * (size_t)m + 1], p3d[3 * (size_t)m + 2], p2d[2 * (size_t)m], p2d[2 * (size_t)m + 1], acc);
       }
       const int wave = tid >> 6, lane = tid & 63;
 #pragma unroll
