@@ -82,6 +82,9 @@ def parse_args():
                     help="A/B: K1 forms the cut's first histogram in its epilogue (isr_corr_argmax_digits + "
                          "isr_select_top_batch_digits, SURVEY 8(f)-2) instead of the plain isr_corr_argmax + ten-launch "
                          "isr_select_top_batch pair; same results, 5 %% slower (profiles/r05_epilogue_histogram_ab.txt)")
+    ap.add_argument("--k1-one-call", action="store_true",
+                    help="A/B: one isr_corr_argmax call per group on the K1 stream (sequence.K1_SPLIT_CLOSE = False) instead of the "
+                         "call's closing kernels on the group's side stream (isr_corr_argmax_phase)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--confidence", type=float, default=0.99,
                     help="RANSAC confidence (cv2.solvePnPRansac's parameter; its default 0.99 is what the reference's "
@@ -550,6 +553,8 @@ def main():
     n_local, n_total = args.images, args.images * world
     if args.epilogue_digits:
         sequence.EPILOGUE_DIGITS = True
+    if args.k1_one_call:
+        sequence.K1_SPLIT_CLOSE = False
     if args.tune:
         ops.set_tuning(**{k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(","))})
     Kcam = synth.camera(args.width, args.height)
@@ -896,6 +901,10 @@ def main():
                          "unit": "TFLOP/s", "frac": k1 / PEAK_BF16_MFMA, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": 2.0 * P * max(args.group, 1) * D + 2.0 * N * D + 8.0 * P * max(args.group, 1),
                          "ms_per_launch": k1_ms, "launches": calls,
+                         "ms_per_launch_covers": ("HIP events on the K1 stream around the opening half of each call: corr_keynorm_kernel + "
+                                                  "the chip-filling kernel (the closing kernels — fallback, finalize, recheck, merge — run on "
+                                                  "the group's side stream: isr_corr_argmax_phase)" if sequence.K1_SPLIT_CLOSE and args.group > 1
+                                                  else "HIP events on the K1 stream around the whole isr_corr_argmax call"),
                          "clock_mhz_under_kernel": k1_clock_mhz,
                          "frac_at_held_clock": (k1 / (PEAK_BF16_MFMA * k1_clock_mhz / 2400.0)) if k1_clock_mhz else None,
                          "clock_note": "peak is quoted at the 2400 MHz boost clock; frac_at_held_clock scales it to the clock "

@@ -52,6 +52,7 @@ SIGNATURES = {
     "isr_corr_argmax_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "isr_corr_argmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "isr_corr_argmax_digits": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "isr_corr_argmax_phase": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _sz, _vp]),
     "isr_corr_argmax_recheck_count": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_corr_argmax_recheck_count_f32": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),
     "isr_corr_argmax_screen_redone": (_i, [_vp, _sz, _i, _i, _i, _vp, _vp]),

@@ -1368,7 +1368,11 @@ namespace {
 // f16: the planes are f16 (RowFrags), eabs the margin test's absolute term.
 int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int ldq, int ldk, bool log2, const CorrPlan& p,
                 const CorrWs& ws, int32_t* idx, float* logp, float* lse, F32Rows f32, float kn_inflate, hipStream_t stream,
-                int sp = 0, bool f16 = false, bool screened = false) {
+                int sp = 0, bool f16 = false, bool screened = false, int phase = 3) {
+  // phase bit 0 ("open"): the key-norm kernel and the chip-filling kernel(s); bit 1 ("close"): fallback, finalize, recheck, merge —
+  // small launches at low occupancy that a caller may put on another stream beside the NEXT call's chip-filling kernel
+  // (isr_corr_argmax_phase)
+  const bool ph1 = (phase & 1) != 0, ph2 = (phase & 2) != 0;
   const float eabs = (sp && f16) ? split_eabs(sp) : 0.f;
   const bool lse_only = idx == nullptr;      // no maxima, no recovery, no recheck (LSE instantiations where they exist)
   const dim3 grid(p.qblocks, p.nsplit);
@@ -1384,44 +1388,57 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
   const int cgrid = (int)(((long)p.qblocks * p.nchunks < kFallbackGrid) ? (long)p.qblocks * p.nchunks : kFallbackGrid);   // fallback: strides over listed blocks x chunks
   const dim3 rgrid(16 * kRSplitGrid);   // workgroups = key ranges (by list length, <= 64) x slots striding over the groups of 256 listed queries
   const double scale = log2 ? 0.6931471805599453094 : 1.0;   // the oracle's logit_scale
-  if (f16) corr_keynorm_kernel<true><<<kKnBlocks, 256, 0, stream>>>(k, N, 16 * sp, ldk, kn_inflate, ws);
-  else corr_keynorm_kernel<false><<<kKnBlocks, 256, 0, stream>>>(k, N, sp ? 16 * sp : D, ldk, kn_inflate, ws);   // planes: |k1|^2
+  if (ph1) {
+    if (f16) corr_keynorm_kernel<true><<<kKnBlocks, 256, 0, stream>>>(k, N, 16 * sp, ldk, kn_inflate, ws);
+    else corr_keynorm_kernel<false><<<kKnBlocks, 256, 0, stream>>>(k, N, sp ? 16 * sp : D, ldk, kn_inflate, ws);   // planes: |k1|^2
+  }
 #define ISR_LAUNCH_BF16(DKv)                                                                                  \
   do {                                                                                                        \
     if (log2) {                                                                                               \
+      if (ph1) {                                                                                              \
       if (lse_only && DKv <= 2)   /* LSE kernels where both copies of their loop fit the registers: D <= 32 */ \
         corr_bf16_direct_kernel<DKv, kQB, false, DKv, 0, false, (DKv <= 2)><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, \
                                                                               p.range_chunks, ws, idx, logp, lse); \
       else                                                                                                    \
       corr_bf16_direct_kernel<DKv, kQB, false><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,          \
                                                                               p.range_chunks, ws, idx, logp, lse); \
+      }                                                                                                       \
+      if (ph2) {                                                                                              \
       corr_bf16_kernel<DKv, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,      \
                                                                   p.nchunks, ws);  \
       corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
+      }                                                                                                       \
     } else {                                                                                                  \
+      if (ph1)                                                                                                \
       corr_bf16_direct_kernel<DKv, kQB, true><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,           \
                                                                              p.range_chunks, ws, idx, logp, lse); \
+      if (ph2) {                                                                                              \
       corr_bf16_kernel<DKv, false><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,     \
                                                                    p.nchunks, ws); \
       corr_finalize_kernel<2><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, \
                                                               idx, logp, lse);                               \
+      }                                                                                                       \
     }                                                                                                         \
-    if (!lse_only) corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);  \
+    if (ph2 && !lse_only) corr_recheck_kernel<DKv><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);  \
   } while (0)
 #define ISR_LAUNCH_PLANES(SPv, F16v)                                                                                              \
   do {                                                                                                                            \
+    if (ph1) {                                                                                                                    \
     if (lse_only && F16v && SPv <= 2)                                                                                             \
       corr_bf16_direct_kernel<3 * SPv, kQB, false, 3 * SPv, SPv, F16v, (F16v && SPv <= 2)><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,  \
                                                                                                      p.range_chunks, ws, idx, logp, lse); \
     else                                                                                                                          \
     corr_bf16_direct_kernel<3 * SPv, kQB, false, 3 * SPv, SPv, F16v><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk,          \
                                                                                                      p.range_chunks, ws, idx, logp, lse); \
+    }                                                                                                                             \
+    if (ph2) {                                                                                                                    \
     corr_bf16_kernel<3 * SPv, true, SPv, F16v><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks,   \
                                                                                 p.nchunks, ws);                                    \
     corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);   \
     if (!lse_only)                                                                                                                \
       corr_recheck_kernel<3 * SPv, SPv, F16v><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);    \
+    }                                                                                                                             \
   } while (0)
   if (sp) {          // plane routes (log2 domain, f32 originals decide the recheck)
     switch (sp * 2 + (f16 ? 1 : 0)) {
@@ -1439,21 +1456,26 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
                                             hipFuncAttributeMaxDynamicSharedMemorySize, kDynLds));
           attr_set = true;
         }
-        corr_bf16_direct_kernel<24, kQB, false, 24, 8, true, false><<<grid, kThreads, kDynLds, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks,
-                                                                                                       ws, idx, logp, lse);
-        corr_bf16_kernel<24, true, 8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
-        corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
-        if (!lse_only) corr_recheck_kernel<24, 8, true><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
+        if (ph1)
+          corr_bf16_direct_kernel<24, kQB, false, 24, 8, true, false><<<grid, kThreads, kDynLds, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks,
+                                                                                                         ws, idx, logp, lse);
+        if (ph2) {
+          corr_bf16_kernel<24, true, 8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
+          corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
+          if (!lse_only) corr_recheck_kernel<24, 8, true><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
+        }
         break;
       }
     }
   } else
 #undef ISR_LAUNCH_PLANES
   if (f32.q) {       // split-f32 route: 128-wide rows whose last two blocks are zero, log2 domain
-    corr_bf16_direct_kernel<8, kQB, false, 6><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws, idx, logp, lse);
-    corr_bf16_kernel<8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
-    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
-    if (!lse_only) corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
+    if (ph1) corr_bf16_direct_kernel<8, kQB, false, 6><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, ws, idx, logp, lse);
+    if (ph2) {
+      corr_bf16_kernel<8, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, ws);
+      corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
+      if (!lse_only) corr_recheck_kernel<8><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, ws);
+    }
   } else
   if (screened) {     // the screened route (corr_sparse.hpp): one key range, D = 64, log2 domain
     ISR_REQUIRE(p.nsplit == 1 && D == 64 && log2, "isr_corr_argmax: the screened route runs D = 64 log2-domain rows over one key range");
@@ -1462,16 +1484,20 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     w2.lower_stride = kLowStride;
     w2.skip_T = (float)screen_T(N);
     const unsigned gq = (unsigned)((2l * P + 255) / 256), gk = (unsigned)((2l * N + 255) / 256);
-    corr_quant_fp6_kernel<false><<<gk, 256, 0, stream>>>(k, N, ldk, ws.k6, nullptr, ws.kmax, ws);
-    corr_quant_fp6_kernel<true><<<gq, 256, 0, stream>>>(q, P, ldq, ws.q6, ws.qnrm, nullptr, ws);
-    corr_fp6_lower_kernel<<<(P + kQPB0 - 1) / kQPB0, kThreads, 0, stream>>>(ws.q6, ws.k6, q, k, P, N, ldq, ldk, ws.lowbuf, ws);
-    corr_fp6_sparse_kernel<<<(P + kQPB1 - 1) / kQPB1, kThreads, 0, stream>>>(ws.q6, ws.k6, q, k, P, N, ldq, ldk, ws.qnrm, ws.kmax, w2, idx, logp, lse);
-    // query blocks pass 1 handed over (most of their first tiles had to be redone: flat logits): the dense kernel with the same
-    // rule — a piece counts when its exact maximum reaches L_q - T — on the same bf16 logits; every other block leaves at once
-    corr_bf16_direct_kernel<4, kQB, false, 4, 0, false, false, 1><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, w2, idx, logp, lse);
-    corr_bf16_kernel<4, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, w2);
-    corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, w2, idx, logp, lse);
-    if (!lse_only) corr_recheck_kernel<4><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, w2);
+    if (ph1) {
+      corr_quant_fp6_kernel<false><<<gk, 256, 0, stream>>>(k, N, ldk, ws.k6, nullptr, ws.kmax, ws);
+      corr_quant_fp6_kernel<true><<<gq, 256, 0, stream>>>(q, P, ldq, ws.q6, ws.qnrm, nullptr, ws);
+      corr_fp6_lower_kernel<<<(P + kQPB0 - 1) / kQPB0, kThreads, 0, stream>>>(ws.q6, ws.k6, q, k, P, N, ldq, ldk, ws.lowbuf, ws);
+      corr_fp6_sparse_kernel<<<(P + kQPB1 - 1) / kQPB1, kThreads, 0, stream>>>(ws.q6, ws.k6, q, k, P, N, ldq, ldk, ws.qnrm, ws.kmax, w2, idx, logp, lse);
+      // query blocks pass 1 handed over (most of their first tiles had to be redone: flat logits): the dense kernel with the same
+      // rule — a piece counts when its exact maximum reaches L_q - T — on the same bf16 logits; every other block leaves at once
+      corr_bf16_direct_kernel<4, kQB, false, 4, 0, false, false, 1><<<grid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, w2, idx, logp, lse);
+    }
+    if (ph2) {
+      corr_bf16_kernel<4, true><<<cgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.range_chunks, p.qblocks, p.nchunks, w2);
+      corr_finalize_kernel<1><<<fin_bf16, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, w2, idx, logp, lse);
+      if (!lse_only) corr_recheck_kernel<4><<<rgrid, kThreads, 0, stream>>>(q, k, P, N, ldq, ldk, p.rsplit, scale, f32, w2);
+    }
   } else
   switch (D) {
     case 16: ISR_LAUNCH_BF16(1); break;
@@ -1480,25 +1506,28 @@ int launch_bf16(const uint16_t* q, const uint16_t* k, int P, int N, int D, int l
     default: ISR_LAUNCH_BF16(8); break;
   }
 #undef ISR_LAUNCH_BF16
-  if (!lse_only) corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, N, p.rsplit, ws, idx);
+  if (ph2 && !lse_only) corr_recheck_merge_kernel<<<64, 256, 0, stream>>>(P, N, p.rsplit, ws, idx);
   ISR_CHECK_LAUNCH("corr bf16 kernels");
   return ISR_OK;
 }
 
 // the f32-MFMA chain kernels of one call
 int launch_f32_chain(const float* q, const float* k, int P, int N, int D, int ldq, int ldk, const CorrPlan& p, const CorrWs& ws,
-                     int32_t* idx, float* logp, float* lse, hipStream_t stream) {
+                     int32_t* idx, float* logp, float* lse, hipStream_t stream, int phase = 3) {
   ISR_REQUIRE(D <= 128, "isr_corr_argmax(f32): D=%d > 128", D);
+  const bool ph1 = (phase & 1) != 0, ph2 = (phase & 2) != 0;
   const dim3 grid(p.qblocks, p.nsplit);
   const int fin_blocks = (P + 255) / 256;
   const float eabs = 0.f;
-  if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-  else if (D <= 12) corr_f32_kernel<12><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);   // the reference's 12-D descriptors: 6 k-steps, not 8
-  else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-  else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-  else if (D <= 64) corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-  else corr_f32_kernel<128><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
-  corr_finalize_kernel<0><<<fin_blocks, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
+  if (ph1) {
+    if (D <= 8) corr_f32_kernel<8><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 12) corr_f32_kernel<12><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);   // the reference's 12-D descriptors: 6 k-steps, not 8
+    else if (D <= 16) corr_f32_kernel<16><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 32) corr_f32_kernel<32><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else if (D <= 64) corr_f32_kernel<64><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+    else corr_f32_kernel<128><<<grid, kThreads, 0, stream>>>(q, k, P, N, D, ldq, ldk, p.range_chunks, ws);
+  }
+  if (ph2) corr_finalize_kernel<0><<<fin_blocks, 256, 0, stream>>>(P, D, eabs, p.nsplit, p.range_chunks, p.nchunks, ws, idx, logp, lse);
   ISR_CHECK_LAUNCH("corr f32 kernels");
   return ISR_OK;
 }
@@ -1508,6 +1537,7 @@ struct DigitArgs {
   const int32_t* n_rows = nullptr;
   int rows_per_image = 1;
   int images = 0;
+  int phase = 3;          // bit 0: the opening kernels (pre-processing, key norms, the chip-filling kernels); bit 1: the closing ones
   void apply(CorrWs* w) const {
     w->digits = hist;
     w->n_rows = n_rows;
@@ -1557,25 +1587,27 @@ int corr_argmax_impl(const void* Q, const void* K, int P, int N, int D, int ldq,
       corr_split3_f32_kernel<SPv><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3);                         \
     }                                                                                                      \
   } while (0)
-    if (f16) ISR_CHECK_HIP(hipMemsetAsync(gate, 0, sizeof(int32_t), stream));
-    switch (sp) {
-      case 1: ISR_SPLIT_PLANES(1); break;
-      case 2: ISR_SPLIT_PLANES(2); break;
-      case 4: ISR_SPLIT_PLANES(4); break;
-      default:      // SP = 8 exists with f16 planes only (f32_route)
-        corr_split2h_f32_kernel<8><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3, gate);
-        corr_split2h_f32_kernel<8><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3, gate);
-        break;
+    if (dg.phase & 1) {
+      if (f16) ISR_CHECK_HIP(hipMemsetAsync(gate, 0, sizeof(int32_t), stream));
+      switch (sp) {
+        case 1: ISR_SPLIT_PLANES(1); break;
+        case 2: ISR_SPLIT_PLANES(2); break;
+        case 4: ISR_SPLIT_PLANES(4); break;
+        default:      // SP = 8 exists with f16 planes only (f32_route)
+          corr_split2h_f32_kernel<8><<<gq, 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q3, gate);
+          corr_split2h_f32_kernel<8><<<gk, 256, 0, stream>>>(kf, N, D, ldk, 1.f, k3, gate);
+          break;
+      }
     }
 #undef ISR_SPLIT_PLANES
     if (f16) ws.skip = gate;
     const int rc = launch_bf16(q3, k3, P, N, f16 ? split_deff_f16(sp) : split_deff(sp), 48 * sp, 48 * sp, true, p, ws, idx, logp, lse,
-                               F32Rows{qf, kf, ldq, ldk, D}, 1.f, stream, sp, f16);
+                               F32Rows{qf, kf, ldq, ldk, D}, 1.f, stream, sp, f16, false, dg.phase);
     if (rc != ISR_OK || !f16) return rc;
     // behind the gate: the f32-MFMA chain kernels, which leave at once unless a descriptor did not fit f16
     cws.only = gate;
     return launch_f32_chain(qf, kf, P, N, D, ldq, ldk, make_plan(P, N, slots_for(ISR_DTYPE_F32, D), kWaves * kQB * 32), cws, idx,
-                            logp, lse, stream);
+                            logp, lse, stream, dg.phase);
   }
   if (route.kind == 1) {
     // round 3's split route: 96-wide rows on the generic direct kernel (corr_split_f32_kernel's header)
@@ -1587,9 +1619,12 @@ int corr_argmax_impl(const void* Q, const void* K, int P, int N, int D, int ldq,
     const CorrPlan p = make_plan(P, N, slots_for(ISR_DTYPE_BF16_LOG2, 128), kWaves * kQB * 32);
     const float* qf = static_cast<const float*>(Q);
     const float* kf = static_cast<const float*>(K);
-    corr_split_f32_kernel<true><<<(unsigned)(((long)P * 16 + 255) / 256), 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q2);
-    corr_split_f32_kernel<false><<<(unsigned)(((long)N * 16 + 255) / 256), 256, 0, stream>>>(kf, N, D, ldk, 1.f, k2);
-    return launch_bf16(q2, k2, P, N, 128, 128, 128, true, p, ws, idx, logp, lse, F32Rows{qf, kf, ldq, ldk, D}, 1.08f, stream);
+    if (dg.phase & 1) {
+      corr_split_f32_kernel<true><<<(unsigned)(((long)P * 16 + 255) / 256), 256, 0, stream>>>(qf, P, D, ldq, kLog2e, q2);
+      corr_split_f32_kernel<false><<<(unsigned)(((long)N * 16 + 255) / 256), 256, 0, stream>>>(kf, N, D, ldk, 1.f, k2);
+    }
+    return launch_bf16(q2, k2, P, N, 128, 128, 128, true, p, ws, idx, logp, lse, F32Rows{qf, kf, ldq, ldk, D}, 1.08f, stream, 0, false,
+                       false, dg.phase);
   }
   CorrPlan p = make_plan(P, N, slots_for(dtype, D), kWaves * kQB * 32);
   const bool screened = screened_route(dtype, N, D);
@@ -1603,11 +1638,14 @@ int corr_argmax_impl(const void* Q, const void* K, int P, int N, int D, int ldq,
   dg.apply(&ws);
   if (dtype != ISR_DTYPE_F32) {
     return launch_bf16(static_cast<const uint16_t*>(Q), static_cast<const uint16_t*>(K), P, N, D, ldq, ldk,
-                       dtype != ISR_DTYPE_BF16, p, ws, idx, logp, lse, F32Rows{nullptr, nullptr, 0, 0, 0}, 1.f, stream, 0, false, screened);
+                       dtype != ISR_DTYPE_BF16, p, ws, idx, logp, lse, F32Rows{nullptr, nullptr, 0, 0, 0}, 1.f, stream, 0, false, screened,
+                       dg.phase);
   }
   // (the chain kernels alone: no key-norm kernel runs ahead of them to zero the histogram)
-  if (dg.hist) ISR_CHECK_HIP(hipMemsetAsync(dg.hist, 0, sizeof(int32_t) * (size_t)dg.images * isr::kDigitBins, stream));
-  return launch_f32_chain(static_cast<const float*>(Q), static_cast<const float*>(K), P, N, D, ldq, ldk, p, ws, idx, logp, lse, stream);
+  if (dg.hist && (dg.phase & 1))
+    ISR_CHECK_HIP(hipMemsetAsync(dg.hist, 0, sizeof(int32_t) * (size_t)dg.images * isr::kDigitBins, stream));
+  return launch_f32_chain(static_cast<const float*>(Q), static_cast<const float*>(K), P, N, D, ldq, ldk, p, ws, idx, logp, lse, stream,
+                          dg.phase);
 }
 
 }  // namespace
@@ -1630,5 +1668,24 @@ extern "C" int isr_corr_argmax_digits(const void* Q, const void* K, int P, int N
   dg.n_rows = n_rows;
   dg.rows_per_image = rows_per_image;
   dg.images = P / rows_per_image;
+  return corr_argmax_impl(Q, K, P, N, D, ldq, ldk, dtype, idx, logp, lse, ws_, ws_bytes, stream_, dg);
+}
+
+extern "C" int isr_corr_argmax_phase(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk,
+                                     int dtype, int32_t* idx, float* logp, float* lse, int rows_per_image,
+                                     const int32_t* n_rows, int32_t* digit_hist, int phase, void* ws_, size_t ws_bytes,
+                                     isr_stream_t stream_) {
+  ISR_REQUIRE(phase >= 1 && phase <= 3, "isr_corr_argmax_phase: phase=%d (1 open, 2 close, 3 both)", phase);
+  DigitArgs dg;
+  dg.phase = phase;
+  if (digit_hist) {
+    ISR_REQUIRE(idx && logp, "isr_corr_argmax_phase: digit_hist needs idx and logp (the digits are those of logp)");
+    ISR_REQUIRE(rows_per_image > 0 && P > 0 && P % rows_per_image == 0,
+                "isr_corr_argmax_phase: P=%d is not a whole number of images of %d rows", P, rows_per_image);
+    dg.hist = digit_hist;
+    dg.n_rows = n_rows;
+    dg.rows_per_image = rows_per_image;
+    dg.images = P / rows_per_image;
+  }
   return corr_argmax_impl(Q, K, P, N, D, ldq, ldk, dtype, idx, logp, lse, ws_, ws_bytes, stream_, dg);
 }

@@ -254,22 +254,30 @@ def prescale_queries_log2(queries: torch.Tensor) -> torch.Tensor:
     return (queries.to(torch.float32) * LOG2E).to(torch.bfloat16)
 
 
-def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = False,
-                log2_prescaled: bool = False, screened: bool = False, rows_per_image: int | None = None,
-                n_rows: torch.Tensor | None = None):
-    """isr_corr_argmax.  queries (P,D), keys (N,D); bf16 tensors take the bf16 MFMA path, f32
-    tensors the exact f32 MFMA path (f16/f64 are converted to f32).  Zero columns are appended
-    where the kernel needs a padded D (exact: they add 0 to every logit).
-    log2_prescaled: the bf16 queries already carry a factor log2(e) (prescale_queries_log2): the
-    kernel works in log2 units with the -M2 reference folded into the MFMA contraction; outputs are
-    still natural-log.
-    screened (with log2_prescaled): ISR_DTYPE_BF16_LOG2_SCREENED — the rows also go through a block-scaled FP6 screen, and
-    pieces of the log-sum-exp proven to lie more than T = 21 + ceil(log2 N) log2 units below the query's maximum are never
-    formed (indices stay exact, lse moves by < 5e-7; D = 64 only, other shapes run unscreened).  For peaked softmaxes.
-    rows_per_image: isr_corr_argmax_digits — the rows are P / rows_per_image images whose top-80 % cut follows; the call also
-    returns digit_hist (images, 2048) i32, the first histogram of that cut's radix select over logp (of image b's first
-    n_rows[b] rows; n_rows None: all), formed where logp is written: pass it to select_top_batch(..., digit_hist=...).
-    Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32][, digit_hist] on the device."""
+@dataclass
+class CorrCall:
+    """An isr_corr_argmax call whose opening half has been enqueued (corr_argmax_open): what corr_argmax_close needs."""
+    q: torch.Tensor
+    k: torch.Tensor
+    P: int
+    N: int
+    Dp: int
+    dtype: int
+    idx: torch.Tensor
+    logp: torch.Tensor
+    lse: torch.Tensor | None
+    rows_per_image: int
+    n_rows: torch.Tensor | None
+    hist: torch.Tensor | None
+    ws: torch.Tensor
+    dev: torch.device
+
+    def outputs(self):
+        out = (self.idx, self.logp) if self.lse is None else (self.idx, self.logp, self.lse)
+        return out if self.hist is None else out + (self.hist,)
+
+
+def _corr_prepare(queries, keys, want_lse, log2_prescaled, screened, rows_per_image, n_rows, ws_tag) -> CorrCall:
     dev = require_cuda(queries, keys, n_rows)
     if queries.ndim != 2 or keys.ndim != 2 or queries.shape[1] != keys.shape[1]:
         raise ValueError(f"queries {tuple(queries.shape)} / keys {tuple(keys.shape)} must be (P,D),(N,D)")
@@ -296,9 +304,7 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
     idx = torch.empty(P, dtype=torch.int32, device=dev)
     logp = torch.empty(P, dtype=torch.float32, device=dev)
     lse = torch.empty(P, dtype=torch.float32, device=dev) if want_lse else None
-    L = lib()
-    nbytes = L.isr_corr_argmax_workspace_bytes(P, N, Dp, dtype)
-    ws = workspace(dev, nbytes, "corr")
+    ws = workspace(dev, lib().isr_corr_argmax_workspace_bytes(P, N, Dp, dtype), ws_tag)
     hist = None
     if rows_per_image is not None:
         if rows_per_image <= 0 or P % rows_per_image:
@@ -306,18 +312,64 @@ def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = Fals
         if n_rows is not None and (n_rows.dtype != torch.int32 or n_rows.numel() != P // rows_per_image):
             raise ValueError("corr_argmax: n_rows must be (images,) int32")
         hist = torch.empty((P // rows_per_image, 2048), dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev), _timed("corr_argmax", 2.0 * P * N * Dp):
-        if hist is None:
-            rc = L.isr_corr_argmax(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, ptr(idx), ptr(logp), ptr(lse),
-                                   ptr(ws), ws.numel(), current_stream(dev))
+    return CorrCall(q, k, P, N, Dp, dtype, idx, logp, lse, int(rows_per_image or 1), n_rows, hist, ws, dev)
+
+
+def _corr_launch(c: CorrCall, phase: int, what: str, work: float) -> None:
+    L = lib()
+    with torch.cuda.device(c.dev), _timed(what, work):
+        if phase == 3 and c.hist is None:
+            rc = L.isr_corr_argmax(ptr(c.q), ptr(c.k), c.P, c.N, c.Dp, c.Dp, c.Dp, c.dtype, ptr(c.idx), ptr(c.logp), ptr(c.lse),
+                                   ptr(c.ws), c.ws.numel(), current_stream(c.dev))
+        elif phase == 3:
+            rc = L.isr_corr_argmax_digits(ptr(c.q), ptr(c.k), c.P, c.N, c.Dp, c.Dp, c.Dp, c.dtype, ptr(c.idx), ptr(c.logp), ptr(c.lse),
+                                          c.rows_per_image, ptr(c.n_rows), ptr(c.hist), ptr(c.ws), c.ws.numel(), current_stream(c.dev))
         else:
-            rc = L.isr_corr_argmax_digits(ptr(q), ptr(k), P, N, Dp, Dp, Dp, dtype, ptr(idx), ptr(logp), ptr(lse),
-                                          int(rows_per_image), ptr(n_rows), ptr(hist), ptr(ws), ws.numel(), current_stream(dev))
+            rc = L.isr_corr_argmax_phase(ptr(c.q), ptr(c.k), c.P, c.N, c.Dp, c.Dp, c.Dp, c.dtype, ptr(c.idx), ptr(c.logp), ptr(c.lse),
+                                         c.rows_per_image, ptr(c.n_rows), ptr(c.hist), phase, ptr(c.ws), c.ws.numel(),
+                                         current_stream(c.dev))
     check(rc, "isr_corr_argmax")
     global _last_corr
-    _last_corr = (ws, P, N, dtype, dev)
-    out = (idx, logp, lse) if want_lse else (idx, logp)
-    return out if hist is None else out + (hist,)
+    _last_corr = (c.ws, c.P, c.N, c.dtype, c.dev)
+
+
+def corr_argmax(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = False,
+                log2_prescaled: bool = False, screened: bool = False, rows_per_image: int | None = None,
+                n_rows: torch.Tensor | None = None):
+    """isr_corr_argmax.  queries (P,D), keys (N,D); bf16 tensors take the bf16 MFMA path, f32
+    tensors the exact f32 MFMA path (f16/f64 are converted to f32).  Zero columns are appended
+    where the kernel needs a padded D (exact: they add 0 to every logit).
+    log2_prescaled: the bf16 queries already carry a factor log2(e) (prescale_queries_log2): the
+    kernel works in log2 units with the -M2 reference folded into the MFMA contraction; outputs are
+    still natural-log.
+    screened (with log2_prescaled): ISR_DTYPE_BF16_LOG2_SCREENED — the rows also go through a block-scaled FP6 screen, and
+    pieces of the log-sum-exp proven to lie more than T = 21 + ceil(log2 N) log2 units below the query's maximum are never
+    formed (indices stay exact, lse moves by < 5e-7; D = 64 only, other shapes run unscreened).  For peaked softmaxes.
+    rows_per_image: isr_corr_argmax_digits — the rows are P / rows_per_image images whose top-80 % cut follows; the call also
+    returns digit_hist (images, 2048) i32, the first histogram of that cut's radix select over logp (of image b's first
+    n_rows[b] rows; n_rows None: all), formed where logp is written: pass it to select_top_batch(..., digit_hist=...).
+    Returns idx (P,) i32, logp (P,) f32[, lse (P,) f32][, digit_hist] on the device."""
+    c = _corr_prepare(queries, keys, want_lse, log2_prescaled, screened, rows_per_image, n_rows, "corr")
+    _corr_launch(c, 3, "corr_argmax", 2.0 * c.P * c.N * c.Dp)
+    return c.outputs()
+
+
+def corr_argmax_open(queries: torch.Tensor, keys: torch.Tensor, want_lse: bool = False, log2_prescaled: bool = False,
+                     screened: bool = False, rows_per_image: int | None = None, n_rows: torch.Tensor | None = None,
+                     ws_tag: str = "corr") -> CorrCall:
+    """isr_corr_argmax_phase, phase 1: pre-processing, key norms and the chip-filling kernel(s) of a corr_argmax call, enqueued
+    on the current stream.  corr_argmax_close(call) enqueues the closing kernels (fallback, finalize, recheck, merge) — on
+    whatever stream is current then, ordered behind this one by the caller (an event) — and returns corr_argmax's outputs.
+    The workspace (cached per stream and ws_tag) must not be opened again before its close has finished: alternate two tags."""
+    c = _corr_prepare(queries, keys, want_lse, log2_prescaled, screened, rows_per_image, n_rows, ws_tag)
+    _corr_launch(c, 1, "corr_argmax", 2.0 * c.P * c.N * c.Dp)
+    return c
+
+
+def corr_argmax_close(call: CorrCall):
+    """isr_corr_argmax_phase, phase 2, for a call opened by corr_argmax_open: the outputs are complete when it has run."""
+    _corr_launch(call, 2, "corr_close", 0.0)
+    return call.outputs()
 
 
 def corr_lse(queries: torch.Tensor, keys: torch.Tensor, log2_prescaled: bool = False, screened: bool = False) -> torch.Tensor:

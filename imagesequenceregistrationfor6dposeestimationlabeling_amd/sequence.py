@@ -216,6 +216,15 @@ def _publish(results: list[ImageResult], consumer: torch.cuda.Stream) -> None:
 
 
 _streams: dict[tuple, list] = {}
+_closed: dict[tuple, torch.cuda.Event] = {}       # (device, workspace tag) -> the event behind the last close on that workspace
+
+# register_block: a group's K1 call is OPENED on the K1 stream (key norms + the chip-filling kernel) and CLOSED on the group's
+# side stream (fallback, finalize, recheck, merge: ~170 us of small launches at low occupancy, ahead of the cut that reads their
+# outputs), so that the next group's chip-filling kernel follows this one's directly: on one stream the closing kernels and the
+# next call's key-norm kernel stood between them (K1's duty cycle 0.977, profiles/r05_side_work_budget.txt).  Two workspaces
+# alternate; an opening waits for the close that last used its workspace.  The chip-filling kernels stay one behind the other on
+# one stream (their durations mean what they say).  False: one isr_corr_argmax call per group.  Same results either way.
+K1_SPLIT_CLOSE = True
 
 
 def _stream_pool(dev: torch.device, n: int) -> list:
@@ -310,29 +319,40 @@ def register_block(model: SequenceModel, queries: torch.Tensor, pix_xy: torch.Te
     for s in pool:
         s.wait_stream(cur)
     k1_stream, side = pool[0], pool[1:]
+    kw = dict(log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
+    if EPILOGUE_DIGITS:
+        kw["rows_per_image"] = P
     out = []
     for gi, g0 in enumerate(range(0, n, group)):
         g1 = min(n, g0 + group)
+        rows = queries[g0:g1].reshape((g1 - g0) * P, -1)
         with torch.cuda.stream(k1_stream):
-            if EPILOGUE_DIGITS:
-                idx_g, logp_g, hist_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys,
-                                                        log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries,
-                                                        rows_per_image=P)
+            if K1_SPLIT_CLOSE:
+                tag = f"corr{gi & 1}"
+                prev = _closed.get((dev.index, tag))
+                if prev is not None:
+                    k1_stream.wait_event(prev)             # the workspace's last close (two groups ago: long finished)
+                call = ops.corr_argmax_open(rows, model.keys, ws_tag=tag, **kw)
+                res = call.outputs()
             else:
-                idx_g, logp_g = ops.corr_argmax(queries[g0:g1].reshape((g1 - g0) * P, -1), model.keys,
-                                                log2_prescaled=model.log2_queries, screened=model.screened and model.log2_queries)
-                hist_g = None
+                res = ops.corr_argmax(rows, model.keys, **kw)
             done = torch.cuda.Event()
             done.record(k1_stream)
         s = side[gi % len(side)]
         s.wait_event(done)
-        for t in (idx_g, logp_g, hist_g):
-            if t is not None:
-                t.record_stream(s)
+        for t in res:
+            t.record_stream(s)
         with torch.cuda.stream(s):
+            if K1_SPLIT_CLOSE:
+                ops.corr_argmax_close(call)
+                closed = torch.cuda.Event()
+                closed.record(s)
+                _closed[(dev.index, tag)] = closed
+            idx_g, logp_g = res[0], res[1]
             out += register_group(model, idx_g.view(g1 - g0, P), logp_g.view(g1 - g0, P),
                                   pix_xy if pix_xy.ndim == 2 else pix_xy[g0:g1], cams[g0:g1], itr, reperr,
-                                  [seed0 + j for j in range(g0, g1)], refine_iters, confidence, digit_hist=hist_g)
+                                  [seed0 + j for j in range(g0, g1)], refine_iters, confidence,
+                                  digit_hist=res[2] if EPILOGUE_DIGITS else None)
     for s in pool:
         cur.wait_stream(s)
     _publish(out, cur)

@@ -30,7 +30,7 @@ extern "C" {
 /* v4 (round 4): isr_corr_argmax accepts idx = logp = NULL (lse-only call), f32 rows run as f16 planes by default
  * (ISR_TUNE_K1_F32_CHAIN values 0-4), new isr_corr_topk / isr_corr_topk_workspace_bytes.
  * v5 (round 5): ISR_DTYPE_BF16_LOG2_SCREENED, isr_corr_argmax_screen_redone; isr_corr_topk_workspace_bytes sized by the key
- * ranges a call uses; isr_corr_argmax_digits + isr_select_top_batch_digits (the cut's first histogram from K1's epilogue). */
+ * ranges a call uses; isr_corr_argmax_digits + isr_select_top_batch_digits (the cut's first histogram from K1's epilogue); isr_corr_argmax_phase (a call's closing kernels on another stream). */
 #define ISR_ABI_VERSION 5
 
 #define ISR_OK 0
@@ -127,6 +127,20 @@ int isr_corr_argmax(const void* Q, const void* K, int P, int N, int D, int ldq, 
 int isr_corr_argmax_digits(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk, int dtype,
                            int32_t* idx, float* logp, float* lse, int rows_per_image, const int32_t* n_rows,
                            int32_t* digit_hist, void* ws, size_t ws_bytes, isr_stream_t stream);
+
+/* isr_corr_argmax in two halves, for callers that launch it back to back (one call per group of images).
+ * phase 1 ("open"):  pre-processing, key norms and the chip-filling kernel(s);
+ * phase 2 ("close"): the closing kernels — fallback for out-of-range queries, finalize, exact recheck, merge: ~170 us of small
+ *                    launches at low occupancy;
+ * phase 3: both (= isr_corr_argmax / isr_corr_argmax_digits).
+ * Both halves take the SAME arguments and the SAME workspace; the close must be ordered behind its open (same stream, or an
+ * event), the outputs are complete when the close has run, and the workspace must not be opened again before its close has
+ * finished (alternate two workspaces).  Putting the close on another stream lets the next group's chip-filling kernel follow
+ * this one's directly instead of behind the closing kernels (bench: +1 %).  Results do not depend on how a call is split.
+ * digit_hist may be NULL (then rows_per_image / n_rows are ignored). */
+int isr_corr_argmax_phase(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk, int dtype,
+                          int32_t* idx, float* logp, float* lse, int rows_per_image, const int32_t* n_rows,
+                          int32_t* digit_hist, int phase, void* ws, size_t ws_bytes, isr_stream_t stream);
 
 /* Diagnostics: number of queries the last isr_corr_argmax call on this workspace (same P, N, dtype)
  * decided by the exact recheck; -1 for ISR_DTYPE_F32.  count_host is a HOST pointer; synchronises. */

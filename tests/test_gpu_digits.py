@@ -5,7 +5,8 @@ isr_select_top_batch_digits), inference.py:142-149 then :282-290.
   * idx / logp / lse are the plain call's bits;
   * the cut that starts from it keeps the same rows, count and threshold as the ten-launch cut.
 (The group routes of sequence.py use the pair; tests/test_gpu_sequence.py compares them, image by image and bit for bit, with
-register_images, which runs the plain calls.)"""
+register_images, which runs the plain calls.)
+Also isr_corr_argmax_phase: a call split into its opening and closing halves on two streams equals the call."""
 import numpy as np
 import pytest
 import torch
@@ -99,3 +100,41 @@ def test_digit_calls_reject_what_they_cannot_do(cuda0):
     rc = L.isr_corr_argmax_digits(ops.ptr(q), ops.ptr(k), 1000, 500, 64, 64, 64, 1, ops.ptr(idx), ops.ptr(logp), None, 300, None,
                                   ops.ptr(hist), ops.ptr(ws), ws.numel(), ops.current_stream(cuda0))
     assert rc != 0 and b"whole number of images" in L.isr_last_error()
+
+
+@pytest.mark.parametrize("route,P,N,D", [("log2", 5000, 9000, 64), ("bf16", 3000, 700, 32), ("screened", 6000, 20000, 64),
+                                         ("f32", 2500, 4000, 64), ("f32chain", 1500, 3000, 40)])
+def test_a_call_in_two_halves_on_two_streams_equals_the_call(cuda0, route, P, N, D):
+    """isr_corr_argmax_phase: the opening half (pre-processing, key norms, chip-filling kernels) on one stream, the closing half
+    (fallback, finalize, recheck, merge) on another behind an event — what sequence.register_block does with a group's call —
+    gives the bits of the single call, digits included; rows outside the direct sums' range (x 12) make the closing half work."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import ops
+    rng = np.random.default_rng(P + N)
+    Q, K = _data(rng, 1, P, N, D, tau=8.0 if route == "screened" else 5.0)
+    kw = {}
+    if route in ("f32", "f32chain"):
+        q, k = torch.from_numpy(Q).to(cuda0), torch.from_numpy(K).to(cuda0)
+    else:
+        log2 = route != "bf16"
+        q = (ops.prescale_queries_log2(torch.from_numpy(Q)) if log2 else torch.from_numpy(Q).bfloat16()).to(cuda0)
+        k = torch.from_numpy(K).bfloat16().to(cuda0)
+        kw = dict(log2_prescaled=log2, screened=route == "screened")
+    a, b = torch.cuda.Stream(device=cuda0), torch.cuda.Stream(device=cuda0)
+    with ops.tuning(**({"k1_f32_chain": 1} if route == "f32chain" else {})):
+        want = ops.corr_argmax(q, k, want_lse=True, rows_per_image=P, **kw)
+        torch.cuda.synchronize()
+        for digits in (True, False):
+            with torch.cuda.stream(a):
+                call = ops.corr_argmax_open(q, k, want_lse=True, ws_tag="halves", rows_per_image=P if digits else None, **kw)
+                opened = torch.cuda.Event()
+                opened.record(a)
+            b.wait_event(opened)
+            with torch.cuda.stream(b):
+                got = ops.corr_argmax_close(call)
+            torch.cuda.synchronize()
+            for x, y in zip(want, got):
+                assert torch.equal(x, y)
+    L = ops.lib()
+    rc = L.isr_corr_argmax_phase(ops.ptr(call.q), ops.ptr(call.k), P, N, call.Dp, call.Dp, call.Dp, call.dtype, ops.ptr(call.idx),
+                                 ops.ptr(call.logp), None, 1, None, None, 4, ops.ptr(call.ws), call.ws.numel(), ops.current_stream(cuda0))
+    assert rc != 0 and b"phase=4" in L.isr_last_error()

@@ -54,17 +54,20 @@ def test_streams_and_grouping_do_not_change_results(cuda0):
     poses = pr.reshape(-1, 3, 4).cpu().numpy()
     for i in range(len(imgs)):
         assert synth.rot_angle(poses[i][:, :3], R[i]) < 5e-3 and np.linalg.norm(poses[i][:, 3] - t[i]) < 1.0
-    # the group route with the cut's first histogram formed in K1's epilogue (sequence.EPILOGUE_DIGITS): the same bits again
-    sequence.EPILOGUE_DIGITS = True
-    try:
-        c = sequence.register_block(model, Q, pix, K, itr=200, seed0=5, n_streams=3, group=4)
-    finally:
-        sequence.EPILOGUE_DIGITS = False
-    pc, sc = sequence.stack_poses(c)
-    assert torch.equal(sc, sr) and torch.equal(pc, pr)
-    for x, y in zip(ref, c):
-        m = int(x.M.item())
-        assert int(y.M.item()) == m and torch.equal(x.keep[:m], y.keep[:m]) and torch.equal(x.logp, y.logp)
+    # the group route's switches — the cut's first histogram formed in K1's epilogue (sequence.EPILOGUE_DIGITS), the K1 call of a
+    # group as ONE call on the K1 stream instead of its closing kernels on the side stream (sequence.K1_SPLIT_CLOSE): the same bits
+    assert sequence.K1_SPLIT_CLOSE and not sequence.EPILOGUE_DIGITS          # the defaults `b` ran with
+    for digits, split in ((True, True), (True, False), (False, False)):
+        sequence.EPILOGUE_DIGITS, sequence.K1_SPLIT_CLOSE = digits, split
+        try:
+            c = sequence.register_block(model, Q, pix, K, itr=200, seed0=5, n_streams=3, group=4)
+        finally:
+            sequence.EPILOGUE_DIGITS, sequence.K1_SPLIT_CLOSE = False, True
+        pc, sc = sequence.stack_poses(c)
+        assert torch.equal(sc, sr) and torch.equal(pc, pr)
+        for x, y in zip(ref, c):
+            m = int(x.M.item())
+            assert int(y.M.item()) == m and torch.equal(x.keep[:m], y.keep[:m]) and torch.equal(x.logp, y.logp) and torch.equal(x.idx, y.idx)
 
 
 def test_pick_by_chamfer_matches_reference_loop(cuda0):
