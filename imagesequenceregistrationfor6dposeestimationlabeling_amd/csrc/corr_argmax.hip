@@ -925,7 +925,11 @@ __device__ __attribute__((noinline)) double chain_logit_f32(const float* __restr
 }
 
 #ifndef ISR_K1_RECHECK_WAVES
-#define ISR_K1_RECHECK_WAVES 1      // waves per SIMD corr_recheck_kernel is compiled for on plain rows of D <= 64
+// waves per SIMD corr_recheck_kernel is compiled for on plain rows of D <= 64.  3 = 168 registers (96 B of spills) instead of 200:
+// 7.7 against 8.4 ms on configs[3]'s long lists (profiles/r04_k1_recheck_ranges.txt), and — what made it the default in round 5 —
+// a wave that fits the slot a K1 wave leaves: since the closing kernels of a call run BESIDE the next call's chip-filling kernel
+// (isr_corr_argmax_phase), the 200-register build waited for two K1 waves to leave one SIMD together (up to 26 ms in a trace)
+#define ISR_K1_RECHECK_WAVES 3
 #endif
 template <int DK, int SP = 0, bool F16 = false>
 __global__ __launch_bounds__(kThreads, (DK <= 4 && SP == 0) ? ISR_K1_RECHECK_WAVES : 1) void corr_recheck_kernel(
