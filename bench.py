@@ -85,6 +85,7 @@ def parse_args():
     ap.add_argument("--k1-one-call", action="store_true",
                     help="A/B: one isr_corr_argmax call per group on the K1 stream (sequence.K1_SPLIT_CLOSE = False) instead of the "
                          "call's closing kernels on the group's side stream (isr_corr_argmax_phase)")
+    ap.add_argument("--host-gc", action="store_true", help="leave Python's cyclic garbage collector enabled during the timed steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--confidence", type=float, default=0.99,
                     help="RANSAC confidence (cv2.solvePnPRansac's parameter; its default 0.99 is what the reference's "
@@ -640,6 +641,8 @@ def main():
                            trans_err_mm=float(np.linalg.norm(pose[:, 3] - t_gt[best])))
         return out
 
+    step_done: list[float] = []            # host time at which each pipelined step's verification returned (diagnostics)
+
     def run_steps(first: int, count: int, confidence: float):
         """`count` steps.  Pipelined (default): registration of batch s + 1 is enqueued as soon as batch
         s's registration is, and batch s's verification (all-gather, pick or vote, ICP, final Chamfer —
@@ -660,9 +663,11 @@ def main():
                 r = register(s, confidence)
                 while len(pending) >= max(args.depth, 1):
                     last = pending.popleft().result()
+                    step_done.append(time.perf_counter())
                 pending.append(pool.submit(verify, *r))
             while pending:
                 last = pending.popleft().result()
+                step_done.append(time.perf_counter())
         return last
 
     def barrier():
@@ -672,11 +677,22 @@ def main():
         torch.cuda.synchronize()
 
     def timed(first: int, count: int, confidence: float):
+        # Python's cyclic collector is paused over the timed steps (collected just before, re-enabled after): a generation-2 pass
+        # in the thread that enqueues the next batch is a host pause of milliseconds that shows up as an idle GPU — with it
+        # running, one repetition in three lost 1-3 % on one box (profiles/r05_host_gc_ab.txt).  No work is skipped; reference
+        # counting frees everything the loop drops.  --host-gc leaves the collector on.
+        import gc
+        gc_was = gc.isenabled()
+        if not args.host_gc:
+            gc.collect()
+            gc.disable()
         barrier()
         t0 = time.perf_counter()
         last = run_steps(first, count, confidence)
         barrier()
         dt_rank = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         dts = [dt_rank]
         if world > 1:
             tt = torch.zeros(world, dtype=torch.float64, device=shard._coll_device())
@@ -729,7 +745,9 @@ def main():
             nn_vote = measure_nn_vote(cad_d, pts, dev, items=min(4096, n_local * n_total))
         f32_exact = measure_k1_f32(Q_all[0], keys_f32, dev, args.k1 != "natural")
     ops.enable_timing(True)
+    step_done.clear()
     last, dt, dts = timed(args.warmup, args.steps, args.confidence)
+    step_intervals_ms = [(b - a) * 1e3 for a, b in zip(step_done[:-1], step_done[1:])]
     timing = ops.drain_timing()
     ops.enable_timing(False)
     # the ICP result of the last step lives on the rank that owned the chosen image: bring it to rank 0
@@ -880,12 +898,15 @@ def main():
                        "ransac_confidence": args.confidence,
                        "hypotheses_scored_mean": last.get("hypotheses_scored_mean"),
                        "parallelism": f"image-sharded x{world}",
+                       "host": "python thread enqueues; cyclic GC " + ("enabled" if args.host_gc else "paused over the timed steps (--host-gc: on)"),
                        "cut_first_histogram": "K1 epilogue (isr_corr_argmax_digits)" if sequence.EPILOGUE_DIGITS else "hist_kernel<21,11> (isr_select_top_batch)",
                        "step_overlap": ("none" if args.no_pipeline else
                                         "verification (all-gather, pick/vote, ICP, final Chamfer) of batch s "
                                         "overlaps the registration of batch s+1")},
             "final_chamfer": last.get("final_chamfer"), "last_step": last_pub, "acceptance": acceptance,
             "object": args.object,
+            "step_intervals_ms": {"what": "host time between consecutive steps' verification results on this rank (the last one includes the "
+                                          "pipeline's drain)", "values": [round(v, 2) for v in step_intervals_ms]},
             "per_rank_ms_per_step": {"min": min(dts) / args.steps * 1e3, "max": max(dts) / args.steps * 1e3,
                                      "all": [d / args.steps * 1e3 for d in dts]},
             "ransac_all_hypotheses": all_hyp,

@@ -58,6 +58,7 @@ print(f"K1 duty cycle {busy / (t1 - t0):.4f}: {len(gaps)} gaps, mean {sum(gaps) 
       f"even gaps (inside a step) mean {sum(gaps[0::2]) / len(gaps[0::2]):.0f} us, odd gaps (between steps) mean {sum(gaps[1::2]) / max(len(gaps[1::2]), 1):.0f} us")
 
 # what runs in the gap between two steps: the kernels alive between the end of a step's second K1 launch and the next step's first
+print("all gaps in launch order, us: " + " ".join(f"{g:.0f}" for g in gaps))
 odd = sorted(range(1, len(gaps), 2), key=lambda j: gaps[j])
 if odd:
     i = odd[len(odd) // 2]                       # the median between-step gap
