@@ -136,7 +136,7 @@ int isr_corr_argmax_digits(const void* Q, const void* K, int P, int N, int D, in
  * Both halves take the SAME arguments and the SAME workspace; the close must be ordered behind its open (same stream, or an
  * event), the outputs are complete when the close has run, and the workspace must not be opened again before its close has
  * finished (alternate two workspaces).  Putting the close on another stream lets the next group's chip-filling kernel follow
- * this one's directly instead of behind the closing kernels (bench: +1 %).  Results do not depend on how a call is split.
+ * this one's directly instead of behind the closing kernels (bench: +0.4 %, profiles/r05_k1_call_split_ab.txt).  Results do not depend on how a call is split.
  * digit_hist may be NULL (then rows_per_image / n_rows are ignored). */
 int isr_corr_argmax_phase(const void* Q, const void* K, int P, int N, int D, int ldq, int ldk, int dtype,
                           int32_t* idx, float* logp, float* lse, int rows_per_image, const int32_t* n_rows,
