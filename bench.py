@@ -90,6 +90,7 @@ def parse_args():
     ap.add_argument("--confidence", type=float, default=0.99,
                     help="RANSAC confidence (cv2.solvePnPRansac's parameter; its default 0.99 is what the reference's "
                          "call uses); 1 scores every hypothesis")
+    ap.add_argument("--icp-iters", type=int, default=30, help="debug only (not a valid bench line): the ICP's iteration cap (Open3D's default 30)")
     ap.add_argument("--ablate", default="", help="debug only (not a valid bench line): 'noverify' skips a13-a15")
     ap.add_argument("--tune", default="", help="debug only (not a valid bench line): library knobs, e.g. 'nn_plan_rq=1,icp_warm=0' (ops.set_tuning)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="host threads for the cpu_baseline leg")
@@ -635,7 +636,7 @@ def main():
                 pose = out["poses_all"][best].reshape(3, 4)
                 src = (upper.astype(np.float64) @ R_gt[best].T + t_gt[best]).astype(np.float32)   # icp.py:68
                 init = np.linalg.inv(np.vstack([pose, [0, 0, 0, 1]]))                               # icp.py:88-92
-                T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init, spatial_order=False)
+                T, fit, rmse = registration.icp_point_to_point(src, lower, 20, init, max_iter=args.icp_iters, spatial_order=False)
                 out.update(final_chamfer=registration.final_chamfer(src, lower, T, cad), icp_fitness=fit,
                            icp_rmse=rmse, rot_err_rad=synth.rot_angle(pose[:, :3], R_gt[best]),
                            trans_err_mm=float(np.linalg.norm(pose[:, 3] - t_gt[best])))

@@ -6,9 +6,11 @@ cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r05
 out=gpurun_out/r05/nulls.txt
 : > $out
+VARS=("$@")
+[ ${#VARS[@]} -eq 0 ] && VARS=("full|" "noverify|--ablate noverify" "norefit|--refine-iters 0" "neither|--ablate noverify --refine-iters 0")
 F="--steps 12 --no-cpu-baseline --no-parity-check --no-estimate-pose --no-f32-step --no-screened-step"
 for rep in 1 2 3; do
-  for v in "full|" "noverify|--ablate noverify" "norefit|--refine-iters 0" "neither|--ablate noverify --refine-iters 0"; do
+  for v in "${VARS[@]}"; do
     IFS='|' read -r name flags <<< "$v"
     python bench.py $F $flags 2>/dev/null | python3 -c "
 import json,sys
