@@ -16,7 +16,11 @@ routes of K1 and under the nearest-neighbour search.  Per case random shapes (ra
          rmse to 1e-9, pose to 1e-9 rad / 1e-7 mm of the oracle loop with exact f64 neighbours.
   crop   the image front end (inference.py:196-232): random frame sizes and masks (boxes touching the frame, one pixel, scattered
          pixels, the whole frame, grey-valued ellipses), with and without blanking: bounding box, affine map, warped mask bytes and
-         normalised network input array_equal to the numpy oracle."""
+         normalised network input array_equal to the numpy oracle.
+  prep   the network-output -> K1 hand-off (inference.py:248-279): random sizes from 1 x 1, strides, mask channel layouts and
+         densities (empty, full), three row formats: row count, pixel coordinates and rows bit for bit, padding rows zero.
+  pose   relative-pose tables (choosePose.py:43-51, verfication.py:9-19) to 1e-9 relative, ADD to 1e-9, ADD-S to 1e-6 (f32 winners,
+         f64 distances against sklearn's KD-tree) on random poses and clouds."""
 import sys
 from pathlib import Path
 
@@ -246,9 +250,60 @@ def crop_case(c):
     assert np.array_equal(inputIM[0].cpu().numpy(), ref_in), f"{tag}: network input differs"
 
 
+def prep_case(c):
+    """inference.py:248-279 literally (torch CPU) against isr_prep_queries."""
+    H, W = int(rng.integers(1, 260)), int(rng.integers(1, 260))
+    C = int(rng.integers(12, 24)); ds = int(rng.choice([1, 2, 3, 4])); ch = int(rng.choice([0, 1, 3]))
+    dtype = str(rng.choice(["f32", "bf16", "bf16_log2"]))
+    feat = torch.from_numpy(rng.normal(0, 2, (1, H, W, C)).astype(np.float32))
+    m = (rng.random((H, W)) < float(rng.choice([0.0, 0.02, 0.5, 1.0]))).astype(np.uint8) * int(rng.integers(1, 256))
+    mask = torch.from_numpy(np.repeat(m[:, :, None], ch, axis=2) if ch else m)
+    tag = f"prep case {c}: {H}x{W}x{C} step {ds} mask channels {ch} {dtype}"
+    imfeats = feat[..., 0:12][:, ::ds, ::ds]
+    inputMask = (mask[:, :, 0] if mask.ndim == 3 else mask)[::ds, ::ds]
+    ids = torch.where(inputMask)
+    mf = imfeats[0][ids]
+    Q, pix, n_dev = ops.prep_queries(feat.to(dev), mask.to(dev), c0=0, D=12, step=ds, dtype=dtype)
+    n = int(n_dev.item())
+    assert n == mf.shape[0], f"{tag}: {n} rows / {mf.shape[0]}"
+    got = pix[:n].cpu().numpy()
+    assert np.array_equal(got[:, 0], ids[1].numpy()) and np.array_equal(got[:, 1], ids[0].numpy()), f"{tag}: pixel coordinates differ"
+    Qh = Q.cpu()
+    if dtype == "f32":
+        assert torch.equal(Qh[:n], mf), f"{tag}: rows differ"
+    else:
+        want = ops.prescale_queries_log2(mf) if dtype == "bf16_log2" else mf.bfloat16()
+        assert torch.equal(Qh[:n, :12].view(torch.int16), want.view(torch.int16)), f"{tag}: rows differ"
+    assert (Qh[n:].float() == 0).all(), f"{tag}: padding rows are not zero"
+
+
+def pose_case(c):
+    """choosePose.py:43-51 / 98-107, verfication.py:9-19, inference.py:116-120 against the device tables and metrics."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import registration as reg
+    from oracle import registration_oracle as ro
+    n = int(rng.integers(1, 12))
+    T = [rand_pose() for _ in range(n)]
+    R = np.stack([t[:, :3] for t in T]); t = np.stack([t[:, 3] + np.array([0, 0, 600.0]) for t in T])
+    for mode, fn in (("choose", ro.compute_rel_poses), ("verif", ro.calculate_relative_pose)):
+        got = reg.relative_pose_table(R, t, mode=mode)
+        want = ro.rel_pose_table(R, t, fn)
+        assert np.allclose(got, want, rtol=0, atol=1e-9 * 600.0), f"pose case {c}: table '{mode}' differs by {np.abs(got - want).max():.3g}"
+    nv, ns = int(rng.integers(1, 3000)), int(rng.integers(1, 4000))
+    verts = rng.normal(0, 30, (nv, 3)).astype(np.float32)
+    surf = rng.normal(0, 30, (ns, 3)).astype(np.float32)
+    i, j = int(rng.integers(n)), int(rng.integers(n))
+    a = reg.ADD(verts, R[i], t[i], R[j], t[j]); ar = ro.ADD(verts.astype(np.float64), R[i], t[i], R[j], t[j])
+    assert abs(a - ar) <= 1e-9 * max(1.0, ar), f"pose case {c}: ADD {a} / {ar}"
+    b = reg.ADDS(verts, R[i], t[i], R[j], t[j], surf); br = ro.ADDS(verts.astype(np.float64), R[i], t[i], R[j], t[j], surf.astype(np.float64))
+    # f32 winners, exact f64 distances: equal to the KD-tree's except at ties of f32 roundings (1e-7 relative of a distance)
+    assert abs(b - br) <= 1e-6 * max(1.0, br), f"pose case {c}: ADD-S {b} / {br}"
+
+
 worst = 0.0
 worst_icp = 0.0
 for c in range(cases):
+    prep_case(c)
+    pose_case(c)
     crop_case(c)
     worst = max(worst, corr_case(c))
     nn_case(c)
@@ -257,5 +312,5 @@ for c in range(cases):
     worst_icp = max(worst_icp, icp_case(c))
     if c % 10 == 9:
         print(f"  seed {seed}: {c + 1} cases", flush=True)
-print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac + {cases} filter + {cases} icp + {cases} crop cases ok; worst corr value error {worst:.3g} "
+print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac + {cases} filter + {cases} icp + {cases} crop + {cases} prep + {cases} pose cases ok; worst corr value error {worst:.3g} "
       f"(relative to max(1, |lse|)), worst ICP rotation difference {worst_icp:.3g} rad")
