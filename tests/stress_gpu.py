@@ -20,7 +20,9 @@ routes of K1 and under the nearest-neighbour search.  Per case random shapes (ra
   prep   the network-output -> K1 hand-off (inference.py:248-279): random sizes from 1 x 1, strides, mask channel layouts and
          densities (empty, full), three row formats: row count, pixel coordinates and rows bit for bit, padding rows zero.
   pose   relative-pose tables (choosePose.py:43-51, verfication.py:9-19) to 1e-9 relative, ADD to 1e-9, ADD-S to 1e-6 (f32 winners,
-         f64 distances against sklearn's KD-tree) on random poses and clouds."""
+         f64 distances against sklearn's KD-tree) on random poses and clouds.
+  vote / pick  the n x n ADD-S vote with and without the distance-field bounds (every decision farther than 1e-6 mm from the threshold
+         equal to choosePose.py:121-145's) and the consecutive-pair Chamfer pick (verfication.py:61-108) to 1e-9."""
 import sys
 from pathlib import Path
 
@@ -299,9 +301,41 @@ def pose_case(c):
     assert abs(b - br) <= 1e-6 * max(1.0, br), f"pose case {c}: ADD-S {b} / {br}"
 
 
+def vote_pick_case(c):
+    """choosePose.py:98-151 (the n x n ADD-S vote, with and without the distance-field bounds) and verfication.py:61-108 (the
+    consecutive-pair Chamfer pick) against the oracle's loops; perturbations sized so that decisions sit near 0.1 x diameter."""
+    from imagesequenceregistrationfor6dposeestimationlabeling_amd import sequence, synth
+    from oracle import registration_oracle as ro
+    solid = synth.bumpy_ellipsoid if rng.random() < 0.5 else synth.tless_like
+    S = solid(rng, int(rng.integers(200, 2500))).astype(np.float32)
+    V = solid(rng, int(rng.integers(50, 800))).astype(np.float32)
+    diam = synth.diameter(S)
+    n = int(rng.integers(2, 9))
+    Rg, tg = synth.random_poses(rng, n)
+    P = [synth.perturb_pose(rng, Rg[i], tg[i], float(rng.choice([0.5, 3.0, 8.0, 50.0])), float(rng.choice([0.5, 2.0, 0.08 * diam]))) for i in range(n)]
+    Rp, tp = np.array([p[0] for p in P]), np.array([p[1] for p in P])
+    tag = f"vote / pick case {c}: n={n} |S|={len(S)} |V|={len(V)}"
+    rerr, adds = ro.vote(V.astype(np.float64), S.astype(np.float64), ro.rel_pose_table(Rg, tg), ro.rel_pose_table(Rp, tp), diam)
+    # an item within 1e-6 mm of the threshold may fall either way (f32 winners against the KD-tree's f64 ones)
+    sure = np.abs(adds - 0.1 * diam) > 1e-6
+    for bounds in (False, True):
+        img, top, err = sequence.vote_choose_image(V, S, Rg, tg, Rp, tp, diam, bounds=bounds)
+        assert np.array_equal(err[sure], rerr[sure]), f"{tag}: bounds={bounds}: {int((err != rerr)[sure].sum())} decisions differ"
+        if sure.all():
+            assert img == int(np.argmax(rerr.sum(1))), f"{tag}: bounds={bounds}: chosen image {img}"
+    pts = torch.from_numpy(S).to(dev)
+    poses = torch.from_numpy(np.concatenate([Rp, tp[:, :, None]], axis=2).reshape(n, 12)).to(dev)
+    idx, val = sequence.pick_by_chamfer(pts, poses, Rg, tg, n)
+    Rrel = np.array([ro.calculate_relative_pose(Rg[i], tg[i], Rg[i + 1], tg[i + 1])[0] for i in range(n - 1)])
+    ch = ro.chamfer_pairs(S.astype(np.float64), Rp, Rrel)
+    assert abs(val - ch.min()) <= 1e-9 * max(1.0, ch.min()) and abs(ch[idx] - ch.min()) <= 1e-9 * max(1.0, ch.min()), \
+        f"{tag}: pick {idx} {val} / {int(np.argmin(ch))} {ch.min()}"
+
+
 worst = 0.0
 worst_icp = 0.0
 for c in range(cases):
+    vote_pick_case(c)
     prep_case(c)
     pose_case(c)
     crop_case(c)
@@ -312,5 +346,5 @@ for c in range(cases):
     worst_icp = max(worst_icp, icp_case(c))
     if c % 10 == 9:
         print(f"  seed {seed}: {c + 1} cases", flush=True)
-print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac + {cases} filter + {cases} icp + {cases} crop + {cases} prep + {cases} pose cases ok; worst corr value error {worst:.3g} "
+print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac + {cases} filter + {cases} icp + {cases} crop + {cases} prep + {cases} pose + {cases} vote / pick cases ok; worst corr value error {worst:.3g} "
       f"(relative to max(1, |lse|)), worst ICP rotation difference {worst_icp:.3g} rad")
