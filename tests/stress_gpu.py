@@ -26,7 +26,9 @@ routes of K1 and under the nearest-neighbour search.  Per case random shapes (ra
   pnp    the fused PnP + RANSAC call on random sizes (4 ...), hypothesis counts, confidences, thresholds and outlier fractions
          (to 85 %): hypotheses scored, inlier set and pose (1e-4 rad / 1e-3 mm) against oracle/pnp_oracle.py.
   batch cut  the cut + assembly of a group of images with ragged device-side counts (0, 1, 2, 500, 501, P among them) against
-         inference.py:274-290 per image; K1's lse-only call against the full call's lse, torch.equal."""
+         inference.py:274-290 per image; K1's lse-only call against the full call's lse, torch.equal.
+  bounds the distance-field brackets of the vote (isr_adds_bounds) contain the exact ADD-S sums: random clouds, grids of 16-128 cells,
+         poses orthonormal to f32 only, vertices hundreds of millimetres off the grid."""
 import sys
 from pathlib import Path
 
@@ -363,12 +365,21 @@ def pnp_case(c):
     # triples, which can move the stopping stage and the winner: compared where the oracle's winner is its unique best
     if int(r.n_eval.item()) != o["n_eval"] or o["best"] != int(np.argmax(o["n_inl"])) or st != 1:
         return "skipped"
+    if synth.rot_angle(o["Rt_all"][o["best"]][:, :3], R[0]) > 0.2:
+        # the winner is not the planted pose (few hypotheses against 85 % outliers: e.g. an object "seen" 18 m away whose 56
+        # inliers are chance): the refit of such a set has a flat direction and the two implementations drift apart along it
+        return "junk"
     n = int(r.n_inl.item())
     idx = r.inl_idx[:n].cpu().numpy()
     if not np.array_equal(idx, o["inliers"]):
         # a correspondence within 1e-6 px of the threshold under two poses 1e-12 apart may fall either way
         sym = np.setxor1d(idx, o["inliers"])
-        assert len(sym) <= max(2, M // 2000), f"{tag}: inlier sets differ in {len(sym)} of {M}"
+        pose_ = r.pose.cpu().numpy()
+        assert len(sym) <= max(2, M // 2000), (f"{tag}: inlier sets differ in {len(sym)} of {M} ({n} / {len(o['inliers'])}); poses "
+                                               f"{synth.rot_angle(pose_[:, :3], o['Rt'][:, :3]):.3g} rad, {np.linalg.norm(pose_[:, 3] - o['Rt'][:, 3]):.3g} mm apart; best "
+                                               f"hypothesis {o['best']} with {int(o['n_inl'][o['best']])} inliers of {o['n_eval']} scored; planted inliers {int(inl.sum())}; "
+                                               f"t device {pose_[:, 3]}, oracle {o['Rt'][:, 3]}, hypothesis {o['Rt_all'][o['best']][:, 3]}, planted {t[0]}; "
+                                               f"hypothesis / planted rotation {synth.rot_angle(o['Rt_all'][o['best']][:, :3], R[0]):.3g} rad")
     pose = r.pose.cpu().numpy()
     same = np.array_equal(idx, o["inliers"])
     if same and not (synth.rot_angle(pose[:, :3], o["Rt"][:, :3]) < 1e-4 and np.linalg.norm(pose[:, 3] - o["Rt"][:, 3]) < 1e-3):
@@ -384,6 +395,26 @@ def pnp_case(c):
         (f"{tag}: pose {synth.rot_angle(pose[:, :3], o['Rt'][:, :3]):.3g} rad, {np.linalg.norm(pose[:, 3] - o['Rt'][:, 3]):.3g} mm from the "
          f"oracle's; inlier sets equal {same} ({n} / {len(o['inliers'])}, differing in {len(np.setxor1d(idx, o['inliers']))}); best hypothesis "
          f"{o['best']} with {int(o['n_inl'][o['best']])} inliers of {o['n_eval']} scored; planted inliers {int(inl.sum())}")
+
+
+def bounds_case(c):
+    """isr_adds_bounds: the distance-field brackets of an item's ADD-S sum must contain isr_nn_batched's exact sum — rigid poses,
+    poses that are orthonormal only to f32 rounding (pred_R.npy), vertices far off the field's grid."""
+    S = rng.normal(0, float(rng.choice([10.0, 40.0])), (int(rng.integers(50, 4000)), 3)).astype(np.float32)
+    V = (rng.normal(0, float(rng.choice([10.0, 40.0, 120.0])), (int(rng.integers(1, 1500)), 3))).astype(np.float32)
+    B = int(rng.integers(1, 40))
+    Tq = np.stack([rand_pose() for _ in range(B)]); Tt = np.stack([rand_pose() for _ in range(B)])
+    if rng.random() < 0.5:
+        Tt = Tt.astype(np.float32).astype(np.float64)            # orthonormal to f32 only
+    if rng.random() < 0.3:
+        Tq[:, :, 3] += rng.normal(0, 300.0, (B, 3))                # far off the grid
+    fld = ops.dist_field(torch.from_numpy(S).to(dev), cells=int(rng.choice([16, 48, 128])))
+    tq, tt = torch.from_numpy(Tq).to(dev), torch.from_numpy(Tt).to(dev)
+    lb, ub = ops.adds_bounds(torch.from_numpy(V).to(dev), tq, tt, fld)
+    ex = ops.nn_batched(torch.from_numpy(V).to(dev), torch.from_numpy(S).to(dev), tq, tt).sum_d
+    lb, ub, ex = lb.cpu().numpy(), ub.cpu().numpy(), ex.cpu().numpy()
+    assert np.all(np.isfinite(lb)) and np.all(np.isfinite(ub)) and np.all(lb <= ex) and np.all(ex <= ub), \
+        f"bounds case {c}: |S|={len(S)} |V|={len(V)} B={B}: bracket violated by {max((lb - ex).max(), (ex - ub).max()):.3g}"
 
 
 def batch_cut_case(c):
@@ -426,9 +457,10 @@ worst = 0.0
 worst_icp = 0.0
 pnp_skipped = pnp_valley = 0
 for c in range(cases):
+    bounds_case(c)
     batch_cut_case(c)
     rc_ = pnp_case(c)
-    pnp_skipped += rc_ == "skipped"
+    pnp_skipped += rc_ in ("skipped", "junk")
     pnp_valley += rc_ == "valley"
     vote_pick_case(c)
     prep_case(c)
@@ -441,5 +473,5 @@ for c in range(cases):
     worst_icp = max(worst_icp, icp_case(c))
     if c % 10 == 9:
         print(f"  seed {seed}: {c + 1} cases", flush=True)
-print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac + {cases} filter + {cases} icp + {cases} crop + {cases} prep + {cases} pose + {cases} vote / pick + {cases} batch cut + {cases} pnp cases ok ({pnp_skipped} pnp cases not comparable: the two P3P solvers disagreed on a marginal triple; {pnp_valley} compared by reprojection error: an ill-conditioned refit of a poor winner); worst corr value error {worst:.3g} "
+print(f"seed {seed}: {cases} corr + {cases} nn + {cases} ransac + {cases} filter + {cases} icp + {cases} crop + {cases} prep + {cases} pose + {cases} vote / pick + {cases} batch cut + {cases} bounds + {cases} pnp cases ok ({pnp_skipped} pnp cases not comparable: the two P3P solvers disagreed on a marginal triple, or the winner is not the planted pose; {pnp_valley} compared by reprojection error: an ill-conditioned refit of a poor winner); worst corr value error {worst:.3g} "
       f"(relative to max(1, |lse|)), worst ICP rotation difference {worst_icp:.3g} rad")
